@@ -1,0 +1,68 @@
+"""Builds libibgs_rast.so (the gfx950 HIP library behind include/ibgs_rast.h) in-tree with hipcc.
+
+No torch.utils.cpp_extension here: under ROCm it would hipify the sources, and the library has no
+torch types in its ABI anyway.  One hipcc invocation per translation unit (parallel), then a link.
+preprocess.hip is compiled with -ffp-contract=off so its integer outputs are bit-identical to the
+C oracle (see the header of that file).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libibgs_rast.so")
+SOURCES = ["api", "preprocess", "scan_sort", "binning", "render_fwd", "render_bwd", "preprocess_bwd"]
+EXTRA = {"preprocess": ["-ffp-contract=off"]}
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newest_dep():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    deps.append(os.path.join(HERE, "..", "include", "ibgs_rast.h"))
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def needs_build():
+    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_dep()
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, "common.h")),
+                   os.path.getmtime(os.path.join(HERE, "..", "include", "ibgs_rast.h")))
+
+    def compile_one(name):
+        src = os.path.join(CSRC, name + ".hip")
+        obj = os.path.join(OBJ, name + ".o")
+        if (not force) and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            return obj
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-c", src, "-o", obj] + EXTRA.get(name, [])
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,135 @@
+"""ctypes binding of libibgs_rast.so (C ABI declared in include/ibgs_rast.h).
+
+The library is the product path: if it is missing or fails to load this module raises -- there is
+no Python / PyTorch / oracle fallback (a silent fallback would void every parity claim).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libibgs_rast.so")
+
+MAX_SRC = 5
+MAX_BUFFER_LENGTH = 8
+FLAG_DEBUG = 1
+FLAG_TEX_QUANT = 2
+
+c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class ForwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("stream", ctypes.c_void_p),
+        ("P", ctypes.c_int32), ("D", ctypes.c_int32), ("M", ctypes.c_int32),
+        ("W", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("means3D", c_float_p), ("shs", c_float_p), ("colors_precomp", c_float_p), ("opacities", c_float_p),
+        ("scales", c_float_p), ("rotations", c_float_p), ("cov3D_precomp", c_float_p), ("all_map", c_float_p),
+        ("scale_modifier", ctypes.c_float),
+        ("bg", c_float_p), ("viewmatrix", c_float_p), ("projmatrix", c_float_p), ("campos", c_float_p),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float),
+        ("n_src", ctypes.c_int32),
+        ("ref_to_src", c_float_p), ("src_cam_pos", c_float_p), ("src_images", c_float_p), ("src_depths", c_float_p),
+        ("buffer_length", ctypes.c_int32), ("depth_error_threshold", ctypes.c_float),
+        ("prefiltered", ctypes.c_int32), ("render_geo", ctypes.c_int32), ("render_depth_only", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("geom", ctypes.c_void_p), ("geom_bytes", ctypes.c_size_t),
+        ("img", ctypes.c_void_p), ("img_bytes", ctypes.c_size_t),
+        ("binning_alloc", ALLOC_FN), ("binning_user", ctypes.c_void_p),
+        ("tex", ctypes.c_void_p), ("tex_bytes", ctypes.c_size_t),
+        ("out_color", c_float_p), ("radii", ctypes.c_void_p), ("out_normal", c_float_p), ("out_depth", c_float_p),
+        ("out_cam_feat", c_float_p), ("out_warped", c_float_p), ("out_min_depth_diff", c_float_p),
+        ("out_camera_ray", c_float_p), ("out_mask", ctypes.c_void_p),
+    ]
+
+
+class BackwardArgs(ctypes.Structure):
+    _fields_ = [
+        ("stream", ctypes.c_void_p),
+        ("P", ctypes.c_int32), ("D", ctypes.c_int32), ("M", ctypes.c_int32),
+        ("W", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("R", ctypes.c_int64),
+        ("means3D", c_float_p), ("shs", c_float_p), ("colors_precomp", c_float_p),
+        ("scales", c_float_p), ("rotations", c_float_p), ("cov3D_precomp", c_float_p), ("all_map", c_float_p),
+        ("scale_modifier", ctypes.c_float),
+        ("bg", c_float_p), ("viewmatrix", c_float_p), ("projmatrix", c_float_p), ("campos", c_float_p),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float),
+        ("n_src", ctypes.c_int32),
+        ("ref_to_src", c_float_p), ("src_cam_pos", c_float_p), ("src_images", c_float_p), ("src_depths", c_float_p),
+        ("radii", ctypes.c_void_p),
+        ("out_depth", c_float_p), ("out_warped", c_float_p),
+        ("geom", ctypes.c_void_p), ("binning", ctypes.c_void_p), ("img", ctypes.c_void_p),
+        ("tex", ctypes.c_void_p), ("tex_bytes", ctypes.c_size_t),
+        ("dL_dcolor", c_float_p), ("dL_dnormal", c_float_p), ("dL_ddepth", c_float_p), ("dL_dwarped", c_float_p),
+        ("grad_acc", c_float_p),
+        ("dL_dmean2D", c_float_p), ("dL_dmean2D_abs", c_float_p), ("dL_dconic", c_float_p), ("dL_dopacity", c_float_p),
+        ("dL_dcolors", c_float_p), ("dL_dmean3D", c_float_p), ("dL_dcov3D", c_float_p), ("dL_dsh", c_float_p),
+        ("dL_dscale", c_float_p), ("dL_drot", c_float_p), ("dL_dall_map", c_float_p),
+        ("render_geo", ctypes.c_int32), ("flags", ctypes.c_uint32),
+    ]
+
+
+# every symbol include/ibgs_rast.h declares
+EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "ibgs_required_tex",
+           "ibgs_forward", "ibgs_backward", "ibgs_mark_visible",
+           "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
+           "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args",
+           "ibgs_last_error", "ibgs_version"]
+
+_lib = None
+
+
+class RasterizerLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libibgs_rast.so (after torch, so that the HIP runtime torch ships is the one in use)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RasterizerLibraryError(
+            "libibgs_rast.so is not built (%s). Run `python -m ibgs_amd._build` or __graft_entry__.build(); "
+            "there is no fallback path." % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64 first; both sides then share one HIP runtime)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RasterizerLibraryError("libibgs_rast.so lacks symbol %s" % name)
+    lib.ibgs_required_geom.restype = ctypes.c_size_t
+    lib.ibgs_required_geom.argtypes = [ctypes.c_int32]
+    lib.ibgs_required_img.restype = ctypes.c_size_t
+    lib.ibgs_required_img.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.ibgs_required_binning.restype = ctypes.c_size_t
+    lib.ibgs_required_binning.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    lib.ibgs_required_tex.restype = ctypes.c_size_t
+    lib.ibgs_required_tex.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    lib.ibgs_forward.restype = ctypes.c_int64
+    lib.ibgs_forward.argtypes = [ctypes.POINTER(ForwardArgs)]
+    lib.ibgs_backward.restype = ctypes.c_int32
+    lib.ibgs_backward.argtypes = [ctypes.POINTER(BackwardArgs)]
+    lib.ibgs_mark_visible.restype = ctypes.c_int32
+    lib.ibgs_mark_visible.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+    for f in (lib.ibgs_geom_offset,):
+        f.restype = ctypes.c_int64
+        f.argtypes = [ctypes.c_int32, ctypes.c_char_p]
+    lib.ibgs_img_offset.restype = ctypes.c_int64
+    lib.ibgs_img_offset.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p]
+    lib.ibgs_binning_offset.restype = ctypes.c_int64
+    lib.ibgs_binning_offset.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p]
+    lib.ibgs_last_error.restype = ctypes.c_char_p
+    lib.ibgs_version.restype = ctypes.c_char_p
+    lib.ibgs_sizeof_forward_args.restype = ctypes.c_size_t
+    lib.ibgs_sizeof_backward_args.restype = ctypes.c_size_t
+    if (lib.ibgs_sizeof_forward_args() != ctypes.sizeof(ForwardArgs)
+            or lib.ibgs_sizeof_backward_args() != ctypes.sizeof(BackwardArgs)):
+        raise RasterizerLibraryError("ctypes struct layout does not match libibgs_rast.so (stale build?)")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().ibgs_last_error().decode("utf-8", "replace")

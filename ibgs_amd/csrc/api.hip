@@ -1,0 +1,255 @@
+// C-ABI entry points and stage orchestration (include/ibgs_rast.h).
+//
+// Stage order of one forward (compare CudaRasterizer::Rasterizer::forward,
+// DPR/cuda_rasterizer/rasterizer_impl.cu:320-515):
+//   preprocess -> depth sort of the P Gaussians (4 x 8-bit LSD passes) -> tiles-touched scan in
+//   depth order -> R read-back (the only host sync, as in the reference :430) -> load-balanced
+//   duplicate emission -> stable tile-id sort (ceil(bits/8) passes) -> tile ranges -> render.
+// Everything is enqueued on the caller's stream; no device-wide synchronisation, no allocation
+// (arenas are caller-owned), no persistent library state.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace ibgs {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static uint32_t higher_msb(uint32_t n)
+{   // rasterizer_impl.cu:152-167
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+GeomState GeomState::carve(char* base, size_t P, size_t* total)
+{
+    Carver c(base);
+    GeomState g;
+    g.rec = c.take<float>(P * REC_FLOATS);
+    g.depths = c.take<float>(P);
+    g.cov3D = c.take<float>(P * 6);
+    g.tiles = c.take<uint32_t>(P);
+    g.rect = c.take<uint32_t>(P * 2);
+    g.clamped = c.take<uint8_t>(P);
+    g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
+    g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
+    g.offsets = c.take<uint32_t>(P + 1);
+    g.hist_elems = radix_hist_elems(P);
+    g.hist = c.take<uint32_t>(g.hist_elems);
+    if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
+    return g;
+}
+
+ImgState ImgState::carve(char* base, int W, int H, size_t* total)
+{
+    Carver c(base);
+    ImgState im;
+    const size_t HW = (size_t)W * H;
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    im.ranges = c.take<uint32_t>(tiles * 2);
+    im.final_T = c.take<float>(HW);
+    im.n_contrib = c.take<uint32_t>(HW);
+    im.sum_w = c.take<float>(HW);
+    im.low_high = c.take<uint32_t>(HW * 2);
+    im.valid_idx = c.take<int32_t>(HW * IBGS_MAX_SRC);
+    im.valid_w = c.take<float>(HW * IBGS_MAX_SRC);
+    if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
+    return im;
+}
+
+BinState BinState::carve(char* base, size_t R, int W, int H, size_t* total)
+{
+    (void)W; (void)H;
+    Carver c(base);
+    BinState b;
+    b.keys[0] = c.take<uint32_t>(R); b.keys[1] = c.take<uint32_t>(R);
+    b.vals[0] = c.take<uint32_t>(R); b.vals[1] = c.take<uint32_t>(R);
+    b.point_list = b.vals[0];            // the tile sort leaves its result in buffer 0
+    b.hist_elems = radix_hist_elems(R);
+    b.hist = c.take<uint32_t>(b.hist_elems);
+    if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
+    return b;
+}
+
+static int stage_check(hipStream_t s, bool debug, const char* what)
+{
+    if (!debug) return 0;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { set_error("stage '%s' failed: %s", what, hipGetErrorString(e)); return -IBGS_ERR_HIP; }
+    return 0;
+}
+
+}  // namespace ibgs
+
+using namespace ibgs;
+
+extern "C" {
+
+const char* ibgs_last_error(void) { return g_err; }
+const char* ibgs_version(void) { return "ibgs_rast 0.1 (gfx950)"; }
+size_t ibgs_sizeof_forward_args(void) { return sizeof(ibgs_forward_args); }
+size_t ibgs_sizeof_backward_args(void) { return sizeof(ibgs_backward_args); }
+
+size_t ibgs_required_geom(int32_t P) { size_t t; GeomState::carve(nullptr, (size_t)(P > 0 ? P : 0), &t); return t; }
+size_t ibgs_required_img(int32_t W, int32_t H) { size_t t; ImgState::carve(nullptr, W, H, &t); return t; }
+size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H) { size_t t; BinState::carve(nullptr, (size_t)(R > 0 ? R : 0), W, H, &t); return t; }
+size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H) { return (size_t)n_src * W * H * sizeof(float4) + 128; }
+
+#define OFF(base_struct, field) if (!strcmp(name, #field)) return (int64_t)((char*)base_struct.field - (char*)nullptr)
+int64_t ibgs_geom_offset(int32_t P, const char* name)
+{
+    size_t t; GeomState g = GeomState::carve(nullptr, (size_t)P, &t);
+    OFF(g, rec); OFF(g, depths); OFF(g, cov3D); OFF(g, tiles); OFF(g, rect); OFF(g, clamped); OFF(g, offsets);
+    if (!strcmp(name, "order")) return (int64_t)((char*)g.sort_val[0] - (char*)nullptr);
+    if (!strcmp(name, "sorted_depth_keys")) return (int64_t)((char*)g.sort_key[0] - (char*)nullptr);
+    return -1;
+}
+int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
+{
+    size_t t; ImgState im = ImgState::carve(nullptr, W, H, &t);
+    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w);
+    return -1;
+}
+int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
+{
+    size_t t; BinState b = BinState::carve(nullptr, (size_t)R, W, H, &t);
+    OFF(b, point_list);
+    if (!strcmp(name, "sorted_tile_keys")) return (int64_t)((char*)b.keys[0] - (char*)nullptr);
+    return -1;
+}
+#undef OFF
+
+int64_t ibgs_forward(const ibgs_forward_args* ap)
+{
+    if (!ap) { set_error("null args"); return -IBGS_ERR_INVALID; }
+    const ibgs_forward_args& a = *ap;
+    hipStream_t s = reinterpret_cast<hipStream_t>(a.stream);
+    const bool debug = (a.flags & IBGS_FLAG_DEBUG) != 0;
+    if (a.P < 0 || a.W <= 0 || a.H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a.P, a.W, a.H); return -IBGS_ERR_INVALID; }
+    if (a.P == 0) return 0;                                     // rasterize_points.cu:101-102
+    if (!a.means3D || !a.opacities || !a.viewmatrix || !a.projmatrix || !a.campos || !a.bg || !a.radii) {
+        set_error("missing required pointer"); return -IBGS_ERR_INVALID;
+    }
+    if ((a.shs == nullptr) == (a.colors_precomp == nullptr) && !a.render_depth_only) {
+        set_error("provide exactly one of shs / colors_precomp"); return -IBGS_ERR_INVALID;
+    }
+    if (((a.scales == nullptr) || (a.rotations == nullptr)) == (a.cov3D_precomp == nullptr)) {
+        set_error("provide exactly one of scales+rotations / cov3D_precomp"); return -IBGS_ERR_INVALID;
+    }
+    if (a.shs && (a.D < 0 || a.D > 3 || (a.D + 1) * (a.D + 1) > a.M)) { set_error("bad SH degree D=%d M=%d", a.D, a.M); return -IBGS_ERR_INVALID; }
+    if (a.render_geo && a.render_depth_only) { set_error("render_geo together with render_depth_only is not supported"); return -IBGS_ERR_INVALID; }
+    if ((a.render_geo || a.render_depth_only) && !a.all_map) { set_error("all_map is required for render_geo / render_depth_only"); return -IBGS_ERR_INVALID; }
+    if (a.render_geo || a.render_depth_only) {
+        if (a.buffer_length < 1 || a.buffer_length > IBGS_MAX_BUFFER_LENGTH) { set_error("buffer_length %d outside 1..%d", a.buffer_length, IBGS_MAX_BUFFER_LENGTH); return -IBGS_ERR_INVALID; }
+        if (!a.out_depth) { set_error("out_depth required"); return -IBGS_ERR_INVALID; }
+    }
+    if (a.render_geo) {
+        if (a.n_src < 1 || a.n_src > IBGS_MAX_SRC) { set_error("n_src %d outside 1..%d", a.n_src, IBGS_MAX_SRC); return -IBGS_ERR_INVALID; }
+        if (!a.ref_to_src || !a.src_cam_pos || !a.src_images || !a.src_depths) { set_error("source view pointers required for render_geo"); return -IBGS_ERR_INVALID; }
+        if (!a.out_normal || !a.out_cam_feat || !a.out_warped || !a.out_min_depth_diff || !a.out_camera_ray || !a.out_mask) { set_error("geo outputs required"); return -IBGS_ERR_INVALID; }
+        if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
+    }
+    if (!a.render_depth_only && !a.out_color) { set_error("out_color required"); return -IBGS_ERR_INVALID; }
+    if (!a.geom || a.geom_bytes < ibgs_required_geom(a.P)) { set_error("geom arena too small"); return -IBGS_ERR_ALLOC; }
+    if (!a.img || a.img_bytes < ibgs_required_img(a.W, a.H)) { set_error("img arena too small"); return -IBGS_ERR_ALLOC; }
+    if (!a.binning_alloc) { set_error("binning_alloc callback required"); return -IBGS_ERR_INVALID; }
+
+    int rc;
+    GeomState g = GeomState::carve(a.geom, (size_t)a.P, nullptr);
+    ImgState im = ImgState::carve(a.img, a.W, a.H, nullptr);
+    const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
+
+    if ((rc = launch_preprocess(s, a, g))) return rc;
+    if ((rc = stage_check(s, debug, "preprocess"))) return rc;
+    if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)a.P, 32, g.hist, g.hist_elems))) return rc;
+    if ((rc = stage_check(s, debug, "depth sort"))) return rc;
+    if ((rc = launch_gather_tiles(s, a.P, g))) return rc;
+    if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)a.P, g.hist, g.hist_elems, true))) return rc;
+    uint32_t R32 = 0;
+    IBGS_HIP(hipMemcpyAsync(&R32, g.offsets + a.P, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    IBGS_HIP(hipStreamSynchronize(s));
+    const int64_t R = (int64_t)R32;
+
+    char* bin_mem = a.binning_alloc(ibgs_required_binning(R, a.W, a.H), a.binning_user);
+    if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)R); return -IBGS_ERR_ALLOC; }
+    BinState b = BinState::carve(bin_mem, (size_t)R, a.W, a.H, nullptr);
+
+    if ((rc = launch_emit(s, a.P, R, gx, g, b))) return rc;
+    if ((rc = stage_check(s, debug, "emit"))) return rc;
+    const int bit = (int)higher_msb((uint32_t)(gx * gy));
+    if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)R, bit, b.hist, b.hist_elems))) return rc;
+    if ((rc = stage_check(s, debug, "tile sort"))) return rc;
+    if ((rc = launch_ranges(s, R, gx * gy, b.keys[0], im.ranges))) return rc;
+    if ((rc = stage_check(s, debug, "ranges"))) return rc;
+
+    const float4* rgba = nullptr;
+    if (a.render_geo) {
+        float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
+        if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
+        rgba = t;
+    }
+    if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc;
+    if ((rc = stage_check(s, debug, "render"))) return rc;
+    return R;
+}
+
+int32_t ibgs_backward(const ibgs_backward_args* ap)
+{
+    if (!ap) { set_error("null args"); return -IBGS_ERR_INVALID; }
+    const ibgs_backward_args& a = *ap;
+    hipStream_t s = reinterpret_cast<hipStream_t>(a.stream);
+    const bool debug = (a.flags & IBGS_FLAG_DEBUG) != 0;
+    if (a.P <= 0) return 0;                                       // rasterize_points.cu:221
+    if (!a.geom || !a.img || (!a.binning && a.R > 0)) { set_error("backward needs the forward's arenas"); return -IBGS_ERR_INVALID; }
+    if (!a.grad_acc) { set_error("grad_acc scratch required"); return -IBGS_ERR_INVALID; }
+    if (!a.dL_dmean2D || !a.dL_dmean2D_abs || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmean3D || !a.dL_dcov3D) {
+        set_error("missing gradient output"); return -IBGS_ERR_INVALID;
+    }
+    if (a.shs && !a.dL_dsh) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
+    if (a.scales && (!a.dL_dscale || !a.dL_drot)) { set_error("dL_dscale / dL_drot required"); return -IBGS_ERR_INVALID; }
+    if (a.render_geo) {
+        if (!a.all_map || !a.dL_dall_map || !a.out_depth || !a.out_warped || !a.ref_to_src || !a.src_images) { set_error("geo backward inputs missing"); return -IBGS_ERR_INVALID; }
+        if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
+    }
+    int rc;
+    GeomState g = GeomState::carve(a.geom, (size_t)a.P, nullptr);
+    ImgState im = ImgState::carve(a.img, a.W, a.H, nullptr);
+    BinState b = BinState::carve(a.binning, (size_t)a.R, a.W, a.H, nullptr);
+    const float4* rgba = nullptr;
+    if (a.render_geo) {
+        float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
+        if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
+        rgba = t;
+    }
+    if (a.R > 0) {
+        if ((rc = launch_render_backward(s, a, g, b, im, rgba))) return rc;
+        if ((rc = stage_check(s, debug, "render backward"))) return rc;
+    }
+    if ((rc = launch_preprocess_backward(s, a, g))) return rc;
+    if ((rc = stage_check(s, debug, "preprocess backward"))) return rc;
+    return 0;
+}
+
+int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
+                          const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;
+    if (P <= 0) return 0;
+    if (!means3D || !viewmatrix || !present) { set_error("null pointer"); return -IBGS_ERR_INVALID; }
+    return launch_mark_visible(reinterpret_cast<hipStream_t>(stream), P, means3D, viewmatrix, present);
+}
+
+}  // extern "C"

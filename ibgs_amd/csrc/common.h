@@ -1,0 +1,129 @@
+// Shared declarations for the gfx950 plane rasterizer (internal; the public ABI is include/ibgs_rast.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ibgs_rast.h"
+
+namespace ibgs {
+
+constexpr int TILE = IBGS_TILE;
+constexpr int WAVE = 64;
+constexpr int REC_FLOATS = 16;   // one 64-byte record per Gaussian (see GaussRec)
+constexpr int GACC_FLOATS = 16;  // one 64-byte gradient accumulation row per Gaussian
+
+// Field indices of the per-Gaussian render record written by preprocess and staged (as 16-byte
+// quads) by the render kernels.  Quad 0 = {x, y, opacity, pad}, quad 1 = {conic a,b,c, dist},
+// quad 2 = {r,g,b, pad}, quad 3 = {nx,ny,nz, pad}.
+enum RecField { R_X = 0, R_Y = 1, R_OP = 2, R_PAD0 = 3, R_CA = 4, R_CB = 5, R_CC = 6, R_DIST = 7,
+                R_R = 8, R_G = 9, R_B = 10, R_PAD1 = 11, R_NX = 12, R_NY = 13, R_NZ = 14, R_PAD2 = 15 };
+
+// Columns of the gradient accumulation row (render backward -> preprocess backward).
+enum GaccField { G_MX = 0, G_MY = 1, G_AX = 2, G_AY = 3, G_CA = 4, G_CB = 5, G_CC = 6, G_OP = 7,
+                 G_R = 8, G_G = 9, G_B = 10, G_NX = 11, G_NY = 12, G_NZ = 13, G_DIST = 14, G_PAD = 15 };
+
+struct Carver {   // 128-byte aligned carve-up of a caller-owned arena (or size computation with base==0)
+    uintptr_t cur;
+    explicit Carver(char* base) : cur(reinterpret_cast<uintptr_t>(base)) {}
+    template <typename T> T* take(size_t count) {
+        cur = (cur + 127) & ~uintptr_t(127);
+        T* p = reinterpret_cast<T*>(cur);
+        cur += count * sizeof(T);
+        return p;
+    }
+};
+
+struct GeomState {
+    float* rec;            // P x 16
+    float* depths;         // P
+    float* cov3D;          // P x 6
+    uint32_t* tiles;       // P   tiles touched
+    uint32_t* rect;        // P x 2  (x0 | x1<<16, y0 | y1<<16)
+    uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
+    uint32_t* sort_key[2]; // P   depth keys (ping-pong)
+    uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered
+    uint32_t* offsets;     // P+1 exclusive scan of tiles in depth order
+    uint32_t* hist;        // radix histogram + scan scratch
+    size_t hist_elems;
+    static GeomState carve(char* base, size_t P, size_t* total);
+};
+
+struct ImgState {
+    uint32_t* ranges;      // tiles x 2
+    float* final_T;        // HW
+    uint32_t* n_contrib;   // HW
+    float* sum_w;          // HW   (geo) sum of median buffer weights
+    uint32_t* low_high;    // HW x 2 (geo) min / max contributor of the median buffer
+    int32_t* valid_idx;    // 5 x HW (geo)
+    float* valid_w;        // 5 x HW (geo)
+    static ImgState carve(char* base, int W, int H, size_t* total);
+};
+
+struct BinState {
+    uint32_t* point_list;  // R   sorted Gaussian ids (final)
+    uint32_t* keys[2];     // R   tile ids (ping-pong)
+    uint32_t* vals[2];     // R   Gaussian ids (ping-pong)
+    uint32_t* hist;        // radix histogram + scan scratch
+    size_t hist_elems;
+    static BinState carve(char* base, size_t R, int W, int H, size_t* total);
+};
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define IBGS_HIP(expr)                                                                    \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ::ibgs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -IBGS_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
+// ---- host launchers (one per stage) ---------------------------------------------------------
+struct Cam {          // camera block handed to kernels by value; matrices stay in device memory
+    const float* vm;      // 16, transposed world->view   (wave-uniform reads -> scalar loads)
+    const float* pm;      // 16, transposed full projection
+    const float* campos;  // 3
+    const float* bg;      // 3
+    float tanfovx, tanfovy, fx, fy;
+    int W, H, gx, gy;
+};
+inline Cam make_cam(const float* vm, const float* pm, const float* campos, const float* bg,
+                    float tanfovx, float tanfovy, int W, int H)
+{
+    Cam c;
+    c.vm = vm; c.pm = pm; c.campos = campos; c.bg = bg;
+    c.tanfovx = tanfovx; c.tanfovy = tanfovy;
+    c.fy = H / (2.0f * tanfovy); c.fx = W / (2.0f * tanfovx);   // rasterizer_impl.cu:362-363
+    c.W = W; c.H = H; c.gx = (W + TILE - 1) / TILE; c.gy = (H + TILE - 1) / TILE;
+    return c;
+}
+
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g);
+int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
+
+// device-wide primitives (scan_sort.hip)
+size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by radix_sort_pairs on n items
+// Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
+int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
+                     uint32_t* hist, size_t hist_elems);
+// Exclusive scan of `n` uint32 (in place allowed); out[n] receives the total when with_total.
+int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch,
+                       size_t scratch_elems, bool with_total);
+size_t scan_scratch_elems(size_t n);
+
+int launch_gather_tiles(hipStream_t s, int P, const GeomState& g);   // tiles in depth order -> offsets input
+int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b);
+int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges);
+
+int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
+int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
+                          const ImgState& im, const float4* src_rgba);
+int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
+                           const ImgState& im, const float4* src_rgba);
+int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g);
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_rect(int lo, int hi) { return (uint32_t)lo | ((uint32_t)hi << 16); }
+
+}  // namespace ibgs

@@ -1,0 +1,244 @@
+// A1 / V1: per-Gaussian projection, EWA covariance, SH -> RGB, tile rectangle.
+//
+// Behaviour follows the reference's preprocessCUDA / computeCov3D / computeCov2D /
+// computeColorFromSH / in_frustum / getRect (DPR/cuda_rasterizer/forward.cu:58-295,
+// auxiliary.h:45-60, 143-168) but is organised for gfx950: the per-Gaussian results that the
+// blend kernels need are packed into ONE 64-byte record (struct-of-quads) so that the render
+// kernels stage a Gaussian with 16-byte loads from a single cache line, instead of the reference's
+// five separate arrays (means2D, conic_opacity, rgb, all_map, depths).
+//
+// This translation unit is compiled with -ffp-contract=off and uses IEEE divide / sqrt so that
+// radii, tile rectangles and the record values are bit-identical to the scalar C oracle
+// (oracle/ibgs_oracle.c: orc_preprocess) -- the integer outputs (radii, tiles touched) are
+// parity-tested exactly.
+#include "common.h"
+
+namespace ibgs {
+
+__constant__ float kC0 = 0.28209479177387814f;
+__constant__ float kC1 = 0.4886025119029199f;
+__constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                             -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                             -0.5900435899266435f};
+
+struct PreParams {
+    int P, D, M;
+    const float* means3D; const float* scales; const float* rotations; const float* opacities;
+    const float* shs; const float* cov3D_precomp; const float* colors_precomp; const float* all_map;
+    float scale_modifier;
+    int depth_only;
+    int32_t* radii;
+    float* rec; float* depths; float* cov3D; uint32_t* tiles; uint32_t* rect; uint8_t* clamped;
+    uint32_t* sort_key; uint32_t* sort_val;
+};
+
+__device__ __forceinline__ float ndc_to_pix(float v, int S)
+{   // auxiliary.h:45-48: evaluated in double because of the double literals
+    return (float)((((double)v + 1.0) * S - 1.0) * 0.5);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
+
+// One thread per Gaussian. The AoS inputs (12..192 B per Gaussian) are read with plain per-lane
+// loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
+__global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.P) return;
+
+    // defaults: culled Gaussians keep radius 0, zero tiles and sort last
+    float rec[REC_FLOATS];
+#pragma unroll
+    for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
+    int radius = 0; uint32_t ntiles = 0; uint32_t rx = 0, ry = 0; float depth = 0.f; uint8_t clampbits = 0;
+    float c6loc[6] = {0, 0, 0, 0, 0, 0};
+
+    const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
+    const float* __restrict__ vm = cam.vm; const float* __restrict__ pm = cam.pm;
+    const float hx = pm[0] * px3 + pm[4] * py3 + pm[8] * pz3 + pm[12];
+    const float hy = pm[1] * px3 + pm[5] * py3 + pm[9] * pz3 + pm[13];
+    const float hw = pm[3] * px3 + pm[7] * py3 + pm[11] * pz3 + pm[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float zview = vm[2] * px3 + vm[6] * py3 + vm[10] * pz3 + vm[14];
+
+    bool alive = zview > 0.2f;   // !(z <= 0.2) differs only for NaN, which is culled either way
+    if (alive) {
+        // ---- 3D covariance (upper triangle) ----
+        if (p.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6loc[k] = p.cov3D_precomp[6 * i + k];
+        } else {
+            const float r = p.rotations[4 * i], x = p.rotations[4 * i + 1], y = p.rotations[4 * i + 2], z = p.rotations[4 * i + 3];
+            float R[3][3];
+            R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z);       R[0][2] = 2.f * (x * z + r * y);
+            R[1][0] = 2.f * (x * y + r * z);       R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+            R[2][0] = 2.f * (x * z - r * y);       R[2][1] = 2.f * (y * z + r * x);       R[2][2] = 1.f - 2.f * (x * x + y * y);
+            const float sv[3] = {p.scale_modifier * p.scales[3 * i], p.scale_modifier * p.scales[3 * i + 1],
+                                 p.scale_modifier * p.scales[3 * i + 2]};
+            float Mm[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) Mm[a][b] = sv[a] * R[b][a];
+#define SIG(a, b) (Mm[0][a] * Mm[0][b] + Mm[1][a] * Mm[1][b] + Mm[2][a] * Mm[2][b])
+            c6loc[0] = SIG(0, 0); c6loc[1] = SIG(0, 1); c6loc[2] = SIG(0, 2);
+            c6loc[3] = SIG(1, 1); c6loc[4] = SIG(1, 2); c6loc[5] = SIG(2, 2);
+#undef SIG
+        }
+        // ---- EWA 2D covariance ----
+        float t0 = vm[0] * px3 + vm[4] * py3 + vm[8] * pz3 + vm[12];
+        float t1 = vm[1] * px3 + vm[5] * py3 + vm[9] * pz3 + vm[13];
+        const float t2 = vm[2] * px3 + vm[6] * py3 + vm[10] * pz3 + vm[14];
+        const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+        const float txtz = t0 / t2, tytz = t1 / t2;
+        t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+        t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+        const float j00 = cam.fx / t2, j02 = -(cam.fx * t0) / (t2 * t2);
+        const float j11 = cam.fy / t2, j12 = -(cam.fy * t1) / (t2 * t2);
+        float A[2][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float rv0 = vm[4 * r + 0], rv1 = vm[4 * r + 1], rv2 = vm[4 * r + 2];
+            A[0][r] = rv0 * j00 + rv1 * 0.0f + rv2 * j02;
+            A[1][r] = rv0 * 0.0f + rv1 * j11 + rv2 * j12;
+        }
+        const float S[3][3] = {{c6loc[0], c6loc[1], c6loc[2]}, {c6loc[1], c6loc[3], c6loc[4]}, {c6loc[2], c6loc[4], c6loc[5]}};
+        float SA[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) SA[a][r] = S[r][0] * A[a][0] + S[r][1] * A[a][1] + S[r][2] * A[a][2];
+        const float ca = A[0][0] * SA[0][0] + A[0][1] * SA[0][1] + A[0][2] * SA[0][2] + 0.3f;
+        const float cb = A[0][0] * SA[1][0] + A[0][1] * SA[1][1] + A[0][2] * SA[1][2];
+        const float cc = A[1][0] * SA[1][0] + A[1][1] * SA[1][1] + A[1][2] * SA[1][2] + 0.3f;
+        const float det = ca * cc - cb * cb;
+        alive = (det != 0.0f);
+        if (alive) {
+            const float det_inv = 1.f / det;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lam1 = mid + disc, lam2 = mid - disc;
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+            const float pxs = ndc_to_pix(hx * pw, cam.W), pys = ndc_to_pix(hy * pw, cam.H);
+            const int rad = (int)my_radius;
+            const int x0 = clampi((int)((pxs - rad) / TILE), 0, cam.gx);
+            const int y0 = clampi((int)((pys - rad) / TILE), 0, cam.gy);
+            const int x1 = clampi((int)((pxs + rad + TILE - 1) / TILE), 0, cam.gx);
+            const int y1 = clampi((int)((pys + rad + TILE - 1) / TILE), 0, cam.gy);
+            alive = ((x1 - x0) * (y1 - y0)) != 0;
+            if (alive) {
+                radius = rad; ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+                rx = pack_rect(x0, x1); ry = pack_rect(y0, y1);
+                depth = zview;
+                rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
+                rec[R_CA] = cc * det_inv; rec[R_CB] = -cb * det_inv; rec[R_CC] = ca * det_inv;
+                if (p.colors_precomp) {
+                    rec[R_R] = p.colors_precomp[3 * i]; rec[R_G] = p.colors_precomp[3 * i + 1]; rec[R_B] = p.colors_precomp[3 * i + 2];
+                } else if (!p.depth_only) {
+                    // ---- SH -> RGB ----
+                    float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2 = pz3 - cam.campos[2];
+                    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                    d0 /= len; d1 /= len; d2 /= len;
+                    float B[16];
+                    int nb = 1;
+                    B[0] = kC0;
+                    if (p.D > 0) {
+                        const float x = d0, y = d1, z = d2;
+                        B[1] = -kC1 * y; B[2] = kC1 * z; B[3] = -kC1 * x; nb = 4;
+                        if (p.D > 1) {
+                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                            B[4] = kC2[0] * xy; B[5] = kC2[1] * yz; B[6] = kC2[2] * (2.0f * zz - xx - yy);
+                            B[7] = kC2[3] * xz; B[8] = kC2[4] * (xx - yy); nb = 9;
+                            if (p.D > 2) {
+                                B[9] = kC3[0] * y * (3.0f * xx - yy);
+                                B[10] = kC3[1] * xy * z;
+                                B[11] = kC3[2] * y * (4.0f * zz - xx - yy);
+                                B[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                                B[13] = kC3[4] * x * (4.0f * zz - xx - yy);
+                                B[14] = kC3[5] * z * (xx - yy);
+                                B[15] = kC3[6] * x * (xx - 3.0f * yy);
+                                nb = 16;
+                            }
+                        }
+                    }
+                    const float* sh = p.shs + (size_t)i * p.M * 3;
+                    float col[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) col[ch] = B[0] * sh[ch];
+                    for (int k = 1; k < nb; k++) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) col[ch] = col[ch] + B[k] * sh[3 * k + ch];
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float v = col[ch] + 0.5f;
+                        if (v < 0) clampbits |= (uint8_t)(1u << ch);
+                        rec[R_R + ch] = fmaxf(v, 0.0f);
+                    }
+                }
+                if (p.all_map) {
+                    rec[R_NX] = p.all_map[5 * i]; rec[R_NY] = p.all_map[5 * i + 1]; rec[R_NZ] = p.all_map[5 * i + 2];
+                    rec[R_DIST] = p.all_map[5 * i + 4];
+                }
+            }
+        }
+    }
+    if (!alive) {
+#pragma unroll
+        for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
+    }
+
+    p.radii[i] = radius;
+    p.tiles[i] = ntiles;
+    p.rect[2 * i] = rx; p.rect[2 * i + 1] = ry;
+    p.depths[i] = depth;
+    p.clamped[i] = clampbits;
+    if (!p.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) p.cov3D[6 * i + k] = c6loc[k];   // computed for every Gaussian past the near cull
+    }
+    float4* out = reinterpret_cast<float4*>(p.rec + (size_t)i * REC_FLOATS);
+    out[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+    out[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+    out[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
+    out[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    // depth sort input: positive float bits order like the floats; culled Gaussians sort last
+    p.sort_key[i] = alive ? __float_as_uint(depth) : 0xFFFFFFFFu;
+    p.sort_val[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present)
+{   // checkFrustum, rasterizer_impl.cu:171-183 (only the z test is live, auxiliary.h:158)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float z = cam.vm[2] * means3D[3 * i] + cam.vm[6] * means3D[3 * i + 1] + cam.vm[10] * means3D[3 * i + 2] + cam.vm[14];
+    present[i] = z > 0.2f ? 1 : 0;
+}
+
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g)
+{
+    PreParams p;
+    p.P = a.P; p.D = a.D; p.M = a.M;
+    p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
+    p.shs = a.shs; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
+    p.scale_modifier = a.scale_modifier; p.depth_only = a.render_depth_only;
+    p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.rect = g.rect;
+    p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0];
+    const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
+    const int blocks = (a.P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p, cam);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present)
+{
+    const Cam cam = make_cam(vm, nullptr, nullptr, nullptr, 1.f, 1.f, 16, 16);
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, cam, present);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ibgs

@@ -1,0 +1,252 @@
+// B3 + B4: per-Gaussian backward -- conic -> 3D covariance / mean, 2D mean -> 3D mean, RGB -> SH,
+// 3D covariance -> scale / rotation.
+//
+// Behaviour: DPR/cuda_rasterizer/backward.cu:241-371 (computeCov2DCUDA), 443-493 (preprocessCUDA),
+// 116-235 (computeColorFromSH backward), 375-438 (computeCov3D backward).  The reference runs two
+// kernels and reads gradients from five atomically-accumulated arrays; here one fused kernel reads
+// the 64-byte accumulation row written by render_bwd.hip (one coalesced line per Gaussian) and writes
+// every output of the operator in the reference's layout (rasterize_points.cu:209-219).
+#include "common.h"
+
+namespace ibgs {
+
+__constant__ float bC1 = 0.4886025119029199f;
+__constant__ float bC0 = 0.28209479177387814f;
+__constant__ float bC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                             -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                             0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                             -0.5900435899266435f};
+
+struct PreBwdParams {
+    int P, D, M;
+    const float* means3D; const int32_t* radii; const float* shs; const uint8_t* clamped;
+    const float* scales; const float* rotations; float scale_modifier;
+    const float* cov3D;        // precomputed input or the forward's computed one
+    const float* gacc;         // P x 16
+    float* dL_dmean2D; float* dL_dmean2D_abs; float* dL_dconic; float* dL_dopacity; float* dL_dcolors;
+    float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+};
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam cam)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.P) return;
+    if (!(p.radii[i] > 0)) return;      // outputs arrive zeroed
+
+    const float4* grow = reinterpret_cast<const float4*>(p.gacc + (size_t)i * GACC_FLOATS);
+    const float4 g0 = grow[0], g1 = grow[1], g2 = grow[2], g3 = grow[3];
+    const float g2x = g0.x, g2y = g0.y;            // dL/dmean2D
+    const float gcx = g1.x, gcy = g1.y, gcz = g1.z; // dL/dconic (a, b, c)
+    const float gcol[3] = {g2.x, g2.y, g2.z};
+
+    p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y;
+    p.dL_dmean2D_abs[3 * i] = g0.z; p.dL_dmean2D_abs[3 * i + 1] = g0.w;
+    if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 3] = gcz; }
+    p.dL_dopacity[i] = g1.w;
+    p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2];
+    if (p.dL_dall_map) {
+        p.dL_dall_map[5 * i] = g2.w; p.dL_dall_map[5 * i + 1] = g3.x; p.dL_dall_map[5 * i + 2] = g3.y;
+        p.dL_dall_map[5 * i + 4] = g3.z;
+    }
+
+    const float* __restrict__ vm = cam.vm; const float* __restrict__ pm = cam.pm;
+    const float mean[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = p.cov3D[6 * i + k];
+
+    // ---- cov2D backward ----
+    float t[3] = {vm[0] * mean[0] + vm[4] * mean[1] + vm[8] * mean[2] + vm[12],
+                  vm[1] * mean[0] + vm[5] * mean[1] + vm[9] * mean[2] + vm[13],
+                  vm[2] * mean[0] + vm[6] * mean[1] + vm[10] * mean[2] + vm[14]};
+    const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+    const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float fx = cam.fx, fy = cam.fy;
+    const float j00 = fx / t[2], j02 = -(fx * t[0]) / (t[2] * t[2]);
+    const float j11 = fy / t[2], j12 = -(fy * t[1]) / (t[2] * t[2]);
+    float A[2][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float rv0 = vm[4 * r + 0], rv1 = vm[4 * r + 1], rv2 = vm[4 * r + 2];
+        A[0][r] = rv0 * j00 + rv1 * 0.0f + rv2 * j02;
+        A[1][r] = rv0 * 0.0f + rv1 * j11 + rv2 * j12;
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float SA[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) SA[a][r] = S[r][0] * A[a][0] + S[r][1] * A[a][1] + S[r][2] * A[a][2];
+    const float a_ = A[0][0] * SA[0][0] + A[0][1] * SA[0][1] + A[0][2] * SA[0][2] + 0.3f;
+    const float b_ = A[0][0] * SA[1][0] + A[0][1] * SA[1][1] + A[0][2] * SA[1][2];
+    const float c_ = A[1][0] * SA[1][0] + A[1][1] * SA[1][1] + A[1][2] * SA[1][2] + 0.3f;
+    const float denom = a_ * c_ - b_ * b_;
+    float da = 0, db = 0, dc = 0;
+    const float d2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float gS[6] = {0, 0, 0, 0, 0, 0};
+    if (d2inv != 0) {
+        da = d2inv * (-c_ * c_ * gcx + 2 * b_ * c_ * gcy + (denom - a_ * c_) * gcz);
+        dc = d2inv * (-a_ * a_ * gcz + 2 * a_ * b_ * gcy + (denom - a_ * c_) * gcx);
+        db = d2inv * 2 * (b_ * c_ * gcx - (denom + 2 * b_ * b_) * gcy + a_ * b_ * gcz);
+        gS[0] = (A[0][0] * A[0][0] * da + A[0][0] * A[1][0] * db + A[1][0] * A[1][0] * dc);
+        gS[3] = (A[0][1] * A[0][1] * da + A[0][1] * A[1][1] * db + A[1][1] * A[1][1] * dc);
+        gS[5] = (A[0][2] * A[0][2] * da + A[0][2] * A[1][2] * db + A[1][2] * A[1][2] * dc);
+        gS[1] = 2 * A[0][0] * A[0][1] * da + (A[0][0] * A[1][1] + A[0][1] * A[1][0]) * db + 2 * A[1][0] * A[1][1] * dc;
+        gS[2] = 2 * A[0][0] * A[0][2] * da + (A[0][0] * A[1][2] + A[0][2] * A[1][0]) * db + 2 * A[1][0] * A[1][2] * dc;
+        gS[4] = 2 * A[0][2] * A[0][1] * da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * db + 2 * A[1][1] * A[1][2] * dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = gS[k];
+    float dA[2][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float a0S = A[0][0] * S[r][0] + A[0][1] * S[r][1] + A[0][2] * S[r][2];
+        const float a1S = A[1][0] * S[r][0] + A[1][1] * S[r][1] + A[1][2] * S[r][2];
+        dA[0][r] = 2 * a0S * da + a1S * db;
+        dA[1][r] = 2 * a1S * dc + a0S * db;
+    }
+    const float dJ00 = vm[0] * dA[0][0] + vm[4] * dA[0][1] + vm[8] * dA[0][2];
+    const float dJ02 = vm[2] * dA[0][0] + vm[6] * dA[0][1] + vm[10] * dA[0][2];
+    const float dJ11 = vm[1] * dA[1][0] + vm[5] * dA[1][1] + vm[9] * dA[1][2];
+    const float dJ12 = vm[2] * dA[1][0] + vm[6] * dA[1][1] + vm[10] * dA[1][2];
+    const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = xmul * -fx * tz2 * dJ02;
+    const float dty = ymul * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * t[0]) * tz3 * dJ02 + (2 * fy * t[1]) * tz3 * dJ12;
+    float gm[3] = {vm[0] * dtx + vm[1] * dty + vm[2] * dtz,
+                   vm[4] * dtx + vm[5] * dty + vm[6] * dtz,
+                   vm[8] * dtx + vm[9] * dty + vm[10] * dtz};
+
+    // ---- 2D mean -> 3D mean ----
+    const float hw = pm[3] * mean[0] + pm[7] * mean[1] + pm[11] * mean[2] + pm[15];
+    const float mw = 1.0f / (hw + 0.0000001f);
+    const float mul1 = (pm[0] * mean[0] + pm[4] * mean[1] + pm[8] * mean[2] + pm[12]) * mw * mw;
+    const float mul2 = (pm[1] * mean[0] + pm[5] * mean[1] + pm[9] * mean[2] + pm[13]) * mw * mw;
+    gm[0] += (pm[0] * mw - pm[3] * mul1) * g2x + (pm[1] * mw - pm[3] * mul2) * g2y;
+    gm[1] += (pm[4] * mw - pm[7] * mul1) * g2x + (pm[5] * mw - pm[7] * mul2) * g2y;
+    gm[2] += (pm[8] * mw - pm[11] * mul1) * g2x + (pm[9] * mw - pm[11] * mul2) * g2y;
+
+    // ---- SH backward ----
+    if (p.shs) {
+        const float dorig[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
+        const float len = sqrtf(dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2]);
+        const float x = dorig[0] / len, y = dorig[1] / len, z = dorig[2] / len;
+        const float* sh = p.shs + (size_t)i * p.M * 3;
+        float* gsh = p.dL_dsh + (size_t)i * p.M * 3;
+        const uint8_t cb = p.clamped[i];
+        float g[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) g[ch] = gcol[ch] * (((cb >> ch) & 1) ? 0.f : 1.f);
+        float B[16];
+        int nb = 1;
+        B[0] = bC0;
+        const int D = p.D;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        if (D > 0) {
+            B[1] = -bC1 * y; B[2] = bC1 * z; B[3] = -bC1 * x; nb = 4;
+            if (D > 1) {
+                B[4] = bC2[0] * xy; B[5] = bC2[1] * yz; B[6] = bC2[2] * (2.0f * zz - xx - yy);
+                B[7] = bC2[3] * xz; B[8] = bC2[4] * (xx - yy); nb = 9;
+                if (D > 2) {
+                    B[9] = bC3[0] * y * (3.0f * xx - yy); B[10] = bC3[1] * xy * z;
+                    B[11] = bC3[2] * y * (4.0f * zz - xx - yy);
+                    B[12] = bC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                    B[13] = bC3[4] * x * (4.0f * zz - xx - yy); B[14] = bC3[5] * z * (xx - yy);
+                    B[15] = bC3[6] * x * (xx - 3.0f * yy); nb = 16;
+                }
+            }
+        }
+        for (int k = 0; k < nb; k++) {
+            gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2];
+        }
+        float gd[3] = {0, 0, 0};
+        if (D > 0) {
+            float dx3[3], dy3[3], dz3[3];
+#define SHK(k, ch) sh[3 * (k) + (ch)]
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dx3[ch] = -bC1 * SHK(3, ch); dy3[ch] = -bC1 * SHK(1, ch); dz3[ch] = bC1 * SHK(2, ch);
+                if (D > 1) {
+                    dx3[ch] += bC2[0] * y * SHK(4, ch) + bC2[2] * 2.f * -x * SHK(6, ch) + bC2[3] * z * SHK(7, ch) + bC2[4] * 2.f * x * SHK(8, ch);
+                    dy3[ch] += bC2[0] * x * SHK(4, ch) + bC2[1] * z * SHK(5, ch) + bC2[2] * 2.f * -y * SHK(6, ch) + bC2[4] * 2.f * -y * SHK(8, ch);
+                    dz3[ch] += bC2[1] * y * SHK(5, ch) + bC2[2] * 2.f * 2.f * z * SHK(6, ch) + bC2[3] * x * SHK(7, ch);
+                    if (D > 2) {
+                        dx3[ch] += (bC3[0] * SHK(9, ch) * 3.f * 2.f * xy + bC3[1] * SHK(10, ch) * yz + bC3[2] * SHK(11, ch) * -2.f * xy +
+                                    bC3[3] * SHK(12, ch) * -3.f * 2.f * xz + bC3[4] * SHK(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                                    bC3[5] * SHK(14, ch) * 2.f * xz + bC3[6] * SHK(15, ch) * 3.f * (xx - yy));
+                        dy3[ch] += (bC3[0] * SHK(9, ch) * 3.f * (xx - yy) + bC3[1] * SHK(10, ch) * xz + bC3[2] * SHK(11, ch) * (-3.f * yy + 4.f * zz - xx) +
+                                    bC3[3] * SHK(12, ch) * -3.f * 2.f * yz + bC3[4] * SHK(13, ch) * -2.f * xy +
+                                    bC3[5] * SHK(14, ch) * -2.f * yz + bC3[6] * SHK(15, ch) * -3.f * 2.f * xy);
+                        dz3[ch] += (bC3[1] * SHK(10, ch) * xy + bC3[2] * SHK(11, ch) * 4.f * 2.f * yz + bC3[3] * SHK(12, ch) * 3.f * (2.f * zz - xx - yy) +
+                                    bC3[4] * SHK(13, ch) * 4.f * 2.f * xz + bC3[5] * SHK(14, ch) * (xx - yy));
+                    }
+                }
+            }
+#undef SHK
+            gd[0] = dx3[0] * g[0] + dx3[1] * g[1] + dx3[2] * g[2];
+            gd[1] = dy3[0] * g[0] + dy3[1] * g[1] + dy3[2] * g[2];
+            gd[2] = dz3[0] * g[0] + dz3[1] * g[1] + dz3[2] * g[2];
+        }
+        const float s2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];
+        const float inv32 = 1.0f / sqrtf(s2 * s2 * s2);
+        gm[0] += ((+s2 - dorig[0] * dorig[0]) * gd[0] - dorig[1] * dorig[0] * gd[1] - dorig[2] * dorig[0] * gd[2]) * inv32;
+        gm[1] += (-dorig[0] * dorig[1] * gd[0] + (s2 - dorig[1] * dorig[1]) * gd[1] - dorig[2] * dorig[1] * gd[2]) * inv32;
+        gm[2] += (-dorig[0] * dorig[2] * gd[0] - dorig[1] * dorig[2] * gd[1] + (s2 - dorig[2] * dorig[2]) * gd[2]) * inv32;
+    }
+    p.dL_dmean3D[3 * i] = gm[0]; p.dL_dmean3D[3 * i + 1] = gm[1]; p.dL_dmean3D[3 * i + 2] = gm[2];
+
+    // ---- cov3D -> scale / rotation ----
+    if (p.scales) {
+        const float r_ = p.rotations[4 * i], x = p.rotations[4 * i + 1], y = p.rotations[4 * i + 2], z = p.rotations[4 * i + 3];
+        float R[3][3];
+        R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r_ * z);      R[0][2] = 2.f * (x * z + r_ * y);
+        R[1][0] = 2.f * (x * y + r_ * z);      R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r_ * x);
+        R[2][0] = 2.f * (x * z - r_ * y);      R[2][1] = 2.f * (y * z + r_ * x);      R[2][2] = 1.f - 2.f * (x * x + y * y);
+        const float sv[3] = {p.scale_modifier * p.scales[3 * i], p.scale_modifier * p.scales[3 * i + 1], p.scale_modifier * p.scales[3 * i + 2]};
+        float Mm[3][3], dS[3][3], dM[3][3], G[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) Mm[r][cc] = sv[r] * R[cc][r];
+        dS[0][0] = gS[0]; dS[1][1] = gS[3]; dS[2][2] = gS[5];
+        dS[0][1] = dS[1][0] = 0.5f * gS[1]; dS[0][2] = dS[2][0] = 0.5f * gS[2]; dS[1][2] = dS[2][1] = 0.5f * gS[4];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) dM[r][cc] = 2.0f * (Mm[r][0] * dS[0][cc] + Mm[r][1] * dS[1][cc] + Mm[r][2] * dS[2][cc]);
+#pragma unroll
+        for (int r = 0; r < 3; r++) p.dL_dscale[3 * i + r] = R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) G[r][cc] = sv[r] * dM[r][cc];
+        p.dL_drot[4 * i + 0] = 2 * z * (G[0][1] - G[1][0]) + 2 * y * (G[2][0] - G[0][2]) + 2 * x * (G[1][2] - G[2][1]);
+        p.dL_drot[4 * i + 1] = 2 * y * (G[1][0] + G[0][1]) + 2 * z * (G[2][0] + G[0][2]) + 2 * r_ * (G[1][2] - G[2][1]) - 4 * x * (G[2][2] + G[1][1]);
+        p.dL_drot[4 * i + 2] = 2 * x * (G[1][0] + G[0][1]) + 2 * r_ * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
+        p.dL_drot[4 * i + 3] = 2 * r_ * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
+    }
+}
+
+int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g)
+{
+    PreBwdParams p;
+    p.P = a.P; p.D = a.D; p.M = a.M;
+    p.means3D = a.means3D; p.radii = a.radii; p.shs = a.shs; p.clamped = g.clamped;
+    p.scales = a.scales; p.rotations = a.rotations; p.scale_modifier = a.scale_modifier;
+    p.cov3D = a.cov3D_precomp ? a.cov3D_precomp : g.cov3D;
+    p.gacc = a.grad_acc;
+    p.dL_dmean2D = a.dL_dmean2D; p.dL_dmean2D_abs = a.dL_dmean2D_abs; p.dL_dconic = a.dL_dconic;
+    p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
+    p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;
+    const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ibgs

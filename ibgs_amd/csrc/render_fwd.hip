@@ -1,0 +1,376 @@
+// F1-F3 + T1: front-to-back alpha blend per tile, plane / median-depth buffer, source-view warp.
+//
+// Behaviour: DPR/cuda_rasterizer/forward.cu:303-665 (renderCUDA) and the texture set-up of
+// rasterizer_impl.cu:34-133.  Organisation is gfx950-native rather than the reference's
+// "256-thread block, one thread per pixel, __syncthreads per round":
+//
+//   * ONE WAVE owns a whole 16x16 tile (PPL = 4: lane l blends pixel (l%8, l/8) of each of the four
+//     8x8 quadrants) or one 8x8 quadrant (PPL = 1, used by the register-heavy geo variant).  There
+//     is no cross-wave synchronisation at all; a workgroup is a single wave, so "barriers" are only
+//     waitcnts and tiles finish independently.
+//   * Gaussian records (64 B, written by preprocess) are staged 64 at a time into LDS with 16-byte
+//     per-lane loads and read back as wave-uniform broadcasts (ds_read_b128), i.e. 3 LDS reads per
+//     Gaussian per 256 pixels.
+//   * Each quadrant is skipped with a wave-uniform branch when no lane has alpha >= 1/255 (ballot),
+//     which recovers 8x8 sub-tile culling without changing any result.
+//   * Early termination is per wave: the tile stops fetching as soon as every pixel is done.
+//   * CUDA layered textures do not exist on gfx950; source images are packed to RGBA float4 once per
+//     call and sampled with explicit bilinear gathers that follow the texture unit's addressing rules
+//     (unnormalised, clamp, linear).
+#include "common.h"
+
+namespace ibgs {
+
+struct FwdParams {
+    const uint32_t* ranges; const uint32_t* point_list; const float4* rec;
+    Cam cam;
+    int ntiles;
+    // geo
+    int n_src; int L; float thr; int tex_quant;
+    const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
+    // per-pixel state
+    float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w;
+    // outputs
+    float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
+    float* out_min_depth_diff; float* out_camera_ray; int32_t* out_mask;
+};
+
+enum { MODE_COLOR = 0, MODE_GEO = 1, MODE_DEPTH = 2 };
+
+__global__ void __launch_bounds__(256) pack_rgba_kernel(const float* __restrict__ src, float4* __restrict__ dst, size_t HW, int n)
+{   // packRGBA, rasterizer_impl.cu:34-56
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= HW * (size_t)n) return;
+    const size_t layer = idx / HW, pix = idx % HW;
+    const float* b = src + layer * 3 * HW;
+    dst[idx] = make_float4(b[pix], b[HW + pix], b[2 * HW + pix], 1.0f);
+}
+
+int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n)
+{
+    const size_t total = (size_t)W * H * n;
+    hipLaunchKernelGGL(pack_rgba_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, (size_t)W * H, n);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+__device__ __forceinline__ float quant8(float a, int quant) { return quant ? floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f) : a; }
+
+// Linear-filtered, clamp-addressed fetch at unnormalised texture coordinate (x, y) -- texel centres
+// at i + 0.5 (what tex2DLayered does with the descriptor of rasterizer_impl.cu:120-126).
+__device__ __forceinline__ float4 tex_rgba(const float4* __restrict__ img, int W, int H, float x, float y, int quant)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fxi = floorf(xb), fyi = floorf(yb);
+    const float a = quant8(xb - fxi, quant), b = quant8(yb - fyi, quant);
+    const int i0 = min(W - 1, max(0, (int)fxi)), i1 = min(W - 1, max(0, (int)fxi + 1));
+    const int j0 = min(H - 1, max(0, (int)fyi)), j1 = min(H - 1, max(0, (int)fyi + 1));
+    const float4 t00 = img[(size_t)j0 * W + i0], t10 = img[(size_t)j0 * W + i1];
+    const float4 t01 = img[(size_t)j1 * W + i0], t11 = img[(size_t)j1 * W + i1];
+    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+    float4 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.w = 1.0f;
+    return r;
+}
+
+__device__ __forceinline__ float tex_depth(const float* __restrict__ img, int W, int H, float x, float y, int quant)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fxi = floorf(xb), fyi = floorf(yb);
+    const float a = quant8(xb - fxi, quant), b = quant8(yb - fyi, quant);
+    const int i0 = min(W - 1, max(0, (int)fxi)), i1 = min(W - 1, max(0, (int)fxi + 1));
+    const int j0 = min(H - 1, max(0, (int)fyi)), j1 = min(H - 1, max(0, (int)fyi + 1));
+    const float t00 = img[(size_t)j0 * W + i0], t10 = img[(size_t)j0 * W + i1];
+    const float t01 = img[(size_t)j1 * W + i0], t11 = img[(size_t)j1 * W + i1];
+    return (1.f - a) * (1.f - b) * t00 + a * (1.f - b) * t10 + (1.f - a) * b * t01 + a * b * t11;
+}
+
+// XCD-aware block -> work item map: consecutive block ids are dealt round-robin to the 8 XCDs, so
+// give every XCD one contiguous band of tiles (neighbouring tiles share Gaussian records in L2).
+__device__ __forceinline__ int xcd_band_map(int b, int n)
+{
+    const int per = (n + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+template <int MODE, int PPL>
+__global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
+{
+    constexpr bool GEO = (MODE == MODE_GEO);
+    constexpr bool DEPTH = (MODE == MODE_DEPTH);
+    constexpr int NQ = GEO ? 4 : 3;          // record quads staged per Gaussian
+    constexpr int MAXL = IBGS_MAX_BUFFER_LENGTH;
+    __shared__ float4 s_rec[NQ][WAVE];
+
+    const int lane = threadIdx.x;
+    const int nitems = p.ntiles * (PPL == 4 ? 1 : 4);
+    const int item = xcd_band_map(blockIdx.x, nitems);
+    if (item >= nitems) return;
+    const int tile = (PPL == 4) ? item : (item >> 2);
+    const int quad0 = (PPL == 4) ? 0 : (item & 3);
+    const int W = p.cam.W, H = p.cam.H;
+    const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
+    const size_t HW = (size_t)W * H;
+
+    int px[PPL], py[PPL];
+    float pxf[PPL], pyf[PPL];
+    bool inside[PPL], done[PPL];
+    float T[PPL], C[PPL][3];
+    uint32_t lastc[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        const int qq = quad0 + q;
+        px[q] = tx0 + (qq & 1) * 8 + (lane & 7);
+        py[q] = ty0 + (qq >> 1) * 8 + (lane >> 3);
+        pxf[q] = (float)px[q]; pyf[q] = (float)py[q];
+        inside[q] = px[q] < W && py[q] < H;
+        done[q] = !inside[q];
+        T[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.f; lastc[q] = 0;
+    }
+    const float fx = p.cam.fx, fy = p.cam.fy;
+    const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
+    const float eps = 1.0e-8f;
+
+    // geo / depth-only state (PPL == 1 for GEO; DEPTH keeps running sums only plus the ring)
+    float Nacc[PPL][3];
+    float bd[PPL][MAXL], bw[PPL][MAXL]; uint32_t bc[PPL][MAXL];
+    int before_ptr[PPL], below_count[PPL];
+    float tot_w[PPL], wd_sum[PPL];
+    int resume[PPL]; uint32_t cnt[PPL];
+    float rayx[PPL], rayy[PPL];
+    const int L = p.L;
+    const int before_cap = (L % 2 == 0) ? (L / 2) : ((L + 1) / 2);
+    const int below_cap = L - before_cap;
+    if (GEO || DEPTH) {
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+            Nacc[q][0] = Nacc[q][1] = Nacc[q][2] = 0.f;
+#pragma unroll
+            for (int s = 0; s < MAXL; s++) { bd[q][s] = 0.f; bw[q][s] = 0.f; bc[q][s] = 0u; }
+            before_ptr[q] = 0; below_count[q] = 0; tot_w[q] = 0.f; wd_sum[q] = 0.f; resume[q] = 0; cnt[q] = 0;
+            rayx[q] = (pxf[q] - cx) / fx; rayy[q] = (pyf[q] - cy) / fy;
+        }
+    }
+
+    const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
+    const int n = (int)(r1 - r0);
+
+    for (int base = 0; base < n; base += WAVE) {
+        {   // stage up to 64 records: lane e loads the quads of entry base+e
+            const int e = base + lane;
+            if (e < n) {
+                const uint32_t id = p.point_list[r0 + e];
+                const float4* r = p.rec + (size_t)id * 4;
+                s_rec[0][lane] = r[0];
+                s_rec[1][lane] = r[1];
+                if (!DEPTH) s_rec[2][lane] = r[2];
+                if (GEO) s_rec[3][lane] = r[3];
+                if (DEPTH) s_rec[2][lane] = r[3];
+            }
+        }
+        __syncthreads();
+        const int count = min(WAVE, n - base);
+        for (int j = 0; j < count; j++) {
+            const float4 q0 = s_rec[0][j];      // x, y, opacity
+            const float4 q1 = s_rec[1][j];      // conic a, b, c, plane distance
+            const float4 q2 = s_rec[2][j];      // rgb (colour/geo) or normal (depth-only)
+            float4 q3 = q2;
+            if (GEO) q3 = s_rec[3][j];          // normal
+            const int e = base + j;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];
+                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+                const float alpha = fminf(0.99f, q0.z * __expf(power));
+                bool live = !done[q];
+                if (DEPTH) live = live && (e >= resume[q]);
+                if (DEPTH && live) cnt[q]++;
+                const bool ok = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(ok) != 0ull) {
+                    const float test_T = T[q] * (1.0f - alpha);
+                    const bool fin = ok && (test_T < 0.0001f);
+                    done[q] = done[q] || fin;
+                    const bool acc = ok && !fin;
+                    const float aT = alpha * T[q];
+                    const uint32_t contributor = DEPTH ? cnt[q] : (uint32_t)(e + 1);
+                    if (!DEPTH) {
+                        const float w = acc ? aT : 0.f;
+                        C[q][0] += q2.x * w; C[q][1] += q2.y * w; C[q][2] += q2.z * w;
+                    }
+                    if (GEO || DEPTH) {
+                        const float dep = -q1.w / (q3.x * rayx[q] + q3.y * rayy[q] + q3.z + eps);
+                        if (GEO) {
+                            const float w = acc ? aT : 0.f;
+                            Nacc[q][0] += q3.x * w; Nacc[q][1] += q3.y * w; Nacc[q][2] += q3.z * w;
+                        }
+                        const bool hit = acc && (dep > 0.0f);
+                        const bool front = T[q] > 0.5f;
+                        int slot = -1;
+                        if (hit && front) slot = before_ptr[q];
+                        else if (hit && below_count[q] < below_cap) slot = before_cap + below_count[q];
+                        if (DEPTH && slot >= 0 && front) {
+                            float oldw = 0.f, oldd = 0.f;
+#pragma unroll
+                            for (int s = 0; s < MAXL; s++) if (s == slot) { oldw = bw[q][s]; oldd = bd[q][s]; }
+                            tot_w[q] -= oldw; wd_sum[q] -= oldw * oldd;
+                        }
+                        if (slot >= 0) {
+#pragma unroll
+                            for (int s = 0; s < MAXL; s++) if (s == slot) { bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
+                            if (front) before_ptr[q] = (before_ptr[q] + 1) % before_cap;
+                            else below_count[q]++;
+                            if (DEPTH) { tot_w[q] += aT; wd_sum[q] += aT * dep; }
+                        }
+                        if (DEPTH && hit && below_count[q] == below_cap) {
+                            // forward.cu:484-488: 'break' leaves the current 256-entry round only
+                            resume[q] = (e / 256 + 1) * 256;
+                        }
+                    }
+                    T[q] = acc ? test_T : T[q];
+                    lastc[q] = acc ? contributor : lastc[q];
+                }
+            }
+        }
+        __syncthreads();
+        bool alldone = true;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) alldone = alldone && done[q];
+        if (__ballot(!alldone) == 0ull) break;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        if (!inside[q]) continue;
+        const size_t pix = (size_t)py[q] * W + px[q];
+        p.final_T[pix] = T[q];
+        p.n_contrib[pix] = lastc[q];
+        if (!DEPTH) {
+            p.out_color[pix] = C[q][0] + T[q] * p.cam.bg[0];
+            p.out_color[HW + pix] = C[q][1] + T[q] * p.cam.bg[1];
+            p.out_color[2 * HW + pix] = C[q][2] + T[q] * p.cam.bg[2];
+        }
+        if (DEPTH) p.out_depth[pix] = wd_sum[q] / (tot_w[q] + eps);
+        if (GEO) {
+            const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
+            const float pdx = pxf[q] - cx, pdy = pyf[q] - cy;
+            float tw = 0.f, med = 0.f;
+            float tw_src[IBGS_MAX_SRC], wc[IBGS_MAX_SRC][3];
+#pragma unroll
+            for (int si = 0; si < IBGS_MAX_SRC; si++) { tw_src[si] = 0.f; wc[si][0] = wc[si][1] = wc[si][2] = 0.f; }
+            uint32_t lo = bc[q][0], hi = bc[q][0];     // Q4: slot 0 even when empty
+            for (int s = 0; s < L; s++) {
+                float w = 0.f, d = 0.f; uint32_t c = 0;
+#pragma unroll
+                for (int k = 0; k < MAXL; k++) if (k == s) { w = bw[q][k]; d = bd[q][k]; c = bc[q][k]; }
+                if (w == 0.0f) continue;
+                const float X = pdx * d * inv_fx, Y = pdy * d * inv_fy, Z = d;
+#pragma unroll
+                for (int si = 0; si < IBGS_MAX_SRC; si++) {
+                    if (si < p.n_src) {
+                        const float* r = p.ref_to_src + 16 * si;
+                        const float tx = r[0] * X + r[1] * Y + r[2] * Z + r[3] * 1.0f;
+                        const float ty = r[4] * X + r[5] * Y + r[6] * Z + r[7] * 1.0f;
+                        const float tz = r[8] * X + r[9] * Y + r[10] * Z + r[11] * 1.0f;
+                        const float iz = 1.0f / (tz + eps);
+                        const float u = tx * fx * iz + cx, v = ty * fy * iz + cy;
+                        if (u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1)) {
+                            const float4 col = tex_rgba(p.src_rgba + (size_t)si * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
+                            wc[si][0] += w * col.x; wc[si][1] += w * col.y; wc[si][2] += w * col.z;
+                            tw_src[si] += w;
+                        }
+                    }
+                }
+                tw += w; med += w * d;
+                lo = min(lo, c); hi = max(hi, c);
+            }
+            p.low_high[2 * pix] = lo; p.low_high[2 * pix + 1] = hi; p.sum_w[pix] = tw;
+            med /= (tw + eps);
+            const float mX = pdx * med * inv_fx, mY = pdy * med * inv_fy, mZ = med;
+            const float* vm = p.cam.vm;
+            const float qx = mX - vm[12], qy = mY - vm[13], qz = mZ - vm[14];
+            const float wx = vm[0] * qx + vm[1] * qy + vm[2] * qz;
+            const float wy = vm[4] * qx + vm[5] * qy + vm[6] * qz;
+            const float wz = vm[8] * qx + vm[9] * qy + vm[10] * qz;
+            float rd0 = wx - p.cam.campos[0], rd1 = wy - p.cam.campos[1], rd2 = wz - p.cam.campos[2];
+            const float rl = sqrtf(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) + eps;
+            rd0 /= rl; rd1 /= rl; rd2 /= rl;
+            p.out_camera_ray[pix] = rd0; p.out_camera_ray[HW + pix] = rd1; p.out_camera_ray[2 * HW + pix] = rd2;
+
+            int nvalid = 0; float min_err = 1.0f;
+#pragma unroll
+            for (int si = 0; si < IBGS_MAX_SRC; si++) {
+                if (si < p.n_src && nvalid < IBGS_MAX_SRC) {
+                    const float* r = p.ref_to_src + 16 * si;
+                    const float tx = r[0] * mX + r[1] * mY + r[2] * mZ + r[3] * 1.0f;
+                    const float ty = r[4] * mX + r[5] * mY + r[6] * mZ + r[7] * 1.0f;
+                    const float tz = r[8] * mX + r[9] * mY + r[10] * mZ + r[11] * 1.0f;
+                    const float iz = 1.0f / (tz + eps);
+                    const float u = tx * fx * iz + cx, v = ty * fy * iz + cy;
+                    float wdep = 0.0f;
+                    if (u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1))
+                        wdep = tex_depth(p.src_depths + (size_t)si * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
+                    const float err = fabsf(wdep - tz) * iz;
+                    if (wdep > 0.0f && err < p.thr) {
+                        const float iw = 1.0f / (tw_src[si] + eps);
+                        const float* sp = p.src_cam_pos + 3 * si;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            p.out_cam_feat[((size_t)nvalid * 4 + ch) * HW + pix] = p.cam.campos[ch] - sp[ch];
+                            p.out_warped[((size_t)nvalid * 3 + ch) * HW + pix] = wc[si][ch] * iw;
+                        }
+                        float s0 = wx - sp[0], s1 = wy - sp[1], s2 = wz - sp[2];
+                        const float sl = sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + eps;
+                        s0 /= sl; s1 /= sl; s2 /= sl;
+                        p.out_cam_feat[((size_t)nvalid * 4 + 3) * HW + pix] = s0 * rd0 + s1 * rd1 + s2 * rd2;
+                        if (si == 0) p.out_mask[pix] = 1;
+                        p.valid_idx[(size_t)nvalid * HW + pix] = si;
+                        p.valid_w[(size_t)nvalid * HW + pix] = tw_src[si];
+                        nvalid++;
+                        min_err = fminf(min_err, err);
+                    }
+                }
+            }
+            if (nvalid <= IBGS_MAX_SRC - 1) p.valid_idx[(size_t)nvalid * HW + pix] = -1;
+            p.out_min_depth_diff[pix] = min_err;
+            p.out_depth[pix] = med;
+            p.out_normal[pix] = Nacc[q][0]; p.out_normal[HW + pix] = Nacc[q][1]; p.out_normal[2 * HW + pix] = Nacc[q][2];
+        }
+    }
+}
+
+int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
+                          const ImgState& im, const float4* src_rgba)
+{
+    FwdParams p;
+    p.ranges = im.ranges; p.point_list = b.point_list; p.rec = reinterpret_cast<const float4*>(g.rec);
+    p.cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
+    p.ntiles = p.cam.gx * p.cam.gy;
+    p.n_src = a.n_src; p.L = a.buffer_length; p.thr = a.depth_error_threshold;
+    p.tex_quant = (a.flags & IBGS_FLAG_TEX_QUANT) ? 1 : 0;
+    p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
+    p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
+    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
+    p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
+    p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
+    p.out_mask = a.out_mask;
+    const int nt = p.ntiles;
+    if (a.render_depth_only && !a.render_geo) {
+        const int grid = ((nt + 7) / 8) * 8;
+        hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4>), dim3(grid), dim3(64), 0, s, p);
+    } else if (a.render_geo) {
+        const int items = nt * 4;
+        const int grid = ((items + 7) / 8) * 8;
+        hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1>), dim3(grid), dim3(64), 0, s, p);
+    } else {
+        const int grid = ((nt + 7) / 8) * 8;
+        hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4>), dim3(grid), dim3(64), 0, s, p);
+    }
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ibgs

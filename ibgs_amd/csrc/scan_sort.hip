@@ -1,0 +1,277 @@
+// A2 / A4: device-wide exclusive scan and stable LSD radix sort of (u32 key, u32 value) pairs.
+//
+// Replaces cub::DeviceScan::InclusiveSum and cub::DeviceRadixSort::SortPairs of the reference
+// (DPR/cuda_rasterizer/rasterizer_impl.cu:426, 452-457).  The pipeline that uses them is different
+// from the reference's (see binning.hip): Gaussians are depth-sorted FIRST (P items, 32-bit keys),
+// duplicates are emitted in depth order, and only the tile id (<= 16 bits) is radix-sorted over the
+// R duplicates -- two 7-bit passes at 1080p instead of six 8-bit passes over 64-bit keys.
+//
+// Kernels are written for wave64: ranking inside a pass uses 64-bit ballots ("match any") and
+// per-wave LDS counters; scatter is staged through LDS so that global writes are runs of
+// consecutive addresses.
+#include "common.h"
+
+namespace ibgs {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;   // 2048
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;         // 4096
+constexpr int RS_MAX_BINS = 256;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread block. Returns the exclusive prefix;
+// *total receives the block sum (valid in every thread).
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds_wave /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) lds_wave[wave] = inc;
+    __syncthreads();
+    const uint32_t w0 = lds_wave[0], w1 = lds_wave[1], w2 = lds_wave[2], w3 = lds_wave[3];
+    uint32_t base = 0;
+    if (wave > 0) base += w0;
+    if (wave > 1) base += w1;
+    if (wave > 2) base += w2;
+    *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// Level kernel: local exclusive scan of a 2048-element chunk; block totals go to sums[block].
+// When `single` (grid of one block) the grand total is written to out[n] if requested.
+__global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_kernel(const uint32_t* in, uint32_t* out,
+                                                                  size_t n, uint32_t* __restrict__ sums, int write_total_single)
+{
+    __shared__ uint32_t lds_wave[4];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t local = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        local += v[k];
+    }
+    uint32_t total;
+    uint32_t pre = block_exclusive_scan_256(local, &total, lds_wave);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = pre;
+        pre += v[k];
+    }
+    if (threadIdx.x == 0) {
+        if (sums) sums[blockIdx.x] = total;
+        if (write_total_single) out[n] = total;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_add_kernel(uint32_t* __restrict__ out, size_t n, const uint32_t* __restrict__ sums,
+                                                                size_t nblocks, int write_total)
+{
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_ITEMS;
+    const uint32_t add = sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < n) out[base + k] += add;
+    if (write_total && blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nblocks];
+}
+
+size_t scan_scratch_elems(size_t n)
+{
+    size_t total = 0;
+    while (n > SCAN_CHUNK) {
+        n = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        total += n + 1 + 32;   // block sums + total slot (+pad)
+    }
+    return total + 64;
+}
+
+int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch,
+                       size_t scratch_elems, bool with_total)
+{
+    if (n == 0) {
+        if (with_total) IBGS_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), s));
+        return 0;
+    }
+    const size_t nblocks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nblocks == 1) {
+        hipLaunchKernelGGL(scan_chunk_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, in, out, n, (uint32_t*)nullptr, with_total ? 1 : 0);
+        IBGS_HIP(hipGetLastError());
+        return 0;
+    }
+    if (scratch_elems < nblocks + 1) { set_error("scan scratch too small"); return -IBGS_ERR_ALLOC; }
+    uint32_t* sums = scratch;
+    hipLaunchKernelGGL(scan_chunk_kernel, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, s, in, out, n, sums, 0);
+    IBGS_HIP(hipGetLastError());
+    const size_t used = nblocks + 1 + 32;
+    int rc = exclusive_scan_u32(s, sums, sums, nblocks, scratch + used, scratch_elems > used ? scratch_elems - used : 0, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, s, out, n, sums, nblocks, with_total ? 1 : 0);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix pass
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift, int nbins,
+                                                                uint32_t* __restrict__ hist, unsigned nblocks)
+{
+    __shared__ uint32_t h[RS_MAX_BINS];
+    for (int k = threadIdx.x; k < nbins; k += RS_THREADS) h[k] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RS_CHUNK;
+    const uint32_t mask = (uint32_t)nbins - 1;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const size_t idx = base + (size_t)k * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += RS_THREADS) hist[(size_t)k * nblocks + blockIdx.x] = h[k];
+}
+
+// Stable scatter of one 4096-element chunk. Element order inside the chunk is
+// wave * 1024 + step * 64 + lane, i.e. each wave owns a contiguous quarter and walks it in
+// 64-element steps, so (earlier wave, earlier step, lower lane) == earlier input position.
+__global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                   size_t n, int shift, int nbits, int nbins,
+                                                                   const uint32_t* __restrict__ hist_scanned, unsigned nblocks)
+{
+    __shared__ uint32_t wcnt[4][RS_MAX_BINS];
+    __shared__ uint32_t dstart[RS_MAX_BINS];
+    __shared__ uint32_t delta[RS_MAX_BINS];
+    __shared__ uint32_t lds_wave[4];
+    __shared__ uint32_t skey[RS_CHUNK];
+    __shared__ uint32_t sval[RS_CHUNK];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < 4 * RS_MAX_BINS; k += RS_THREADS) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+
+    const size_t base = (size_t)blockIdx.x * RS_CHUNK;
+    const uint32_t mask = (uint32_t)nbins - 1;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
+        const bool valid = idx < n;
+        key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[k] = valid ? vals_in[idx] : 0u;
+        const uint32_t d = (key[k] >> shift) & mask;
+        // match-any over the digit bits
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit && valid);
+            peers &= bit ? bal : ~bal;
+        }
+        uint32_t r = 0;
+        if (valid) {
+            // cross-lane hand-off through LDS inside one wave: LDS ops of a wave execute in order;
+            // volatile keeps the compiler from caching the counter across steps
+            volatile uint32_t* wc = &wcnt[wave][0];
+            const uint32_t pre = wc[d];
+            r = pre + (uint32_t)__popcll(peers & lt_mask);
+            const int leader = __ffsll((unsigned long long)peers) - 1;
+            if (lane == leader) wc[d] = pre + (uint32_t)__popcll(peers);
+        }
+        rank[k] = r;
+    }
+    __syncthreads();
+
+    // per digit: exclusive prefix over the 4 waves, block total, exclusive scan over digits
+    uint32_t tot = 0;
+    if (threadIdx.x < nbins) {
+        const uint32_t c0 = wcnt[0][threadIdx.x], c1 = wcnt[1][threadIdx.x], c2 = wcnt[2][threadIdx.x], c3 = wcnt[3][threadIdx.x];
+        wcnt[0][threadIdx.x] = 0; wcnt[1][threadIdx.x] = c0; wcnt[2][threadIdx.x] = c0 + c1; wcnt[3][threadIdx.x] = c0 + c1 + c2;
+        tot = c0 + c1 + c2 + c3;
+    }
+    uint32_t blocktotal;
+    const uint32_t ds = block_exclusive_scan_256(tot, &blocktotal, lds_wave);
+    if (threadIdx.x < nbins) {
+        dstart[threadIdx.x] = ds;
+        delta[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * nblocks + blockIdx.x] - ds;
+    }
+    __syncthreads();
+
+    const size_t remaining = n - base;
+    const uint32_t count = remaining < (size_t)RS_CHUNK ? (uint32_t)remaining : (uint32_t)RS_CHUNK;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[k] >> shift) & mask;
+            const uint32_t lpos = dstart[d] + wcnt[wave][d] + rank[k];
+            skey[lpos] = key[k];
+            sval[lpos] = val[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t l = (uint32_t)k * RS_THREADS + threadIdx.x;
+        if (l < count) {
+            const uint32_t kk = skey[l];
+            const uint32_t d = (kk >> shift) & mask;
+            const uint32_t dst = l + delta[d];     // wraps correctly in uint32 arithmetic
+            keys_out[dst] = kk;
+            vals_out[dst] = sval[l];
+        }
+    }
+}
+
+size_t radix_hist_elems(size_t n)
+{
+    const size_t nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    const size_t hist = (size_t)RS_MAX_BINS * (nblocks ? nblocks : 1) + 1;
+    return hist + 64 + scan_scratch_elems(hist);
+}
+
+int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
+                     uint32_t* hist, size_t hist_elems)
+{
+    if (n == 0 || nbits_total <= 0) return 0;
+    const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
+    const int npass = (nbits_total + 7) / 8;
+    const int dbits = (nbits_total + npass - 1) / npass;
+    const int nbins = 1 << dbits;
+    const size_t hist_n = (size_t)nbins * nblocks;
+    if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
+    uint32_t* scan_scratch = hist + hist_n + 1 + 63;
+    const size_t scan_elems = hist_elems - (hist_n + 1 + 63);
+    int cur = 0;
+    for (int pass = 0; pass < npass; pass++) {
+        const int shift = pass * dbits;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, shift, nbins, hist, nblocks);
+        IBGS_HIP(hipGetLastError());
+        int rc = exclusive_scan_u32(s, hist, hist, hist_n, scan_scratch, scan_elems, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                           n, shift, dbits, nbins, hist, nblocks);
+        IBGS_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    if (cur != 0) {   // odd number of passes: bring the result back to buffer 0
+        IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+}  // namespace ibgs

@@ -1,0 +1,420 @@
+"""Host-side mirror of the reference operator for the plane rasterizer.
+
+Same names, argument order, return values and error behaviour as
+``submodules/diff-plane-rasterization/diff_plane_rasterization/__init__.py`` (reference), so that
+``gaussian_renderer.render()`` / ``train.py`` / ``render.py`` can import it unchanged:
+
+* ``GaussianRasterizationSettings``  (reference :252-276, 21 fields, same order)
+* ``GaussianRasterizer``             (reference :278-331; ``forward`` and ``markVisible``)
+* ``rasterize_gaussians`` / ``_RasterizeGaussians`` (reference :21-250; 11 inputs, 9 outputs, 11 grads)
+* ``_C``  -- an object with ``rasterize_gaussians`` (29 args), ``rasterize_gaussians_backward`` (34 args)
+  and ``mark_visible`` like the reference's pybind module (ext.cpp:15-19, rasterize_points.cu:37-292),
+  implemented over the C ABI of ``libibgs_rast.so`` (include/ibgs_rast.h).
+
+PyTorch is used for device memory, streams and autograd plumbing only; all arithmetic happens in the
+HIP library.  If the library is missing the import of ``_lib`` raises -- there is no fallback.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+NUM_CHANNELS = 3
+NUM_NORMAL_CHANNELS = 3
+NUM_PLANE_PARAMS = 5
+M_SRC = _lib.MAX_SRC
+
+# Tests may flip this to emulate the CUDA texture unit's 8-bit filter weights.
+TEX_QUANT = False
+
+_tex_scratch = {}
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+def _dev_f32(t, device):
+    """contiguous fp32 tensor on `device`, or None for the reference's 'empty tensor = not provided'."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _tex(device, nbytes):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _tex_scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _tex_scratch[key] = buf
+    return buf
+
+
+def _zero_plane(c, H, W, device, dtype=torch.float32):
+    """Outputs that the selected mode never writes: zeros of the reference's shape without the
+    reference's per-call memset (rasterize_points.cu:80-90 fills 47 planes every forward)."""
+    return torch.zeros(1, dtype=dtype, device=device).expand(c, H, W)
+
+
+class _CModule:
+    """Stand-in for the reference's pybind module ``diff_plane_rasterization._C``."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                            cov3D_precomp, all_map, viewmatrix, projmatrix, ref_to_src_list, src_cam_pos,
+                            src_images, src_rendered_depths, nb_src_images, buffer_length,
+                            depth_error_threshold, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                            campos, prefiltered, render_geo, render_depth_only, debug):
+        lib = _lib.load()
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:69-71
+        if not means3D.is_cuda:
+            raise RuntimeError("means3D must live on a HIP device (libibgs_rast.so has no CPU path)")
+        device = means3D.device
+        P = int(means3D.size(0)); H = int(image_height); W = int(image_width)
+        render_geo = bool(render_geo); render_depth_only = bool(render_depth_only)
+
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            means3D_c = _dev_f32(means3D, device)
+            sh_c = _dev_f32(sh, device); colors_c = _dev_f32(colors, device)
+            opacity_c = _dev_f32(opacity, device)
+            scales_c = _dev_f32(scales, device); rot_c = _dev_f32(rotations, device)
+            cov_c = _dev_f32(cov3D_precomp, device); all_map_c = _dev_f32(all_map, device)
+            bg_c = _dev_f32(background, device); vm_c = _dev_f32(viewmatrix, device); pm_c = _dev_f32(projmatrix, device)
+            campos_c = _dev_f32(campos, device)
+            r2s_c = _dev_f32(ref_to_src_list, device); scp_c = _dev_f32(src_cam_pos, device)
+            simg_c = _dev_f32(src_images, device); sdep_c = _dev_f32(src_rendered_depths, device)
+
+            radii = torch.zeros(P, dtype=torch.int32, device=device)
+            write_color = not render_depth_only
+            out_color = torch.zeros(NUM_CHANNELS, H, W, device=device) if write_color else _zero_plane(NUM_CHANNELS, H, W, device)
+            if render_geo:
+                out_normal = torch.zeros(NUM_NORMAL_CHANNELS, H, W, device=device)
+                out_depth = torch.zeros(1, H, W, device=device)
+                out_cam_feat = torch.zeros(4 * M_SRC, H, W, device=device)
+                out_warped = torch.zeros(3 * M_SRC, H, W, device=device)
+                out_min_depth_diff = torch.zeros(1, H, W, device=device)
+                out_camera_ray = torch.zeros(3, H, W, device=device)
+                out_mask = torch.zeros(1, H, W, dtype=torch.int32, device=device)
+            else:
+                out_normal = _zero_plane(NUM_NORMAL_CHANNELS, H, W, device)
+                out_depth = torch.zeros(1, H, W, device=device) if render_depth_only else _zero_plane(1, H, W, device)
+                out_cam_feat = _zero_plane(4 * M_SRC, H, W, device)
+                out_warped = _zero_plane(3 * M_SRC, H, W, device)
+                out_min_depth_diff = _zero_plane(1, H, W, device)
+                out_camera_ray = _zero_plane(3, H, W, device)
+                out_mask = _zero_plane(1, H, W, device, torch.int32)
+
+            geomBuffer = torch.empty(0, dtype=torch.uint8, device=device)
+            binningBuffer = torch.empty(0, dtype=torch.uint8, device=device)
+            imgBuffer = torch.empty(0, dtype=torch.uint8, device=device)
+            rendered = 0
+            if P != 0:
+                M = 0 if sh_c is None else int(sh_c.size(1))
+                geomBuffer = torch.empty(lib.ibgs_required_geom(P), dtype=torch.uint8, device=device)
+                imgBuffer = torch.empty(lib.ibgs_required_img(W, H), dtype=torch.uint8, device=device)
+                holder = {}
+
+                def _alloc(nbytes, _user):
+                    try:
+                        holder["t"] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                        return holder["t"].data_ptr()
+                    except Exception as ex:  # surfaces as IBGS_ERR_ALLOC
+                        holder["err"] = ex
+                        return 0
+
+                cb = _lib.ALLOC_FN(_alloc)
+                a = _lib.ForwardArgs()
+                a.stream = stream
+                a.P, a.D, a.M, a.W, a.H = P, int(degree), M, W, H
+                a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c)
+                a.opacities = _ptr(opacity_c); a.scales = _ptr(scales_c); a.rotations = _ptr(rot_c)
+                a.cov3D_precomp = _ptr(cov_c); a.all_map = _ptr(all_map_c)
+                a.scale_modifier = float(scale_modifier)
+                a.bg = _ptr(bg_c); a.viewmatrix = _ptr(vm_c); a.projmatrix = _ptr(pm_c); a.campos = _ptr(campos_c)
+                a.tanfovx = float(tan_fovx); a.tanfovy = float(tan_fovy)
+                a.n_src = int(nb_src_images)
+                a.ref_to_src = _ptr(r2s_c); a.src_cam_pos = _ptr(scp_c); a.src_images = _ptr(simg_c); a.src_depths = _ptr(sdep_c)
+                a.buffer_length = int(buffer_length); a.depth_error_threshold = float(depth_error_threshold)
+                a.prefiltered = int(bool(prefiltered)); a.render_geo = int(render_geo); a.render_depth_only = int(render_depth_only)
+                a.flags = (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                a.geom = geomBuffer.data_ptr(); a.geom_bytes = geomBuffer.numel()
+                a.img = imgBuffer.data_ptr(); a.img_bytes = imgBuffer.numel()
+                a.binning_alloc = cb; a.binning_user = None
+                if render_geo:
+                    if simg_c is None or simg_c.numel() < int(nb_src_images) * 3 * H * W:
+                        raise RuntimeError("src_images must hold nb_src_images x 3 x H x W values")
+                    if sdep_c is None or sdep_c.numel() < int(nb_src_images) * H * W:
+                        raise RuntimeError("src_rendered_depths must hold nb_src_images x 1 x H x W values")
+                    tex = _tex(device, lib.ibgs_required_tex(int(nb_src_images), W, H))
+                    a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
+                a.out_color = out_color.data_ptr() if write_color else None
+                a.radii = radii.data_ptr()
+                if render_geo:
+                    a.out_normal = out_normal.data_ptr(); a.out_depth = out_depth.data_ptr()
+                    a.out_cam_feat = out_cam_feat.data_ptr(); a.out_warped = out_warped.data_ptr()
+                    a.out_min_depth_diff = out_min_depth_diff.data_ptr(); a.out_camera_ray = out_camera_ray.data_ptr()
+                    a.out_mask = out_mask.data_ptr()
+                elif render_depth_only:
+                    a.out_depth = out_depth.data_ptr()
+                rc = lib.ibgs_forward(ctypes.byref(a))
+                if rc < 0:
+                    if "err" in holder:
+                        raise holder["err"]
+                    raise RuntimeError("ibgs_forward failed (%d): %s" % (rc, _lib.last_error()))
+                rendered = int(rc)
+                binningBuffer = holder.get("t", binningBuffer)
+        return (rendered, out_color, radii, out_normal, out_depth, out_cam_feat, out_warped, out_min_depth_diff,
+                out_camera_ray, out_mask, geomBuffer, binningBuffer, imgBuffer)
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, normal_map_pixels, intersected_depth_pixels, warped_image_pixels,
+                                     means3D, radii, colors, all_maps, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, ref_to_src_list, src_cam_pos,
+                                     src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
+                                     dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
+                                     dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                     imageBuffer, render_geo, debug):
+        lib = _lib.load()
+        device = means3D.device
+        P = int(means3D.size(0))
+        H = int(normal_map_pixels.size(1)); W = int(normal_map_pixels.size(2))
+        render_geo = bool(render_geo)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            sh_c = _dev_f32(sh, device)
+            M = 0 if sh_c is None else int(sh_c.size(1))
+            opts = dict(dtype=torch.float32, device=device)
+            dL_dmeans3D = torch.zeros(P, 3, **opts); dL_dmeans2D = torch.zeros(P, 3, **opts)
+            dL_dmeans2D_abs = torch.zeros(P, 3, **opts); dL_dcolors = torch.zeros(P, NUM_CHANNELS, **opts)
+            dL_dall_map = torch.zeros(P, NUM_PLANE_PARAMS, **opts)
+            dL_dopacity = torch.zeros(P, 1, **opts); dL_dcov3D = torch.zeros(P, 6, **opts)
+            dL_dsh = torch.zeros(P, M, 3, **opts); dL_dscales = torch.zeros(P, 3, **opts)
+            dL_drotations = torch.zeros(P, 4, **opts)
+            if P != 0:
+                means3D_c = _dev_f32(means3D, device); colors_c = _dev_f32(colors, device)
+                scales_c = _dev_f32(scales, device); rot_c = _dev_f32(rotations, device)
+                cov_c = _dev_f32(cov3D_precomp, device); all_map_c = _dev_f32(all_maps, device)
+                bg_c = _dev_f32(background, device); vm_c = _dev_f32(viewmatrix, device); pm_c = _dev_f32(projmatrix, device)
+                campos_c = _dev_f32(campos, device)
+                r2s_c = _dev_f32(ref_to_src_list, device); scp_c = _dev_f32(src_cam_pos, device)
+                simg_c = _dev_f32(src_images, device); sdep_c = _dev_f32(src_rendered_depths, device)
+                g_color = _dev_f32(dL_dout_color, device)
+                g_normal = _dev_f32(dL_dout_normal_map, device) if render_geo else None
+                g_depth = _dev_f32(dL_dout_median_intersected_depth, device) if render_geo else None
+                g_warp = _dev_f32(dL_dout_warped_image, device) if render_geo else None
+                depth_c = _dev_f32(intersected_depth_pixels, device) if render_geo else None
+                warped_c = _dev_f32(warped_image_pixels, device) if render_geo else None
+                grad_acc = torch.zeros(P, 16, **opts)
+                radii_c = radii.contiguous()
+                a = _lib.BackwardArgs()
+                a.stream = stream
+                a.P, a.D, a.M, a.W, a.H = P, int(degree), M, W, H
+                a.R = int(R)
+                a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c)
+                a.scales = _ptr(scales_c); a.rotations = _ptr(rot_c); a.cov3D_precomp = _ptr(cov_c); a.all_map = _ptr(all_map_c)
+                a.scale_modifier = float(scale_modifier)
+                a.bg = _ptr(bg_c); a.viewmatrix = _ptr(vm_c); a.projmatrix = _ptr(pm_c); a.campos = _ptr(campos_c)
+                a.tanfovx = float(tan_fovx); a.tanfovy = float(tan_fovy)
+                a.n_src = int(nb_src_images)
+                a.ref_to_src = _ptr(r2s_c); a.src_cam_pos = _ptr(scp_c); a.src_images = _ptr(simg_c); a.src_depths = _ptr(sdep_c)
+                a.radii = radii_c.data_ptr()
+                a.out_depth = _ptr(depth_c); a.out_warped = _ptr(warped_c)
+                a.geom = geomBuffer.data_ptr(); a.binning = binningBuffer.data_ptr() if binningBuffer.numel() else None
+                a.img = imageBuffer.data_ptr()
+                if render_geo:
+                    tex = _tex(device, lib.ibgs_required_tex(int(nb_src_images), W, H))
+                    a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
+                a.dL_dcolor = _ptr(g_color); a.dL_dnormal = _ptr(g_normal); a.dL_ddepth = _ptr(g_depth); a.dL_dwarped = _ptr(g_warp)
+                a.grad_acc = grad_acc.data_ptr()
+                a.dL_dmean2D = dL_dmeans2D.data_ptr(); a.dL_dmean2D_abs = dL_dmeans2D_abs.data_ptr()
+                a.dL_dconic = None
+                a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr()
+                a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr()
+                a.dL_dsh = dL_dsh.data_ptr() if M else None
+                a.dL_dscale = dL_dscales.data_ptr(); a.dL_drot = dL_drotations.data_ptr()
+                a.dL_dall_map = dL_dall_map.data_ptr()
+                a.render_geo = int(render_geo)
+                a.flags = (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                rc = lib.ibgs_backward(ctypes.byref(a))
+                if rc < 0:
+                    raise RuntimeError("ibgs_backward failed (%d): %s" % (rc, _lib.last_error()))
+        return (dL_dmeans2D, dL_dmeans2D_abs, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                dL_dscales, dL_drotations, dL_dall_map)
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        lib = _lib.load()
+        device = means3D.device
+        P = int(means3D.size(0))
+        present = torch.zeros(P, dtype=torch.bool, device=device)
+        if P != 0:
+            with torch.cuda.device(device):
+                m = _dev_f32(means3D, device); vm = _dev_f32(viewmatrix, device); pm = _dev_f32(projmatrix, device)
+                rc = lib.ibgs_mark_visible(torch.cuda.current_stream(device).cuda_stream, P, m.data_ptr(),
+                                           vm.data_ptr(), _ptr(pm), present.data_ptr())
+                if rc < 0:
+                    raise RuntimeError("ibgs_mark_visible failed (%d): %s" % (rc, _lib.last_error()))
+        return present
+
+
+_C = _CModule()
+
+
+def rasterize_gaussians(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, all_map, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, all_map, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, all_maps, raster_settings):
+        # argument order of the reference's _C.rasterize_gaussians (reference __init__.py:66-98)
+        args = (
+            raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
+            raster_settings.scale_modifier, cov3Ds_precomp, all_maps,
+            raster_settings.viewmatrix, raster_settings.projmatrix,
+            raster_settings.ref_to_src_list, raster_settings.src_cam_pos, raster_settings.src_images,
+            raster_settings.src_rendered_depths, raster_settings.nb_src_images,
+            raster_settings.buffer_length, raster_settings.depth_error_threshold,
+            raster_settings.tanfovx, raster_settings.tanfovy,
+            raster_settings.image_height, raster_settings.image_width,
+            sh, raster_settings.sh_degree, raster_settings.campos, raster_settings.prefiltered,
+            raster_settings.render_geo, raster_settings.render_depth_only, raster_settings.debug,
+        )
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            try:
+                res = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            res = _C.rasterize_gaussians(*args)
+        (num_rendered, color, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
+         out_min_depth_diff, out_camera_ray, out_use_first_src_frame, geomBuffer, binningBuffer, imgBuffer) = res
+
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        # outputs that the loss does not touch arrive as None instead of freshly zero-filled planes
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(out_normal_map, out_median_intersected_depth, out_warped_image, colors_precomp,
+                              all_maps, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii, out_use_first_src_frame)
+        return (color, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
+                out_min_depth_diff, out_camera_ray, out_use_first_src_frame)
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_out_normal_map, grad_out_median_intersected_depth,
+                 grad_out_cam_feat, grad_out_warped_image, grad_out_min_depth_diff, grad_out_camera_ray,
+                 grad_out_use_first_src_frame):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels, colors_precomp, all_maps, means3D,
+         scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+
+        # argument order of the reference's _C.rasterize_gaussians_backward (reference __init__.py:182-221)
+        args = (raster_settings.bg, normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels,
+                means3D, radii, colors_precomp, all_maps, scales, rotations, raster_settings.scale_modifier,
+                cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix,
+                raster_settings.ref_to_src_list, raster_settings.src_cam_pos, raster_settings.src_images,
+                raster_settings.src_rendered_depths, raster_settings.nb_src_images,
+                raster_settings.tanfovx, raster_settings.tanfovy,
+                grad_out_color, grad_out_normal_map, grad_out_median_intersected_depth, grad_out_warped_image,
+                sh, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered, binningBuffer,
+                imgBuffer, raster_settings.render_geo, raster_settings.debug)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                res = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            res = _C.rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_means2D_abs, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
+         grad_sh, grad_scales, grad_rotations, grad_all_map) = res
+        return (grad_means3D, grad_means2D, grad_means2D_abs, grad_sh, grad_colors_precomp, grad_opacities,
+                grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_all_map, None)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    ref_to_src_list: torch.Tensor
+    src_cam_pos: torch.Tensor
+    src_images: torch.Tensor
+    src_rendered_depths: torch.Tensor
+    nb_src_images: int
+    buffer_length: int
+    depth_error_threshold: float
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    render_geo: bool
+    render_depth_only: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # boolean mask of points passing the near-plane test of the camera (reference :283-292)
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, means2D_abs, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None, all_map=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        if all_map is None:
+            all_map = torch.Tensor([])
+
+        return rasterize_gaussians(means3D, means2D, means2D_abs, shs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, all_map, raster_settings)

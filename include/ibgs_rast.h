@@ -1,0 +1,188 @@
+/*
+ * ibgs_rast.h -- C ABI of libibgs_rast.so, the MI355X (gfx950) plane rasterizer for IBGS.
+ *
+ * This is the drop-in boundary for the reference's native rasterizer library
+ * (/root/reference/submodules/diff-plane-rasterization/, "DPR/" below):
+ *
+ *   ibgs_forward       replaces CudaRasterizer::Rasterizer::forward   (DPR/cuda_rasterizer/rasterizer.h:98-144,
+ *                      rasterizer_impl.cu:320-515) as called by RasterizeGaussiansCUDA (DPR/rasterize_points.cu:37-160)
+ *   ibgs_backward      replaces CudaRasterizer::Rasterizer::backward  (rasterizer.h:146-203, rasterizer_impl.cu:519-666)
+ *                      as called by RasterizeGaussiansBackwardCUDA (rasterize_points.cu:162-271)
+ *   ibgs_mark_visible  replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:91-96, rasterizer_impl.cu:258-270)
+ *   ibgs_required_*    replace  CudaRasterizer::required<GeometryState|ImageState|BinningState>
+ *                      (rasterizer_impl.h:69-76) -- arena sizes for caller-owned scratch
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous memory unless its name starts with "host_";
+ *     fp32 / int32 element types as named; a NULL input pointer means "not provided"
+ *     (the reference's empty-tensor convention, DPR/diff_plane_rasterization/__init__.py:304-316);
+ *   - `stream` is a hipStream_t passed as void*; every kernel and copy is issued on it;
+ *   - scratch arenas (geom / binning / img) are owned by the caller and must stay alive and
+ *     unmodified between a forward and its backward (the reference keeps them in the autograd
+ *     ctx, DPR/diff_plane_rasterization/__init__.py:133-140); the library keeps no state;
+ *   - gradient outputs of ibgs_backward must arrive ZEROED (rasterize_points.cu:209-219);
+ *   - return value: >= 0 on success (ibgs_forward: the number of rendered (Gaussian, tile)
+ *     instances R), < 0 = -(IBGS_ERR_*). ibgs_last_error() returns a static message.
+ */
+#ifndef IBGS_RAST_H
+#define IBGS_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBGS_MAX_SRC 5           /* DPR/cuda_rasterizer/auxiliary.h:22-23 (MAX_M, M) */
+#define IBGS_MAX_BUFFER_LENGTH 8 /* auxiliary.h:21 */
+#define IBGS_TILE 16             /* config.h: BLOCK_X, BLOCK_Y */
+
+#define IBGS_ERR_INVALID 1  /* bad argument combination */
+#define IBGS_ERR_HIP 2      /* HIP runtime error (message has the HIP string) */
+#define IBGS_ERR_ALLOC 3    /* arena callback returned NULL / arena too small */
+
+/* Arena callback: must return a device pointer to at least `bytes` bytes (128-B aligned is
+ * enough).  Mirrors std::function<char*(size_t)> of the reference (rasterizer.h:101-103,
+ * rasterize_points.cu:29-35). */
+typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
+
+/* Option flags (ibgs_forward_args.flags / ibgs_backward_args.flags) */
+#define IBGS_FLAG_DEBUG 1u      /* synchronise + check after every stage (auxiliary.h:170-177) */
+#define IBGS_FLAG_TEX_QUANT 2u  /* emulate the CUDA texture unit's 8-bit filter weights */
+
+typedef struct ibgs_forward_args {
+    void* stream;
+    /* problem size */
+    int32_t P;         /* number of Gaussians */
+    int32_t D;         /* active SH degree (0..3) */
+    int32_t M;         /* SH coefficients per Gaussian in memory (shs is P x M x 3) */
+    int32_t W, H;
+    /* per-Gaussian inputs */
+    const float* means3D;        /* P x 3 */
+    const float* shs;            /* P x M x 3 or NULL */
+    const float* colors_precomp; /* P x 3 or NULL */
+    const float* opacities;      /* P */
+    const float* scales;         /* P x 3 or NULL */
+    const float* rotations;      /* P x 4 (w,x,y,z) or NULL */
+    const float* cov3D_precomp;  /* P x 6 or NULL */
+    const float* all_map;        /* P x 5 or NULL */
+    float scale_modifier;
+    /* camera */
+    const float* bg;         /* 3 */
+    const float* viewmatrix; /* 16, transposed world->view (scene/cameras.py:102) */
+    const float* projmatrix; /* 16, transposed full projection (cameras.py:104) */
+    const float* campos;     /* 3 */
+    float tanfovx, tanfovy;
+    /* source views (geo path) */
+    int32_t n_src;              /* 1..IBGS_MAX_SRC */
+    const float* ref_to_src;    /* n_src x 16, row-major true matrices */
+    const float* src_cam_pos;   /* n_src x 3 */
+    const float* src_images;    /* n_src x 3 x H x W */
+    const float* src_depths;    /* n_src x 1 x H x W */
+    int32_t buffer_length;      /* 1..IBGS_MAX_BUFFER_LENGTH */
+    float depth_error_threshold;
+    /* modes */
+    int32_t prefiltered;
+    int32_t render_geo;
+    int32_t render_depth_only;
+    uint32_t flags;
+    /* scratch arenas */
+    char* geom;  size_t geom_bytes;    /* >= ibgs_required_geom(P) */
+    char* img;   size_t img_bytes;     /* >= ibgs_required_img(W, H) */
+    ibgs_alloc_fn binning_alloc;       /* called once with ibgs_required_binning(R, W, H) */
+    void* binning_user;
+    char* tex;   size_t tex_bytes;     /* render_geo only: >= ibgs_required_tex(n_src, W, H); contents are
+                                          transient (packed RGBA source images), may be shared between calls */
+    /* outputs; planes must arrive zeroed where the mode leaves them untouched.
+     * Pointers the mode does not write may be NULL. */
+    float* out_color;          /* 3 x H x W */
+    int32_t* radii;            /* P */
+    float* out_normal;         /* 3 x H x W   (render_geo) */
+    float* out_depth;          /* 1 x H x W   (render_geo or render_depth_only) */
+    float* out_cam_feat;       /* 20 x H x W  (render_geo) */
+    float* out_warped;         /* 15 x H x W  (render_geo) */
+    float* out_min_depth_diff; /* 1 x H x W   (render_geo) */
+    float* out_camera_ray;     /* 3 x H x W   (render_geo) */
+    int32_t* out_mask;         /* 1 x H x W   (render_geo) */
+} ibgs_forward_args;
+
+typedef struct ibgs_backward_args {
+    void* stream;
+    int32_t P, D, M, W, H;
+    int64_t R;                   /* value returned by ibgs_forward */
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* all_map;
+    float scale_modifier;
+    const float* bg;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    float tanfovx, tanfovy;
+    int32_t n_src;
+    const float* ref_to_src;
+    const float* src_cam_pos;
+    const float* src_images;
+    const float* src_depths;
+    const int32_t* radii;
+    /* forward results that the kernels re-read (backward.cu:705, 734) */
+    const float* out_depth;   /* median depth, 1 x H x W */
+    const float* out_warped;  /* 15 x H x W */
+    /* arenas exactly as the forward left them */
+    char* geom; char* binning; char* img;
+    char* tex; size_t tex_bytes;   /* render_geo only: transient scratch, >= ibgs_required_tex(n_src, W, H) */
+    /* incoming gradients (NULL = zero) */
+    const float* dL_dcolor;   /* 3 x H x W */
+    const float* dL_dnormal;  /* 3 x H x W */
+    const float* dL_ddepth;   /* 1 x H x W */
+    const float* dL_dwarped;  /* 15 x H x W */
+    /* scratch: P x 16 floats, ZEROED by the caller (per-Gaussian accumulation rows) */
+    float* grad_acc;
+    /* gradient outputs, zeroed by the caller */
+    float* dL_dmean2D;     /* P x 3 */
+    float* dL_dmean2D_abs; /* P x 3 */
+    float* dL_dconic;      /* P x 4 (x,y,w used) */
+    float* dL_dopacity;    /* P */
+    float* dL_dcolors;     /* P x 3 */
+    float* dL_dmean3D;     /* P x 3 */
+    float* dL_dcov3D;      /* P x 6 */
+    float* dL_dsh;         /* P x M x 3 */
+    float* dL_dscale;      /* P x 3 */
+    float* dL_drot;        /* P x 4 */
+    float* dL_dall_map;    /* P x 5 */
+    int32_t render_geo;
+    uint32_t flags;
+} ibgs_backward_args;
+
+size_t ibgs_required_geom(int32_t P);
+size_t ibgs_required_img(int32_t W, int32_t H);
+size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H);
+size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H);
+
+int64_t ibgs_forward(const ibgs_forward_args* args);
+int32_t ibgs_backward(const ibgs_backward_args* args);
+int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
+                          const float* projmatrix, uint8_t* present /* P bools */);
+
+/* Introspection for tests: byte offsets of the named sub-arrays inside the arenas.
+ * Returns -1 for an unknown name. Names: see DESIGN.md "Arena layout". */
+int64_t ibgs_geom_offset(int32_t P, const char* name);
+int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name);
+int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name);
+
+/* ABI self-check for FFI bindings: sizeof the two argument structs as this library was built. */
+size_t ibgs_sizeof_forward_args(void);
+size_t ibgs_sizeof_backward_args(void);
+
+const char* ibgs_last_error(void);
+const char* ibgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IBGS_RAST_H */

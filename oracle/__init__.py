@@ -1,0 +1,224 @@
+"""CPU oracle for the IBGS plane rasterizer -- TEST INFRASTRUCTURE ONLY.
+
+Thin numpy/ctypes front-end over ``ibgs_oracle.c`` (the C restatement of the reference's
+CUDA rasterizer; every C function cites the reference file:line it follows).  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; the product path (``ibgs_amd``) never does.
+
+PARITY STATUS: "parity unpinned" -- see the header of ``ibgs_oracle.c`` and DESIGN.md.
+
+The front-end mirrors the stage order of ``CudaRasterizer::Rasterizer::forward/backward``
+(cuda_rasterizer/rasterizer_impl.cu:320-515, 519-666) and the tensor allocation of
+``RasterizeGaussiansCUDA`` / ``RasterizeGaussiansBackwardCUDA`` (rasterize_points.cu:37-271).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libibgs_oracle.so")
+_SRC = os.path.join(_HERE, "ibgs_oracle.c")
+_lib = None
+
+MAX_SRC = 5
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (a few seconds)."""
+    if (not force) and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
+           "-o", _SO, _SRC, "-lm"]
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_bin_count.restype = ctypes.c_int64
+        _lib.orc_higher_msb.restype = ctypes.c_uint32
+    return _lib
+
+
+def _p(a):
+    """numpy array (or None) -> void*"""
+    if a is None:
+        return ctypes.c_void_p(0)
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be contiguous"
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _f32(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    return a if a.size else None
+
+
+def _cf(x):
+    return ctypes.c_float(float(x))
+
+
+def _ci(x):
+    return ctypes.c_int(int(x))
+
+
+def tile_grid(W, H):
+    return (W + 15) // 16, (H + 15) // 16
+
+
+def mark_visible(means3D, viewmatrix):
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    out = np.zeros(P, dtype=np.uint8)
+    lib().orc_mark_visible(_ci(P), _p(means3D), _p(_f32(viewmatrix).reshape(-1)), _p(out))
+    return out.astype(bool)
+
+
+def forward(inp, tex_quant=False):
+    """Run the full forward.  ``inp`` is a dict of numpy arrays / scalars:
+
+    means3D (P,3), opacities (P,) or (P,1), one of {shs (P,M,3) | colors_precomp (P,3)},
+    one of {scales (P,3) + rotations (P,4) | cov3D_precomp (P,6)}, all_map (P,5) or None,
+    bg (3,), viewmatrix (16,) / (4,4) [transposed convention], projmatrix, campos (3,),
+    W, H, tanfovx, tanfovy, sh_degree, scale_modifier,
+    n_src, ref_to_src (n,16), src_cam_pos (n,3), src_images (n,3,H,W), src_depths (n,1,H,W),
+    buffer_length, depth_thr, render_geo, render_depth_only.
+
+    Returns a dict with the 9 public outputs plus every internal state array.
+    """
+    L = lib()
+    means3D = _f32(inp["means3D"]); P = means3D.shape[0]
+    W, H = int(inp["W"]), int(inp["H"]); HW = W * H
+    gx, gy = tile_grid(W, H)
+    shs = _f32(inp.get("shs")); colors_precomp = _f32(inp.get("colors_precomp"))
+    scales = _f32(inp.get("scales")); rotations = _f32(inp.get("rotations"))
+    cov3D_precomp = _f32(inp.get("cov3D_precomp")); all_map = _f32(inp.get("all_map"))
+    opac = _f32(inp["opacities"]).reshape(-1)
+    vm = _f32(inp["viewmatrix"]).reshape(-1); pm = _f32(inp["projmatrix"]).reshape(-1)
+    campos = _f32(inp["campos"]).reshape(-1); bg = _f32(inp["bg"]).reshape(-1)
+    D = int(inp.get("sh_degree", 0)); M = 0 if shs is None else int(shs.shape[1])
+    mod = float(inp.get("scale_modifier", 1.0))
+    tanx, tany = float(inp["tanfovx"]), float(inp["tanfovy"])
+    render_geo = bool(inp.get("render_geo", False)); depth_only = bool(inp.get("render_depth_only", False))
+    n_src = int(inp.get("n_src", 1)); Lbuf = int(inp.get("buffer_length", 4)); thr = float(inp.get("depth_thr", 0.01))
+    ref_to_src = _f32(inp.get("ref_to_src")); src_cam_pos = _f32(inp.get("src_cam_pos"))
+    src_images = _f32(inp.get("src_images")); src_depths = _f32(inp.get("src_depths"))
+    if ref_to_src is None: ref_to_src = np.zeros((n_src, 16), np.float32)
+    if src_cam_pos is None: src_cam_pos = np.zeros((n_src, 3), np.float32)
+    if src_images is None: src_images = np.zeros((n_src, 3, H, W), np.float32)
+    if src_depths is None: src_depths = np.zeros((n_src, 1, H, W), np.float32)
+
+    st = {}
+    st["radii"] = np.zeros(P, np.int32); st["means2D"] = np.zeros((P, 2), np.float32)
+    st["depths"] = np.zeros(P, np.float32); st["cov3D"] = np.zeros((P, 6), np.float32)
+    st["rgb"] = np.zeros((P, 3), np.float32); st["conic_opacity"] = np.zeros((P, 4), np.float32)
+    st["tiles_touched"] = np.zeros(P, np.uint32); st["clamped"] = np.zeros((P, 3), np.uint8)
+    out = {
+        "color": np.zeros((3, H, W), np.float32), "normal_map": np.zeros((3, H, W), np.float32),
+        "median_depth": np.zeros((1, H, W), np.float32), "cam_feat": np.zeros((4 * MAX_SRC, H, W), np.float32),
+        "warped_image": np.zeros((3 * MAX_SRC, H, W), np.float32), "min_depth_diff": np.zeros((1, H, W), np.float32),
+        "camera_ray": np.zeros((3, H, W), np.float32), "use_first_src_frame_mask": np.zeros((1, H, W), np.int32),
+    }
+    st["ranges"] = np.zeros((gx * gy, 2), np.uint32)
+    st["final_T"] = np.zeros(HW, np.float32); st["n_contrib"] = np.zeros(HW, np.uint32)
+    st["cache_sum_w"] = np.zeros(HW, np.float32); st["cache_low"] = np.zeros(HW, np.uint32)
+    st["cache_high"] = np.zeros(HW, np.uint32)
+    st["valid_src_idx"] = np.full((MAX_SRC, HW), -1, np.int32); st["valid_src_w"] = np.zeros((MAX_SRC, HW), np.float32)
+    if P == 0:   # rasterize_points.cu:101-102
+        st["point_list"] = np.zeros(0, np.uint32); st["keys"] = np.zeros(0, np.uint64)
+        out.update(st); out["num_rendered"] = 0
+        return out
+
+    L.orc_preprocess(_ci(P), _ci(D), _ci(M), _p(means3D), _p(scales), _cf(mod), _p(rotations), _p(opac), _p(shs),
+                     _p(cov3D_precomp), _p(colors_precomp), _p(vm), _p(pm), _p(campos), _ci(W), _ci(H),
+                     _cf(tanx), _cf(tany), _ci(depth_only),
+                     _p(st["radii"]), _p(st["means2D"]), _p(st["depths"]), _p(st["cov3D"]), _p(st["rgb"]),
+                     _p(st["conic_opacity"]), _p(st["tiles_touched"]), _p(st["clamped"]))
+    R = int(L.orc_bin_count(_ci(P), _p(st["tiles_touched"])))
+    st["keys"] = np.zeros(R, np.uint64); st["point_list"] = np.zeros(R, np.uint32)
+    rc = L.orc_bin(_ci(P), ctypes.c_int64(R), _p(st["radii"]), _p(st["means2D"]), _p(st["depths"]), _ci(W), _ci(H),
+                   _p(st["keys"]), _p(st["point_list"]), _p(st["ranges"]))
+    assert rc == 0, "oracle binning failed (%d)" % rc
+    feats = colors_precomp if colors_precomp is not None else st["rgb"]
+    L.orc_render_forward(_ci(W), _ci(H), _p(st["ranges"]), _p(st["point_list"]), _p(st["means2D"]), _p(feats),
+                         _p(all_map), _p(st["conic_opacity"]), _p(vm), _p(campos), _p(bg), _cf(tanx), _cf(tany),
+                         _ci(n_src), _p(ref_to_src.reshape(-1)), _p(src_cam_pos.reshape(-1)),
+                         _p(src_images.reshape(-1)), _p(src_depths.reshape(-1)), _ci(Lbuf), _cf(thr),
+                         _ci(render_geo), _ci(depth_only), _ci(bool(tex_quant)),
+                         _p(st["final_T"]), _p(st["n_contrib"]), _p(st["cache_sum_w"]), _p(st["cache_low"]),
+                         _p(st["cache_high"]), _p(st["valid_src_idx"]), _p(st["valid_src_w"]),
+                         _p(out["color"]), _p(out["normal_map"]), _p(out["median_depth"]), _p(out["cam_feat"]),
+                         _p(out["warped_image"]), _p(out["min_depth_diff"]), _p(out["camera_ray"]),
+                         _p(out["use_first_src_frame_mask"]))
+    out.update(st)
+    out["num_rendered"] = R
+    return out
+
+
+def backward(inp, fwd, dL_dcolor, dL_dnormal=None, dL_ddepth=None, dL_dwarped=None, tex_quant=False):
+    """Full backward given ``forward``'s result.  Returns the reference's 10 gradients
+    (rasterize_points.cu:209-219, 270) plus dL_dconic."""
+    L = lib()
+    means3D = _f32(inp["means3D"]); P = means3D.shape[0]
+    W, H = int(inp["W"]), int(inp["H"])
+    shs = _f32(inp.get("shs")); colors_precomp = _f32(inp.get("colors_precomp"))
+    scales = _f32(inp.get("scales")); rotations = _f32(inp.get("rotations"))
+    cov3D_precomp = _f32(inp.get("cov3D_precomp")); all_map = _f32(inp.get("all_map"))
+    vm = _f32(inp["viewmatrix"]).reshape(-1); pm = _f32(inp["projmatrix"]).reshape(-1)
+    campos = _f32(inp["campos"]).reshape(-1); bg = _f32(inp["bg"]).reshape(-1)
+    D = int(inp.get("sh_degree", 0)); M = 0 if shs is None else int(shs.shape[1])
+    mod = float(inp.get("scale_modifier", 1.0))
+    tanx, tany = float(inp["tanfovx"]), float(inp["tanfovy"])
+    render_geo = bool(inp.get("render_geo", False))
+    n_src = int(inp.get("n_src", 1))
+    ref_to_src = _f32(inp.get("ref_to_src")); src_images = _f32(inp.get("src_images"))
+    if ref_to_src is None: ref_to_src = np.zeros((n_src, 16), np.float32)
+    if src_images is None: src_images = np.zeros((n_src, 3, H, W), np.float32)
+    g_c = _f32(dL_dcolor)
+    g_n = _f32(dL_dnormal) if dL_dnormal is not None else np.zeros((3, H, W), np.float32)
+    g_d = _f32(dL_ddepth) if dL_ddepth is not None else np.zeros((1, H, W), np.float32)
+    g_w = _f32(dL_dwarped) if dL_dwarped is not None else np.zeros((3 * MAX_SRC, H, W), np.float32)
+    if g_n is None: g_n = np.zeros((3, H, W), np.float32)
+    if g_d is None: g_d = np.zeros((1, H, W), np.float32)
+    if g_w is None: g_w = np.zeros((3 * MAX_SRC, H, W), np.float32)
+
+    res = {
+        "dL_dmeans3D": np.zeros((P, 3), np.float32), "dL_dmeans2D": np.zeros((P, 3), np.float32),
+        "dL_dmeans2D_abs": np.zeros((P, 3), np.float32), "dL_dcolors": np.zeros((P, 3), np.float32),
+        "dL_dall_map": np.zeros((P, 5), np.float32), "dL_dconic": np.zeros((P, 4), np.float32),
+        "dL_dopacity": np.zeros((P, 1), np.float32), "dL_dcov3D": np.zeros((P, 6), np.float32),
+        "dL_dsh": np.zeros((P, M, 3), np.float32), "dL_dscales": np.zeros((P, 3), np.float32),
+        "dL_drotations": np.zeros((P, 4), np.float32),
+    }
+    if P == 0:
+        return res
+    acc_m = np.zeros((P, 2), np.float64); acc_ma = np.zeros((P, 2), np.float64)
+    acc_c = np.zeros((P, 3), np.float64); acc_o = np.zeros(P, np.float64)
+    acc_col = np.zeros((P, 3), np.float64); acc_am = np.zeros((P, 5), np.float64)
+    feats = colors_precomp if colors_precomp is not None else fwd["rgb"]
+    L.orc_render_backward(_ci(W), _ci(H), _p(fwd["ranges"]), _p(fwd["point_list"]), _p(fwd["means2D"]),
+                          _p(fwd["conic_opacity"]), _p(feats), _p(all_map), _p(bg), _cf(tanx), _cf(tany),
+                          _ci(n_src), _p(ref_to_src.reshape(-1)), _p(src_images.reshape(-1)),
+                          _p(fwd["median_depth"]), _p(fwd["warped_image"]),
+                          _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(fwd["cache_sum_w"]), _p(fwd["cache_low"]),
+                          _p(fwd["cache_high"]), _p(fwd["valid_src_idx"]), _p(fwd["valid_src_w"]),
+                          _p(g_c), _p(g_n), _p(g_d), _p(g_w), _ci(render_geo), _ci(bool(tex_quant)),
+                          _p(acc_m), _p(acc_ma), _p(acc_c), _p(acc_o), _p(acc_col), _p(acc_am))
+    res["dL_dmeans2D"][:, :2] = acc_m; res["dL_dmeans2D_abs"][:, :2] = acc_ma
+    res["dL_dconic"][:, 0] = acc_c[:, 0]; res["dL_dconic"][:, 1] = acc_c[:, 1]; res["dL_dconic"][:, 3] = acc_c[:, 2]
+    res["dL_dopacity"][:, 0] = acc_o; res["dL_dcolors"][:] = acc_col; res["dL_dall_map"][:] = acc_am
+    cov = cov3D_precomp if cov3D_precomp is not None else fwd["cov3D"]
+    L.orc_preprocess_backward(_ci(P), _ci(D), _ci(M), _p(means3D), _p(fwd["radii"]), _p(shs), _p(fwd["clamped"]),
+                              _p(scales), _p(rotations), _cf(mod), _p(cov), _p(vm), _p(pm), _p(campos),
+                              _ci(W), _ci(H), _cf(tanx), _cf(tany),
+                              _p(res["dL_dmeans2D"]), _p(res["dL_dconic"]), _p(res["dL_dcolors"]),
+                              _p(res["dL_dmeans3D"]), _p(res["dL_dcov3D"]), _p(res["dL_dsh"]),
+                              _p(res["dL_dscales"]), _p(res["dL_drotations"]))
+    return res
