@@ -74,7 +74,7 @@ class BackwardArgs(ctypes.Structure):
 EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "ibgs_required_tex",
            "ibgs_forward", "ibgs_backward", "ibgs_mark_visible",
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
-           "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args",
+           "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -122,6 +122,10 @@ def load():
     lib.ibgs_binning_offset.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p]
     lib.ibgs_last_error.restype = ctypes.c_char_p
     lib.ibgs_version.restype = ctypes.c_char_p
+    lib.ibgs_timing_enable.restype = None
+    lib.ibgs_timing_enable.argtypes = [ctypes.c_uint32]
+    lib.ibgs_timing_collect.restype = ctypes.c_int32
+    lib.ibgs_timing_collect.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.ibgs_sizeof_forward_args.restype = ctypes.c_size_t
     lib.ibgs_sizeof_backward_args.restype = ctypes.c_size_t
     if (lib.ibgs_sizeof_forward_args() != ctypes.sizeof(ForwardArgs)
@@ -129,6 +133,28 @@ def load():
         raise RasterizerLibraryError("ctypes struct layout does not match libibgs_rast.so (stale build?)")
     _lib = lib
     return lib
+
+
+STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render_fwd", "render_bwd",
+          "preprocess_bwd"]
+
+
+def timing_enable(stages):
+    """Bracket the named stages with hipEvents on the op's stream (bench.py roofline)."""
+    mask = 0
+    for s in stages:
+        mask |= 1 << STAGES.index(s)
+    load().ibgs_timing_enable(mask)
+
+
+def timing_collect():
+    """-> {stage: (total_ms, launches)} since the previous collect."""
+    ms = (ctypes.c_float * len(STAGES))()
+    n = (ctypes.c_int32 * len(STAGES))()
+    rc = load().ibgs_timing_collect(ms, n)
+    if rc < 0:
+        raise RuntimeError("ibgs_timing_collect failed: %s" % last_error())
+    return {STAGES[i]: (float(ms[i]), int(n[i])) for i in range(len(STAGES))}
 
 
 def last_error():

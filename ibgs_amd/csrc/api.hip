@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace ibgs {
 
@@ -83,6 +84,32 @@ BinState BinState::carve(char* base, size_t R, int W, int H, size_t* total)
     return b;
 }
 
+// ---- optional stage timing (bench.py roofline) ------------------------------------------------
+struct TimedPair { hipEvent_t a, b; int stage; };
+static uint32_t g_time_mask = 0;
+static std::vector<TimedPair> g_pairs;
+static std::vector<hipEvent_t> g_free_events;
+
+static hipEvent_t get_event()
+{
+    if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageTimer {   // RAII: records an event pair around one stage when that stage is selected
+    hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int stage; bool on;
+    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), on((g_time_mask >> stage_) & 1u)
+    {
+        if (on) { a = get_event(); b = get_event(); (void)hipEventRecord(a, s); }
+    }
+    ~StageTimer()
+    {
+        if (on) { (void)hipEventRecord(b, s); g_pairs.push_back({a, b, stage}); }
+    }
+};
+
 static int stage_check(hipStream_t s, bool debug, const char* what)
 {
     if (!debug) return 0;
@@ -100,6 +127,22 @@ extern "C" {
 
 const char* ibgs_last_error(void) { return g_err; }
 const char* ibgs_version(void) { return "ibgs_rast 0.1 (gfx950)"; }
+void ibgs_timing_enable(uint32_t stage_mask) { g_time_mask = stage_mask; }
+int32_t ibgs_timing_collect(float* ms, int32_t* launches)
+{
+    for (int i = 0; i < IBGS_NUM_STAGES; i++) { if (ms) ms[i] = 0.f; if (launches) launches[i] = 0; }
+    for (auto& p : g_pairs) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(p.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, p.a, p.b);
+        if (e != hipSuccess) { set_error("timing collect: %s", hipGetErrorString(e)); return -IBGS_ERR_HIP; }
+        if (ms) ms[p.stage] += t;
+        if (launches) launches[p.stage] += 1;
+        g_free_events.push_back(p.a); g_free_events.push_back(p.b);
+    }
+    g_pairs.clear();
+    return 0;
+}
 size_t ibgs_sizeof_forward_args(void) { return sizeof(ibgs_forward_args); }
 size_t ibgs_sizeof_backward_args(void) { return sizeof(ibgs_backward_args); }
 
@@ -172,12 +215,14 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     ImgState im = ImgState::carve(a.img, a.W, a.H, nullptr);
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
 
-    if ((rc = launch_preprocess(s, a, g))) return rc;
+    { StageTimer t(s, IBGS_STAGE_PREPROCESS); if ((rc = launch_preprocess(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess"))) return rc;
-    if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)a.P, 32, g.hist, g.hist_elems))) return rc;
+    { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
+      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)a.P, 32, g.hist, g.hist_elems))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
-    if ((rc = launch_gather_tiles(s, a.P, g))) return rc;
-    if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)a.P, g.hist, g.hist_elems, true))) return rc;
+    { StageTimer t(s, IBGS_STAGE_SCAN);
+      if ((rc = launch_gather_tiles(s, a.P, g))) return rc;
+      if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)a.P, g.hist, g.hist_elems, true))) return rc; }
     uint32_t R32 = 0;
     IBGS_HIP(hipMemcpyAsync(&R32, g.offsets + a.P, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     IBGS_HIP(hipStreamSynchronize(s));
@@ -187,12 +232,13 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)R); return -IBGS_ERR_ALLOC; }
     BinState b = BinState::carve(bin_mem, (size_t)R, a.W, a.H, nullptr);
 
-    if ((rc = launch_emit(s, a.P, R, gx, g, b))) return rc;
+    { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, a.P, R, gx, g, b))) return rc; }
     if ((rc = stage_check(s, debug, "emit"))) return rc;
     const int bit = (int)higher_msb((uint32_t)(gx * gy));
-    if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)R, bit, b.hist, b.hist_elems))) return rc;
+    { StageTimer t(s, IBGS_STAGE_TILE_SORT);
+      if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)R, bit, b.hist, b.hist_elems))) return rc; }
     if ((rc = stage_check(s, debug, "tile sort"))) return rc;
-    if ((rc = launch_ranges(s, R, gx * gy, b.keys[0], im.ranges))) return rc;
+    { StageTimer t(s, IBGS_STAGE_RANGES); if ((rc = launch_ranges(s, R, gx * gy, b.keys[0], im.ranges))) return rc; }
     if ((rc = stage_check(s, debug, "ranges"))) return rc;
 
     const float4* rgba = nullptr;
@@ -201,7 +247,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
         rgba = t;
     }
-    if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc;
+    { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }
     if ((rc = stage_check(s, debug, "render"))) return rc;
     return R;
 }
@@ -235,10 +281,10 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         rgba = t;
     }
     if (a.R > 0) {
-        if ((rc = launch_render_backward(s, a, g, b, im, rgba))) return rc;
+        { StageTimer t(s, IBGS_STAGE_RENDER_BWD); if ((rc = launch_render_backward(s, a, g, b, im, rgba))) return rc; }
         if ((rc = stage_check(s, debug, "render backward"))) return rc;
     }
-    if ((rc = launch_preprocess_backward(s, a, g))) return rc;
+    { StageTimer t(s, IBGS_STAGE_PREPROCESS_BWD); if ((rc = launch_preprocess_backward(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess backward"))) return rc;
     return 0;
 }

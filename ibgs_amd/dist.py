@@ -1,0 +1,106 @@
+"""View-parallel training step: one process per GPU, one training view per rank, Gaussian
+parameters replicated, gradients summed with ONE all-reduce per step (RCCL over xGMI on MI355X;
+``gloo`` on CPU for the tests).
+
+The reference has no distributed layer at all -- it renders exactly one view per iteration
+(train.py:275-292).  The semantics implemented here: the all-reduced
+gradient equals the SUM of the single-view gradients that the reference would accumulate by
+running those views sequentially without an optimizer step in between.  Densification statistics
+are per-view non-linear (scene/gaussian_model.py:600-604), so their norms are computed locally
+and only then reduced.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world_size, local_rank).  A single process needs no initialisation."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def views_for_rank(step, rank, world_size, n_views):
+    """Rank r renders view (world_size * step + r) mod n_views."""
+    return (world_size * step + rank) % n_views
+
+
+class GradBucket:
+    """A persistent flat fp32 buffer that the per-tensor gradients are packed into so that the step
+    issues a single large all-reduce (xGMI is point-to-point; one 200+ MB collective keeps all seven
+    links busy, many small ones are latency-bound)."""
+
+    def __init__(self, tensors):
+        self.shapes = [t.shape for t in tensors]
+        self.numels = [t.numel() for t in tensors]
+        total = sum(self.numels)
+        ref = tensors[0]
+        self.flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
+
+    def pack(self, grads):
+        off = 0
+        for g, n in zip(grads, self.numels):
+            if g is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(g.reshape(-1))
+            off += n
+        return self.flat
+
+    def unpack(self):
+        out, off = [], 0
+        for shp, n in zip(self.shapes, self.numels):
+            out.append(self.flat[off:off + n].view(shp))
+            off += n
+        return out
+
+
+def allreduce_gradients(params, bucket=None, group=None, average=False):
+    """Sum (or average) ``p.grad`` of every tensor in ``params`` over all ranks, in place.
+    Returns the bucket so that callers can reuse it across steps."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bucket
+    if bucket is None:
+        bucket = GradBucket(params)
+    flat = bucket.pack([p.grad for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat.div_(dist.get_world_size(group))
+    for p, g in zip(params, bucket.unpack()):
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+    return bucket
+
+
+def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None):
+    """Per-view statistics consumed by GaussianModel.add_densification_stats
+    (scene/gaussian_model.py:600-604; train.py:400-410), reduced over the views of this step:
+    returns (sum of ||grad[:, :2]||, sum of ||grad_abs[:, :2]||, visible count, max radii)."""
+    vis = radii > 0
+    gn = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
+    gna = torch.norm(viewspace_grad_abs[:, :2], dim=-1, keepdim=True) * vis[:, None]
+    cnt = vis.to(torch.float32)[:, None]
+    rmax = radii.clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        packed = torch.cat([gn, gna, cnt], dim=1).contiguous()
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        gn, gna, cnt = packed[:, 0:1], packed[:, 1:2], packed[:, 2:3]
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
+    return gn, gna, cnt, rmax

@@ -1,0 +1,269 @@
+"""Render glue: this repository's counterpart of the reference's ``gaussian_renderer/__init__.py``.
+
+``render()``, ``render_depth()`` and ``render_normal()`` keep the reference's signatures, argument
+meaning and returned dictionary keys (reference gaussian_renderer/__init__.py:143-147, 349-363, 41-43,
+16-26) so that a ``train.py`` / ``render.py`` written against the reference can call them unchanged.
+What they do around the rasterizer:
+
+  (i)   zero ``viewspace_points`` / ``viewspace_points_abs`` sinks whose ``.grad`` receive dL/dmean2D
+        (reference :153-159),
+  (ii)  tan(FoV/2), camera matrices, SH or pre-computed colours, scale+rotation or 3D covariance,
+  (iii) source-frame selection, ``ref_to_src`` = W2C_src @ C2W_ref, source camera centres (:228-267),
+        optional fresh depth-only renders of the sources (:245-253),
+  (iv)  the per-Gaussian plane map ``[n_cam, 1, |d_cam|]`` (:304-316),
+  (v)   depth -> normal by finite differences (:338-342; utils/graphics_utils.py:25-83),
+  (vi)  the appearance affine ``exp(a) * img + b`` (:344-347).
+
+Unlike the reference nothing here hard-codes ``device="cuda"``: tensors follow ``pc.get_xyz.device``
+(one process per GPU in view-parallel mode must not assume device 0).
+"""
+import math
+import random
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+_C0 = 0.28209479177387814
+_C1 = 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+def eval_sh(deg, sh, dirs):
+    """SH -> colour (before the +0.5 / clamp), sh: (..., 3, K), dirs: (..., 3) unit vectors.
+    Same polynomial as the kernels (reference utils/sh_utils.py:57-112, degrees 0..3)."""
+    res = _C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        res = res - _C1 * y * sh[..., 1] + _C1 * z * sh[..., 2] - _C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            res = (res + _C2[0] * xy * sh[..., 4] + _C2[1] * yz * sh[..., 5] + _C2[2] * (2.0 * zz - xx - yy) * sh[..., 6]
+                   + _C2[3] * xz * sh[..., 7] + _C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                res = (res + _C3[0] * y * (3 * xx - yy) * sh[..., 9] + _C3[1] * xy * z * sh[..., 10]
+                       + _C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                       + _C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + _C3[5] * z * (xx - yy) * sh[..., 14]
+                       + _C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return res
+
+
+def normal_from_depth_image(depth, intrinsic, extrinsic=None):
+    """(H,W) depth -> (H,W,3) normals from the cross product of central differences of the
+    back-projected points, border = 0 (reference utils/graphics_utils.py:25-83, offset=None branch)."""
+    H, W = depth.shape
+    dev = depth.device
+    xs = torch.arange(W, dtype=torch.float32, device=dev) / (W - 1)
+    ys = torch.arange(H, dtype=torch.float32, device=dev) / (H - 1)
+    gx, gy = torch.meshgrid(xs, ys, indexing="xy")
+    ndc = torch.stack([gx, gy], dim=-1) * torch.tensor([[W - 1, H - 1]], dtype=torch.float32, device=dev)
+    cam = torch.cat([ndc * depth[..., None], depth[..., None]], dim=-1)
+    xyz = cam @ torch.inverse(intrinsic.to(dev).t())
+    bottom = xyz[2:H, 1:W - 1]; top = xyz[0:H - 2, 1:W - 1]
+    right = xyz[1:H - 1, 2:W]; left = xyz[1:H - 1, 0:W - 2]
+    n = torch.cross(right - left, top - bottom, dim=-1)
+    n = torch.nn.functional.normalize(n, p=2, dim=-1)
+    n = torch.nn.functional.pad(n.permute(2, 0, 1), (1, 1, 1, 1), mode="constant").permute(1, 2, 0)
+    return n
+
+
+def render_normal(viewpoint_cam, depth, offset=None, normal=None, scale=1):
+    intrinsic_matrix, extrinsic_matrix = viewpoint_cam.get_calib_matrix_nerf(scale=scale)
+    st = max(int(scale / 2) - 1, 0)
+    normal_ref = normal_from_depth_image(depth[st::scale, st::scale], intrinsic_matrix.to(depth.device),
+                                         extrinsic_matrix.to(depth.device))
+    return normal_ref.permute(2, 0, 1)
+
+
+def _plane_map(pc, viewpoint_camera, learnt_normal, means3D):
+    """all_map (P,5) = [normal in camera frame, 1, |plane offset in camera frame|]."""
+    V = viewpoint_camera.world_view_transform.to(means3D.device)
+    if learnt_normal:
+        global_normal, offset_global = pc.get_normal(viewpoint_camera)
+    else:
+        global_normal = pc.get_normal_w_smallest_axis(viewpoint_camera)
+    local_normal = global_normal @ V[:3, :3]
+    global_distance = -(global_normal * means3D).sum(-1)
+    if learnt_normal:
+        global_distance = global_distance + offset_global.squeeze()
+    local_distance = (global_distance - torch.sum(local_normal * V[[3], :3], dim=1)).abs()
+    all_map = torch.zeros((means3D.shape[0], 5), device=means3D.device, dtype=torch.float32)
+    all_map[:, :3] = local_normal
+    all_map[:, 3] = 1.0
+    all_map[:, 4] = local_distance
+    return all_map
+
+
+def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            feats = pc.get_features
+            shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.to(feats.device).repeat(feats.shape[0], 1)
+            dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    return scales, rotations, cov3D_precomp, shs, colors_precomp
+
+
+def _sinks(pc):
+    xyz = pc.get_xyz
+    a = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    b = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    try:
+        a.retain_grad(); b.retain_grad()
+    except Exception:
+        pass
+    return a, b
+
+
+def _no_sources(viewpoint_camera, dev):
+    hw = int(viewpoint_camera.image_height) * int(viewpoint_camera.image_width)
+    return (1, torch.zeros((1, 16), device=dev), torch.zeros((1, 3, hw), device=dev),
+            torch.zeros((1, 1, hw), device=dev), torch.zeros((1, 3), device=dev))
+
+
+def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, learnt_normal: bool,
+                 nb_src_frames: int, buffer_length: int, depth_error_threshold: Optional[float] = None,
+                 scaling_modifier=1.0, override_color=None):
+    """Depth-only pass (median ray/plane depth), reference gaussian_renderer/__init__.py:41-140."""
+    dev = pc.get_xyz.device
+    means2D, means2D_abs = _sinks(pc)
+    means3D = pc.get_xyz
+    scales, rotations, cov3D_precomp, shs, colors_precomp = _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color)
+    if depth_error_threshold is None:
+        depth_error_threshold = getattr(args, "depth_error_threshold", 0.01)
+    n, ref_to_src_list, src_images, src_rendered_depths, src_cam_pos = _no_sources(viewpoint_camera, dev)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        ref_to_src_list=ref_to_src_list, src_cam_pos=src_cam_pos, src_images=src_images,
+        src_rendered_depths=src_rendered_depths, nb_src_images=n, buffer_length=buffer_length,
+        depth_error_threshold=float(depth_error_threshold), sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, render_geo=False, render_depth_only=True,
+        debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    input_all_map = _plane_map(pc, viewpoint_camera, learnt_normal, means3D)
+    outs = rasterizer(means3D=means3D, means2D=means2D, means2D_abs=means2D_abs, shs=shs,
+                      colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
+                      all_map=input_all_map, cov3D_precomp=cov3D_precomp)
+    return outs[3]
+
+
+def find_closest_frames(viewpoint_camera, scene, args):
+    """Neighbour search of the test-time path (reference :200-227): sort training views by distance
+    then angle, keep those inside the angle / distance window, optionally move the most similar pose
+    to the front."""
+    dev = scene.camera_centers.device
+    camera_center = viewpoint_camera.camera_center.to(dev)
+    R = torch.as_tensor(viewpoint_camera.R, dtype=torch.float32, device=dev)
+    center_ray = torch.tensor([0.0, 0.0, 1.0], device=dev) @ R.transpose(-1, -2)
+    dist = torch.norm(camera_center.unsqueeze(0) - scene.camera_centers, dim=-1).detach().cpu().numpy()
+    ang = (torch.arccos(torch.sum(center_ray.unsqueeze(0) * scene.center_rays, dim=-1)) * 180 / torch.pi).detach().cpu().numpy()
+    order = np.lexsort((ang, dist))
+    keep = (ang[order] < args.multi_view_max_angle) & (dist[order] > args.multi_view_min_dis) & (dist[order] < args.multi_view_max_dis)
+    order = order[keep]
+    order = order[:min(args.multi_view_num, len(order))].tolist()
+    if getattr(args, "enable_exposure_correction", False) and len(order) > 0:
+        w2c = viewpoint_camera.world_view_transform.T.to(dev)
+        rel = torch.matmul(w2c.unsqueeze(0), torch.inverse(scene.world_view_transforms))
+        diff = torch.mean(torch.abs(rel - torch.eye(4, device=dev).unsqueeze(0)), dim=[1, 2]).detach().cpu().numpy()
+        best = order[int(np.argmin(diff[order]))]
+        order.remove(best)
+        order = [best] + order
+    return np.array(order)
+
+
+def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, learnt_normal: bool,
+           nb_src_frames: int, buffer_length: int, depth_error_threshold: Optional[float] = None,
+           scaling_modifier=1.0, override_color=None, app_model=None, render_geo=True, return_depth_normal=True,
+           do_find_closest_frame=False, do_render_src_depth=False, render_depth_only=False):
+    """Render one view; returns the reference's dictionary (gaussian_renderer/__init__.py:349-363)."""
+    dev = pc.get_xyz.device
+    screenspace_points, screenspace_points_abs = _sinks(pc)
+    if depth_error_threshold is None:
+        depth_error_threshold = getattr(args, "depth_error_threshold", 0.01)
+    depth_error_threshold = float(depth_error_threshold)
+    means3D = pc.get_xyz
+    scales, rotations, cov3D_precomp, shs, colors_precomp = _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color)
+
+    if render_geo:
+        nearest = find_closest_frames(viewpoint_camera, scene, args) if do_find_closest_frame else viewpoint_camera.nearest_id
+        if len(nearest) == 0:
+            nb_src_frames, ref_to_src_list, src_images, src_rendered_depths, src_cam_pos = _no_sources(viewpoint_camera, dev)
+        else:
+            nb_src_frames = min(nb_src_frames, len(nearest))
+            if getattr(args, "shuffle_source_frame", False):
+                chosen = random.sample(list(nearest), nb_src_frames)
+            else:
+                chosen = list(nearest[:nb_src_frames])
+            src_images = scene.original_image_list[chosen]
+            if do_render_src_depth:
+                deps = [render_depth(scene.getTrainCameras()[i], pc, scene, pipe, args, bg_color, learnt_normal, nb_src_frames,
+                                     buffer_length, depth_error_threshold, scaling_modifier, override_color) for i in chosen]
+                src_rendered_depths = torch.stack(deps, dim=0)
+            else:
+                src_rendered_depths = scene.rendered_depth_list[chosen]
+            world_to_src = scene.world_view_transforms[chosen].to(dev)
+            src_to_world = torch.inverse(world_to_src)
+            ref_to_world = viewpoint_camera.world_view_transform.T.to(dev).inverse()
+            ref_to_src_list = world_to_src @ ref_to_world.unsqueeze(0)
+            src_cam_pos = src_to_world[:, :3, 3].contiguous()
+            src_rendered_depths = src_rendered_depths.to(dev)
+            src_images = src_images.to(dev)
+    else:
+        nb_src_frames, ref_to_src_list, src_images, src_rendered_depths, src_cam_pos = _no_sources(viewpoint_camera, dev)
+
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        ref_to_src_list=ref_to_src_list, src_cam_pos=src_cam_pos, src_images=src_images,
+        src_rendered_depths=src_rendered_depths, nb_src_images=nb_src_frames, buffer_length=buffer_length,
+        depth_error_threshold=depth_error_threshold, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, render_geo=render_geo,
+        render_depth_only=render_depth_only, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    input_all_map = _plane_map(pc, viewpoint_camera, learnt_normal, means3D) if (render_geo or render_depth_only) else None
+
+    (rendered_image, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
+     out_min_depth_diff, out_camera_ray, use_first_src_frame_mask) = rasterizer(
+        means3D=means3D, means2D=screenspace_points, means2D_abs=screenspace_points_abs, shs=shs,
+        colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
+        all_map=input_all_map, cov3D_precomp=cov3D_precomp)
+
+    rendered_normal = out_normal_map[0:3] if render_geo else None
+    if return_depth_normal:
+        dn = render_normal(viewpoint_camera, out_median_intersected_depth.squeeze())
+        dn = dn / (torch.norm(dn, dim=0, keepdim=True) + 1e-8)
+    else:
+        dn = None
+    if app_model is not None and getattr(pc, "use_app", False):
+        ab = app_model.appear_ab[torch.tensor(viewpoint_camera.uid, device=dev)]
+        app_image = torch.exp(ab[0]) * rendered_image + ab[1]
+    else:
+        app_image = None
+
+    return {"render": rendered_image, "app_image": app_image,
+            "viewspace_points": screenspace_points, "viewspace_points_abs": screenspace_points_abs,
+            "visibility_filter": radii > 0, "radii": radii, "rendered_normal": rendered_normal,
+            "median_intersected_depth": out_median_intersected_depth, "median_intersected_depth_normal": dn,
+            "cam_feat": out_cam_feat, "warped_image": out_warped_image, "min_depth_diff": out_min_depth_diff,
+            "camera_ray": out_camera_ray, "use_first_src_frame_mask": use_first_src_frame_mask}

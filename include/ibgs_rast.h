@@ -175,6 +175,23 @@ int64_t ibgs_geom_offset(int32_t P, const char* name);
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name);
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name);
 
+/* Optional per-stage timing for bench.py's roofline object: when enabled, ibgs_forward / ibgs_backward
+ * bracket the selected stages with hipEvents on the caller's stream.  ibgs_timing_collect synchronises
+ * those events and returns, per stage, the summed milliseconds and the number of launches since the last
+ * collect.  The only library state besides the last-error string; off by default. */
+#define IBGS_STAGE_PREPROCESS 0
+#define IBGS_STAGE_DEPTH_SORT 1
+#define IBGS_STAGE_SCAN 2
+#define IBGS_STAGE_EMIT 3
+#define IBGS_STAGE_TILE_SORT 4
+#define IBGS_STAGE_RANGES 5
+#define IBGS_STAGE_RENDER_FWD 6
+#define IBGS_STAGE_RENDER_BWD 7
+#define IBGS_STAGE_PREPROCESS_BWD 8
+#define IBGS_NUM_STAGES 9
+void ibgs_timing_enable(uint32_t stage_mask);   /* bit i = time stage i; 0 disables */
+int32_t ibgs_timing_collect(float* ms /* IBGS_NUM_STAGES */, int32_t* launches /* IBGS_NUM_STAGES */);
+
 /* ABI self-check for FFI bindings: sizeof the two argument structs as this library was built. */
 size_t ibgs_sizeof_forward_args(void);
 size_t ibgs_sizeof_backward_args(void);

@@ -173,6 +173,7 @@ int orc_preprocess(int P, int D, int M,
     const float fy = H / (2.0f * tanfovy), fx = W / (2.0f * tanfovx); /* rasterizer_impl.cu:362-363 */
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     int visible = 0;
+#pragma omp parallel for schedule(static) reduction(+ : visible)
     for (int i = 0; i < P; i++) {
         radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
         means2D[2 * i] = means2D[2 * i + 1] = 0.f;
@@ -572,6 +573,9 @@ void orc_render_backward(
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
 
+    /* rows in parallel; the double accumulators are updated atomically (sum order is then
+     * nondeterministic at the 1e-16 level, far below the fp32 results being checked) */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int py = 0; py < H; py++) for (int px = 0; px < W; px++) {
         const size_t pix = (size_t)py * W + px;
         const int tile = (py / TILE) * gx + (px / TILE);
@@ -618,6 +622,7 @@ void orc_render_backward(
                 accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
                 last_color[ch] = c;
                 dL_dalpha += (c - accum_rec[ch]) * g_pix[ch];
+#pragma omp atomic
                 acc_color[3 * id + ch] += (double)(w * g_pix[ch]);
             }
             if (render_geo) {
@@ -678,7 +683,10 @@ void orc_render_backward(
                         }
                     }
                 }
-                for (int ch = 0; ch < 5; ch++) acc_all_map[5 * id + ch] += (double)gm[ch];
+                for (int ch = 0; ch < 5; ch++) {
+#pragma omp atomic
+                    acc_all_map[5 * id + ch] += (double)gm[ch];
+                }
             }
             dL_dalpha *= T;
             last_alpha = alpha;
@@ -689,11 +697,21 @@ void orc_render_backward(
             const float dG_ddelx = -gdx * co[0] - gdy * co[1];
             const float dG_ddely = -gdy * co[2] - gdx * co[1];
             const float mx = dL_dG * dG_ddelx * ddelx_dx, my = dL_dG * dG_ddely * ddely_dy;
-            acc_mean2D[2 * id] += (double)mx; acc_mean2D[2 * id + 1] += (double)my;
-            acc_mean2D_abs[2 * id] += (double)fabsf(mx); acc_mean2D_abs[2 * id + 1] += (double)fabsf(my);
+#pragma omp atomic
+            acc_mean2D[2 * id] += (double)mx;
+#pragma omp atomic
+            acc_mean2D[2 * id + 1] += (double)my;
+#pragma omp atomic
+            acc_mean2D_abs[2 * id] += (double)fabsf(mx);
+#pragma omp atomic
+            acc_mean2D_abs[2 * id + 1] += (double)fabsf(my);
+#pragma omp atomic
             acc_conic[3 * id + 0] += (double)(-0.5f * gdx * dx * dL_dG);
+#pragma omp atomic
             acc_conic[3 * id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
+#pragma omp atomic
             acc_conic[3 * id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
+#pragma omp atomic
             acc_opacity[id] += (double)(G * dL_dalpha);
         }
     }
@@ -718,6 +736,7 @@ void orc_preprocess_backward(
     if (shs) memset(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * P);
     if (scales) { memset(dL_dscale, 0, sizeof(float) * 3 * (size_t)P); memset(dL_drot, 0, sizeof(float) * 4 * (size_t)P); }
 
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
         if (!(radii[i] > 0)) continue;
         const float* mean = means3D + 3 * i;
@@ -842,3 +861,10 @@ void orc_preprocess_backward(
         }
     }
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_num_threads(void) { return 1; }
+#endif
