@@ -196,7 +196,7 @@ class _CModule:
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             sh_c = _dev_f32(sh, device)
-            M = 0 if sh_c is None else int(sh_c.size(1))
+            M = int(sh.size(1)) if sh.dim() == 3 else 0     # keeps (0, M, 3) for P == 0 so autograd accepts the shape
             opts = dict(dtype=torch.float32, device=device)
             dL_dmeans3D = torch.zeros(P, 3, **opts); dL_dmeans2D = torch.zeros(P, 3, **opts)
             dL_dmeans2D_abs = torch.zeros(P, 3, **opts); dL_dcolors = torch.zeros(P, NUM_CHANNELS, **opts)

@@ -94,13 +94,13 @@ def forward(inp, tex_quant=False):
     Returns a dict with the 9 public outputs plus every internal state array.
     """
     L = lib()
-    means3D = _f32(inp["means3D"]); P = means3D.shape[0]
+    means3D = np.ascontiguousarray(np.asarray(inp["means3D"], dtype=np.float32)).reshape(-1, 3); P = means3D.shape[0]
     W, H = int(inp["W"]), int(inp["H"]); HW = W * H
     gx, gy = tile_grid(W, H)
     shs = _f32(inp.get("shs")); colors_precomp = _f32(inp.get("colors_precomp"))
     scales = _f32(inp.get("scales")); rotations = _f32(inp.get("rotations"))
     cov3D_precomp = _f32(inp.get("cov3D_precomp")); all_map = _f32(inp.get("all_map"))
-    opac = _f32(inp["opacities"]).reshape(-1)
+    opac = np.ascontiguousarray(np.asarray(inp["opacities"], dtype=np.float32)).reshape(-1)
     vm = _f32(inp["viewmatrix"]).reshape(-1); pm = _f32(inp["projmatrix"]).reshape(-1)
     campos = _f32(inp["campos"]).reshape(-1); bg = _f32(inp["bg"]).reshape(-1)
     D = int(inp.get("sh_degree", 0)); M = 0 if shs is None else int(shs.shape[1])
@@ -166,7 +166,7 @@ def backward(inp, fwd, dL_dcolor, dL_dnormal=None, dL_ddepth=None, dL_dwarped=No
     """Full backward given ``forward``'s result.  Returns the reference's 10 gradients
     (rasterize_points.cu:209-219, 270) plus dL_dconic."""
     L = lib()
-    means3D = _f32(inp["means3D"]); P = means3D.shape[0]
+    means3D = np.ascontiguousarray(np.asarray(inp["means3D"], dtype=np.float32)).reshape(-1, 3); P = means3D.shape[0]
     W, H = int(inp["W"]), int(inp["H"])
     shs = _f32(inp.get("shs")); colors_precomp = _f32(inp.get("colors_precomp"))
     scales = _f32(inp.get("scales")); rotations = _f32(inp.get("rotations"))
@@ -222,3 +222,12 @@ def backward(inp, fwd, dL_dcolor, dL_dnormal=None, dL_ddepth=None, dL_dwarped=No
                               _p(res["dL_dmeans3D"]), _p(res["dL_dcov3D"]), _p(res["dL_dsh"]),
                               _p(res["dL_dscales"]), _p(res["dL_drotations"]))
     return res
+
+
+def eval_sh(deg, shs, dirs):
+    """shs (N,M,3), dirs (N,3) unit -> (N,3) SH colour before the +0.5 / clamp."""
+    shs = _f32(shs); dirs = _f32(dirs)
+    N, M = shs.shape[0], shs.shape[1]
+    out = np.zeros((N, 3), np.float32)
+    lib().orc_eval_sh(_ci(N), _ci(deg), _ci(M), _p(dirs), _p(shs), _p(out))
+    return out

@@ -868,3 +868,18 @@ int orc_num_threads(void) { return omp_get_max_threads(); }
 #else
 int orc_num_threads(void) { return 1; }
 #endif
+
+/* Test hook: SH colour (before +0.5 / clamp) through the same sh_basis() the preprocess uses. */
+void orc_eval_sh(int N, int D, int M, const float* dirs, const float* shs /* N x M x 3 */, float* out /* N x 3 */)
+{
+    for (int i = 0; i < N; i++) {
+        float B[16];
+        const int nb = sh_basis(D, dirs + 3 * i, B);
+        const float* sh = shs + (size_t)i * M * 3;
+        for (int ch = 0; ch < 3; ch++) {
+            float r = B[0] * sh[ch];
+            for (int k = 1; k < nb; k++) r = r + B[k] * sh[3 * k + ch];
+            out[3 * i + ch] = r;
+        }
+    }
+}

@@ -1,0 +1,63 @@
+"""View-parallel gradient reduction on CPU: 2 processes over gloo (the GPU path uses RCCL through the
+same code).  The all-reduced gradients must equal the sequential accumulation of the per-view gradients."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ibgs_amd import dist as vdist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = vdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    params = [torch.randn(50, 3, generator=g).requires_grad_(True), torch.randn(50, 16, 3, generator=g).requires_grad_(True),
+              torch.randn(50, 1, generator=g).requires_grad_(True)]
+    view = vdist.views_for_rank(step=3, rank=rank, world_size=world, n_views=8)
+    # a stand-in "render loss" that depends on the view so that ranks produce different gradients
+    loss = sum(((p * (view + 1.0 + i)) ** 2).sum() for i, p in enumerate(params))
+    loss.backward()
+    local = [p.grad.clone() for p in params]
+    bucket = vdist.allreduce_gradients(params)
+    bucket = vdist.allreduce_gradients(params, bucket) if False else bucket
+    radii = torch.tensor([0, 3, 5, 0, 2][rank:] + [1] * (45 + rank), dtype=torch.int32)[:50]
+    vg = torch.randn(50, 3, generator=torch.Generator().manual_seed(10 + rank))
+    gn, gna, cnt, rmax = vdist.allreduce_densification_stats(vg, vg.abs(), radii)
+    torch.save({"view": view, "local": local, "reduced": [p.grad.clone() for p in params], "gn": gn, "cnt": cnt, "rmax": rmax,
+                "vg": vg, "radii": radii}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_equals_sequential_accumulation(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "r%d.pt" % r)) for r in range(world)]
+    assert [r["view"] for r in res] == [6, 7]
+    for i in range(3):
+        want = res[0]["local"][i] + res[1]["local"][i]
+        for r in res:
+            np.testing.assert_allclose(r["reduced"][i].numpy(), want.numpy(), rtol=1e-6)
+    gn = sum(torch.norm(r["vg"][:, :2], dim=-1, keepdim=True) * (r["radii"] > 0)[:, None] for r in res)
+    np.testing.assert_allclose(res[0]["gn"].numpy(), gn.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(res[1]["cnt"].numpy(), sum((r["radii"] > 0).float()[:, None] for r in res).numpy())
+    assert torch.equal(res[0]["rmax"], torch.maximum(res[0]["radii"], res[1]["radii"]))
+
+
+def test_single_process_is_a_noop():
+    p = [torch.ones(4, requires_grad=True)]
+    p[0].grad = torch.full((4,), 2.0)
+    assert vdist.allreduce_gradients(p) is None
+    assert torch.all(p[0].grad == 2.0)
+    b = vdist.GradBucket(p)
+    flat = b.pack([p[0].grad])
+    assert flat.numel() == 4 and torch.all(b.unpack()[0] == 2.0)

@@ -1,0 +1,267 @@
+"""HIP path vs oracle on the same seeded inputs (run on the MI355X box: pytest -m gpu).
+
+Everything goes through the product path: GaussianRasterizer -> autograd.Function -> C ABI ->
+libibgs_rast.so.  Bars: integer / index results bit-exact (radii, tiles touched, sorted lists, tile
+ranges, clamp flags, preprocess records); blended floats within the north-star tolerance (mean L1 per
+pixel <= 1e-4, PSNR delta <= 0.05 dB -- asserted far tighter); gradients relative L2 <= 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from ibgs_amd import rasterizer, synthetic as syn
+from tests import hipref
+from tests.metrics import l1, psnr, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+L1_TOL = 1e-4          # north_star: forward renders within 1e-4 L1 per pixel
+GRAD_TOL = 1e-3        # gradient relative L2 <= 1e-3
+
+
+def scene(P=4000, W=208, H=144, deg=3, seed=1, opacity="init", planes=False, scale_mul=1.0):
+    inp = syn.make_scene(P, W, H, sh_degree=deg, seed=seed, opacity=opacity, with_planes=planes)
+    if scale_mul != 1.0:
+        inp["scales"] = (inp["scales"] * scale_mul).astype(np.float32)
+        if planes:
+            inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
+    return inp
+
+
+def add_sources(inp, n_src=3, L=4, seed=5, depth=None):
+    W, H = inp["W"], inp["H"]
+    srcs = [syn.make_camera(W, H, azimuth_deg=a) for a in (7.0, -7.0, 14.0, -14.0, 21.0)[:n_src]]
+    r2s, scp = syn.ref_to_src(inp["_cam"], srcs)
+    rng = np.random.default_rng(seed)
+    if depth is None:   # plausible source depths: the oracle's own depth-only render of each source view
+        deps = []
+        for s in srcs:
+            d = dict(inp); d.update(viewmatrix=s["viewmatrix"], projmatrix=s["projmatrix"], campos=s["campos"],
+                                    render_geo=False, render_depth_only=True, buffer_length=4,
+                                    all_map=syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], s))
+            deps.append(oracle.forward(d)["median_depth"])
+        depth = np.stack(deps)
+    inp = dict(inp)
+    inp.update(render_geo=True, n_src=n_src, buffer_length=L, ref_to_src=r2s, src_cam_pos=scp,
+               src_images=rng.uniform(0, 1, (n_src, 3, H, W)).astype(np.float32), src_depths=depth.astype(np.float32), depth_thr=0.05)
+    return inp
+
+
+def check_stages(ist, o, ref):
+    """Integer / index stages and the preprocess record: exact."""
+    assert np.array_equal(o["radii"], ref["radii"])
+    assert np.array_equal(ist["tiles"], ref["tiles_touched"])
+    assert ist["R"] == ref["num_rendered"]
+    for a, b in ((ist["depths"], ref["depths"]), (ist["rec"][:, 0:2], ref["means2D"]), (ist["rec"][:, 4:7], ref["conic_opacity"][:, :3]),
+                 (ist["rec"][:, 2], ref["conic_opacity"][:, 3]), (ist["cov3D"], ref["cov3D"])):
+        assert np.array_equal(a.view(np.uint32), np.ascontiguousarray(b).view(np.uint32)), "preprocess record not bit-identical"
+    assert np.array_equal(ist["ranges"], ref["ranges"])
+    assert np.array_equal(ist["point_list"], ref["point_list"])
+    assert np.array_equal(ist["sorted_tile_keys"], (ref["keys"] >> 32).astype(np.uint32))
+
+
+def check_color(o, ist, ref, frac_contrib=2e-4):
+    assert l1(o["color"], ref["color"]) <= L1_TOL * 1e-2
+    assert float(np.abs(o["color"] - ref["color"]).max()) < 5e-3
+    bad = (ist["n_contrib"] != ref["n_contrib"]).mean()
+    assert bad <= frac_contrib, "n_contrib differs on %.4f%% of the pixels" % (100 * bad)
+    assert l1(ist["final_T"], ref["final_T"]) < 1e-6
+    tgt = np.random.default_rng(0).uniform(0, 1, ref["color"].shape)
+    assert abs(psnr(o["color"], tgt)[0] - psnr(ref["color"], tgt)[0]) <= 0.05
+
+
+def run(inp, grads=None, debug=True):
+    ref = oracle.forward(inp, tex_quant=rasterizer.TEX_QUANT)
+    outs, leaves, _ = hipref.run_forward(inp, debug=debug)
+    ist = hipref.internal_state(outs, inp)
+    o = hipref.to_np(outs)
+    gb = None
+    if grads is not None:
+        loss = 0
+        for k, g in grads.items():
+            loss = loss + (outs[k] * torch.as_tensor(g, device="cuda")).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        gb = oracle.backward(inp, ref, grads["color"], grads.get("normal_map"), grads.get("median_depth"),
+                             grads.get("warped_image"), tex_quant=rasterizer.TEX_QUANT)
+    return ref, o, ist, leaves, gb
+
+
+GRAD_PAIRS = [("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("means2D_abs", "dL_dmeans2D_abs"), ("shs", "dL_dsh"),
+              ("colors_precomp", "dL_dcolors"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
+              ("rotations", "dL_drotations"), ("cov3D_precomp", "dL_dcov3D"), ("all_map", "dL_dall_map")]
+
+
+def check_grads(leaves, gb, tol=GRAD_TOL, skip=()):
+    for lk, rk in GRAD_PAIRS:
+        if leaves.get(lk) is None or lk in skip:
+            continue
+        g = leaves[lk].grad
+        assert g is not None, lk
+        a = g.cpu().numpy(); b = gb[rk].reshape(a.shape)
+        if np.abs(b).max() == 0:
+            assert np.abs(a).max() == 0, lk
+            continue
+        assert rel_l2(a, b) <= tol, "%s relL2 %.3e" % (lk, rel_l2(a, b))
+
+
+def canon_valid(v):
+    """valid_src_indices is only defined up to its -1 terminator (forward.cu:648-655)."""
+    v = v.copy()
+    dead = np.zeros(v.shape[1], bool)
+    for k in range(v.shape[0]):
+        dead |= v[k] == -1
+        v[k][dead] = -1
+    return v
+
+
+def rnd(shape, seed):
+    return np.random.default_rng(seed).normal(size=shape).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("deg,opacity", [(3, "init"), (0, "trained"), (1, "trained"), (2, "init")])
+def test_colour_path_forward_backward(deg, opacity):
+    inp = scene(deg=deg, opacity=opacity, seed=10 + deg)
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, inp["H"], inp["W"]), 1)})
+    check_stages(ist, o, ref)
+    check_color(o, ist, ref)
+    cb = ref["clamped"][:, 0] | (ref["clamped"][:, 1] << 1) | (ref["clamped"][:, 2] << 2)
+    assert np.array_equal(ist["clamped"], cb.astype(np.uint8))
+    assert np.array_equal(ist["rec"][:, 8:11].view(np.uint32), ref["rgb"].view(np.uint32))
+    check_grads(leaves, gb)
+    for k in ("normal_map", "median_depth", "cam_feat", "warped_image", "min_depth_diff", "camera_ray", "use_first_src_frame_mask"):
+        assert o[k].shape == ref[k].shape and not o[k].any()          # untouched outputs: zeros of the reference's shape
+
+
+def test_c1_config_full_size():
+    """BASELINE.json configs[0]: 10k random-init Gaussians, 400x400 (lists > 256 entries per tile)."""
+    c = syn.CONFIGS["C1"]
+    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"])
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, c["H"], c["W"]), 2)})
+    assert (ref["ranges"][:, 1] - ref["ranges"][:, 0]).max() > 256
+    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
+def test_precomputed_colour_and_covariance_inputs():
+    inp = scene(P=1500, deg=0, seed=4, opacity="trained")
+    f0 = oracle.forward(inp)
+    alt = {k: v for k, v in inp.items() if k not in ("shs", "scales", "rotations")}
+    alt["colors_precomp"] = np.random.default_rng(1).uniform(0, 1, (1500, 3)).astype(np.float32)
+    alt["cov3D_precomp"] = f0["cov3D"] + 0        # every Gaussian past the near cull has one; the others are culled anyway
+    ref, o, ist, leaves, gb = run(alt, {"color": rnd((3, inp["H"], inp["W"]), 3)})
+    assert np.array_equal(o["radii"], ref["radii"]) and np.array_equal(ist["point_list"], ref["point_list"])
+    check_color(o, ist, ref); check_grads(leaves, gb)
+
+
+@pytest.mark.parametrize("W,H", [(250, 130), (16, 16), (33, 17), (640, 48)])
+def test_ragged_image_sizes(W, H):
+    inp = scene(P=1200, W=W, H=H, deg=1, seed=W + H, scale_mul=2.0)
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, H, W), 4)})
+    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
+def test_huge_and_tiny_gaussians_and_depth_ties():
+    inp = scene(P=600, W=160, H=96, deg=0, seed=9)
+    inp["scales"][:5] *= 60.0                       # cover every tile
+    inp["scales"][5:50] *= 0.02                     # sub-pixel: the 0.3 low-pass dominates
+    inp["means3D"][100:140] = inp["means3D"][100]   # 40 coincident Gaussians: equal depth keys, order must stay by index (Q9)
+    inp["scales"][100:140] = inp["scales"][100]; inp["rotations"][100:140] = inp["rotations"][100]
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, 96, 160), 5)})
+    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
+def test_empty_inputs_and_everything_culled():
+    inp = scene(P=50, W=64, H=48, deg=0)
+    empty = dict(inp)
+    for k in ("means3D", "shs", "scales", "rotations", "opacities"):
+        empty[k] = inp[k][:0]
+    outs, leaves, _ = hipref.run_forward(empty)
+    assert outs["color"].shape == (3, 48, 64) and not outs["color"].any() and outs["radii"].numel() == 0
+    outs["color"].sum().backward()
+    assert leaves["means3D"].grad.shape == (0, 3)
+    culled = dict(inp); culled["means3D"] = (inp["means3D"] + np.array([0, 0, 100.0], np.float32)).astype(np.float32)
+    culled["bg"] = np.array([0.3, 0.6, 0.9], np.float32)
+    ref, o, ist, leaves, gb = run(culled, {"color": rnd((3, 48, 64), 6)})
+    assert ref["num_rendered"] == 0 and ist["R"] == 0 and not o["radii"].any()
+    assert np.array_equal(o["color"], ref["color"])
+    assert all((leaves[k].grad is None or not leaves[k].grad.any()) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
+
+
+@pytest.mark.parametrize("L,n_src", [(4, 3), (5, 2), (1, 1), (8, 5)])
+def test_geo_path_forward_backward(L, n_src):
+    inp = add_sources(scene(P=2500, W=176, H=112, deg=2, seed=20 + L, opacity="trained", planes=True, scale_mul=1.5), n_src=n_src, L=L)
+    H, W = inp["H"], inp["W"]
+    grads = {"color": rnd((3, H, W), 7), "normal_map": rnd((3, H, W), 8), "median_depth": rnd((1, H, W), 9),
+             "warped_image": rnd((15, H, W), 10)}
+    ref, o, ist, leaves, gb = run(inp, grads)
+    check_stages(ist, o, ref); check_color(o, ist, ref)
+    assert (ref["valid_src_idx"][0] >= 0).mean() > 0.2, "scene does not exercise the warp path"
+    assert np.array_equal(ist["low_high"][:, 0], ref["cache_low"]) and np.array_equal(ist["low_high"][:, 1], ref["cache_high"])
+    same = np.all(canon_valid(ist["valid_idx"]) == canon_valid(ref["valid_src_idx"]), axis=0)
+    assert same.mean() > 0.999                       # validity is a threshold test on an interpolated depth
+    assert l1(o["normal_map"], ref["normal_map"]) < 1e-6
+    assert l1(ist["sum_w"], ref["cache_sum_w"]) < 1e-6
+    ok = same.reshape(H, W)
+    for k, tol in (("median_depth", 1e-4), ("cam_feat", 1e-5), ("warped_image", 1e-5), ("min_depth_diff", 1e-5), ("camera_ray", 1e-5)):
+        d = np.abs(o[k] - ref[k])[:, ok]
+        scale = np.abs(ref[k][:, ok]).mean() + 1e-9
+        assert d.mean() / scale < tol, "%s: mean rel err %.3e" % (k, d.mean() / scale)
+    assert np.array_equal(o["use_first_src_frame_mask"][0][ok], ref["use_first_src_frame_mask"][0][ok])
+    check_grads(leaves, gb, tol=5e-3)               # the median/warp terms divide by small buffer weights
+
+
+def test_geo_path_texture_weight_quantisation_switch():
+    inp = add_sources(scene(P=1500, W=128, H=96, deg=0, seed=31, planes=True, scale_mul=1.5), n_src=2, L=4)
+    try:
+        rasterizer.TEX_QUANT = True
+        ref, o, ist, _, _ = run(inp)
+        plain = oracle.forward(inp, tex_quant=False)
+    finally:
+        rasterizer.TEX_QUANT = False
+    assert l1(o["warped_image"], ref["warped_image"]) < 1e-6
+    # the switch does change the samples (by <= 2^-9 * dI each) wherever the set of valid sources is unchanged
+    ok = np.all(canon_valid(ref["valid_src_idx"]) == canon_valid(plain["valid_src_idx"]), axis=0).reshape(inp["H"], inp["W"])
+    assert ok.mean() > 0.99
+    d = np.abs(ref["warped_image"] - plain["warped_image"])[:, ok]
+    assert d.mean() > 1e-6 and d.max() < 4e-3
+
+
+@pytest.mark.parametrize("L", [4, 5, 1, 2])
+def test_depth_only_pass(L):
+    c = syn.CONFIGS["C1"]
+    inp = syn.make_scene(4000, c["W"], c["H"], sh_degree=0, seed=3, with_planes=True)
+    inp["scales"] = (inp["scales"] * 2.5).astype(np.float32)          # > 256 entries per tile: exercises the per-round 'break'
+    inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
+    inp.update(render_depth_only=True, buffer_length=L)
+    ref = oracle.forward(inp)
+    assert (ref["ranges"][:, 1] - ref["ranges"][:, 0]).max() > 256
+    outs, _, _ = hipref.run_forward(inp, debug=True, requires_grad=False)
+    o = hipref.to_np(outs)
+    assert np.array_equal(o["radii"], ref["radii"])
+    d = np.abs(o["median_depth"] - ref["median_depth"])
+    assert d.mean() / (np.abs(ref["median_depth"]).mean() + 1e-9) < 1e-5
+    assert (d > 1e-3 * (1 + np.abs(ref["median_depth"]))).mean() < 1e-3
+    assert not o["color"].any()
+
+
+def test_mark_visible():
+    inp = scene(P=3000, deg=0)
+    st = hipref.settings_from(inp, "cuda")
+    vis = rasterizer.GaussianRasterizer(st).markVisible(torch.as_tensor(inp["means3D"], device="cuda"))
+    assert vis.dtype == torch.bool
+    assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(inp["means3D"], inp["viewmatrix"]))
+
+
+def test_idempotent_forward_and_linear_backward():
+    inp = scene(P=3000, deg=3, seed=77, opacity="trained")
+    g = rnd((3, inp["H"], inp["W"]), 11)
+    res = []
+    for scale in (1.0, 1.0, 2.0):
+        outs, leaves, _ = hipref.run_forward(inp)
+        (outs["color"] * torch.as_tensor(g * scale, device="cuda")).sum().backward()
+        res.append((outs["color"].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items() if v is not None and v.grad is not None}))
+    assert np.array_equal(res[0][0], res[1][0])                                         # forward is deterministic
+    for k in res[0][1]:
+        assert rel_l2(res[1][1][k], res[0][1][k]) < 1e-5                                # float atomics: order noise only
+        assert rel_l2(res[2][1][k], 2.0 * res[0][1][k]) < 1e-5                          # backward is linear in dL/dC
