@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libibgs_rast.so")
 SOURCES = ["api", "preprocess", "scan_sort", "binning", "render_fwd", "render_bwd", "preprocess_bwd"]
-EXTRA = {"preprocess": ["-ffp-contract=off"]}
+EXTRA = {"preprocess": ["-ffp-contract=off"]}  # bit-identical to the oracle (see preprocess.hip)
 ARCH = "gfx950"
 
 

@@ -13,6 +13,7 @@ MAX_SRC = 5
 MAX_BUFFER_LENGTH = 8
 FLAG_DEBUG = 1
 FLAG_TEX_QUANT = 2
+FLAG_NO_TILE_CULL = 4
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 

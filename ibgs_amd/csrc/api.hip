@@ -43,6 +43,7 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.cov3D = c.take<float>(P * 6);
     g.tiles = c.take<uint32_t>(P);
     g.rect = c.take<uint32_t>(P * 2);
+    g.tmask = c.take<uint64_t>(P);
     g.clamped = c.take<uint8_t>(P);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
@@ -155,7 +156,7 @@ size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H) { return (size_t)n
 int64_t ibgs_geom_offset(int32_t P, const char* name)
 {
     size_t t; GeomState g = GeomState::carve(nullptr, (size_t)P, &t);
-    OFF(g, rec); OFF(g, depths); OFF(g, cov3D); OFF(g, tiles); OFF(g, rect); OFF(g, clamped); OFF(g, offsets);
+    OFF(g, rec); OFF(g, depths); OFF(g, cov3D); OFF(g, tiles); OFF(g, rect); OFF(g, tmask); OFF(g, clamped); OFF(g, offsets);
     if (!strcmp(name, "order")) return (int64_t)((char*)g.sort_val[0] - (char*)nullptr);
     if (!strcmp(name, "sorted_depth_keys")) return (int64_t)((char*)g.sort_key[0] - (char*)nullptr);
     return -1;

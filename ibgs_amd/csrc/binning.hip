@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
                                                           const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ offs /* P+1 */,
                                                           const uint32_t* __restrict__ rect,
+                                                          const uint64_t* __restrict__ tmask,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     __shared__ uint32_t win[EM_CHUNK + 2];
@@ -88,10 +89,22 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
                 if (win[mid] <= s) lo = mid; else hi = mid;
             }
             const uint32_t id = order[j_lo + lo];
-            const uint32_t k = s - win[lo];
+            uint32_t k = s - win[lo];
             const uint32_t rx = rect[2 * id], ry = rect[2 * id + 1];
-            const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu;
+            const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
             const uint32_t w = x1 - x0;
+            if (w * (y1 - y0) <= 64u) {
+                // k-th surviving tile = position of the k-th set bit of the cull mask
+                uint64_t m = tmask[id];
+                uint32_t pos = 0;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    const uint64_t low = m & ((1ull << sft) - 1ull);
+                    const uint32_t c = (uint32_t)__popcll(low);
+                    if (k >= c) { k -= c; m >>= sft; pos += (uint32_t)sft; } else { m = low; }
+                }
+                k = pos;
+            }
             const uint32_t ty = y0 + k / w, tx = x0 + k % w;
             keys[s] = ty * (uint32_t)gx + tx;
             vals[s] = id;
@@ -104,7 +117,7 @@ int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, con
     if (R <= 0) return 0;
     const unsigned nblocks = (unsigned)((R + EM_CHUNK - 1) / EM_CHUNK);
     hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(EM_THREADS), 0, s, (uint32_t)P, (uint32_t)R, gx,
-                       g.sort_val[0], g.offsets, g.rect, b.keys[0], b.vals[0]);
+                       g.sort_val[0], g.offsets, g.rect, g.tmask, b.keys[0], b.vals[0]);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

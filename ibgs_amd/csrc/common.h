@@ -38,7 +38,8 @@ struct GeomState {
     float* depths;         // P
     float* cov3D;          // P x 6
     uint32_t* tiles;       // P   tiles touched
-    uint32_t* rect;        // P x 2  (x0 | x1<<16, y0 | y1<<16)
+    uint32_t* rect;        // P x 2  (x0 | x1<<16, y0 | y1<<16), tightened by the tile cull
+    uint64_t* tmask;       // P   surviving tiles inside rect (row-major bit mask, rects of <= 64 tiles)
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered

@@ -30,8 +30,9 @@ struct PreParams {
     float scale_modifier;
     int depth_only;
     int32_t* radii;
-    float* rec; float* depths; float* cov3D; uint32_t* tiles; uint32_t* rect; uint8_t* clamped;
+    float* rec; float* depths; float* cov3D; uint32_t* tiles; uint32_t* rect; uint64_t* tmask; uint8_t* clamped;
     uint32_t* sort_key; uint32_t* sort_val;
+    int cull;
 };
 
 __device__ __forceinline__ float ndc_to_pix(float v, int S)
@@ -40,6 +41,60 @@ __device__ __forceinline__ float ndc_to_pix(float v, int S)
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, max(lo, v)); }
+
+// ---- tile culling ------------------------------------------------------------------------------
+// A Gaussian passes the blend's alpha >= 1/255 test only where q = a dx^2 + 2b dx dy + c dy^2 <=
+// 2 ln(255 o).  Tiles of the reference rectangle whose pixel-centre box lies outside that ellipse
+// (0.1 % + 1e-3 margin, orders of magnitude above the fp32 rounding of `power` in the blend) are
+// never emitted: shorter lists, identical images and gradients.  Same arithmetic as
+// oracle/ibgs_oracle.c:tile_cull (basic IEEE ops only, so the masks agree bit for bit).
+__device__ __forceinline__ float ln_portable(float x)
+{
+    uint32_t u = __float_as_uint(x);
+    const int e = (int)(u >> 23) - 127;
+    u = (u & 0x007FFFFFu) | 0x3F800000u;
+    const float m = __uint_as_float(u);
+    const float s = (m - 1.0f) / (m + 1.0f), z = s * s;
+    const float poly = 1.0f + z * (0.33333334f + z * (0.2f + z * (0.14285715f + z * 0.11111111f)));
+    return (float)e * 0.6931472f + 2.0f * s * poly;
+}
+
+__device__ __forceinline__ float clampf_(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ uint32_t tile_cull(float px, float py, float sxx, float syy, float A, float B, float C, float o,
+                              int& x0, int& y0, int& x1, int& y1, uint64_t& mask)
+{
+    mask = ~0ull;
+    const float x255 = 255.0f * o;
+    if (!(x255 >= 1.0f)) { x1 = x0; y1 = y0; mask = 0; return 0; }
+    const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
+    const float hx = sqrtf(qmax * sxx), hy = sqrtf(qmax * syy);
+    int tx0 = (int)ceilf((px - hx - 15.0f) / 16.0f), tx1 = (int)floorf((px + hx) / 16.0f) + 1;
+    int ty0 = (int)ceilf((py - hy - 15.0f) / 16.0f), ty1 = (int)floorf((py + hy) / 16.0f) + 1;
+    tx0 = max(tx0, x0); tx1 = min(tx1, x1); ty0 = max(ty0, y0); ty1 = min(ty1, y1);
+    if (tx1 <= tx0 || ty1 <= ty0) { x1 = x0; y1 = y0; mask = 0; return 0; }
+    x0 = tx0; x1 = tx1; y0 = ty0; y1 = ty1;
+    const int w = tx1 - tx0, h = ty1 - ty0;
+    if (w * h > 64 || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
+    uint64_t m = 0; uint32_t cnt = 0;
+    for (int ty = ty0; ty < ty1; ty++)
+        for (int tx = tx0; tx < tx1; tx++) {
+            const float X0 = (float)(tx * 16) - px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
+            bool keep;
+            if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) keep = true;
+            else {
+                float qmin, t, q;
+                t = clampf_(-B * X0 / C, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
+                t = clampf_(-B * X1 / C, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = q < qmin ? q : qmin;
+                t = clampf_(-B * Y0 / A, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = q < qmin ? q : qmin;
+                t = clampf_(-B * Y1 / A, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
+                keep = !(qmin > qmax);
+            }
+            if (keep) { m |= 1ull << ((ty - ty0) * w + (tx - tx0)); cnt++; }
+        }
+    mask = m;
+    return cnt;
+}
 
 // One thread per Gaussian. The AoS inputs (12..192 B per Gaussian) are read with plain per-lane
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
@@ -53,6 +108,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
 #pragma unroll
     for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     int radius = 0; uint32_t ntiles = 0; uint32_t rx = 0, ry = 0; float depth = 0.f; uint8_t clampbits = 0;
+    uint64_t tmask = 0;
     float c6loc[6] = {0, 0, 0, 0, 0, 0};
 
     const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
@@ -123,13 +179,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
             const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
             const float pxs = ndc_to_pix(hx * pw, cam.W), pys = ndc_to_pix(hy * pw, cam.H);
             const int rad = (int)my_radius;
-            const int x0 = clampi((int)((pxs - rad) / TILE), 0, cam.gx);
-            const int y0 = clampi((int)((pys - rad) / TILE), 0, cam.gy);
-            const int x1 = clampi((int)((pxs + rad + TILE - 1) / TILE), 0, cam.gx);
-            const int y1 = clampi((int)((pys + rad + TILE - 1) / TILE), 0, cam.gy);
+            int x0 = clampi((int)((pxs - rad) / TILE), 0, cam.gx);
+            int y0 = clampi((int)((pys - rad) / TILE), 0, cam.gy);
+            int x1 = clampi((int)((pxs + rad + TILE - 1) / TILE), 0, cam.gx);
+            int y1 = clampi((int)((pys + rad + TILE - 1) / TILE), 0, cam.gy);
             alive = ((x1 - x0) * (y1 - y0)) != 0;
             if (alive) {
                 radius = rad; ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+                tmask = ~0ull;
+                if (p.cull)
+                    ntiles = tile_cull(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, tmask);
                 rx = pack_rect(x0, x1); ry = pack_rect(y0, y1);
                 depth = zview;
                 rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
@@ -193,6 +252,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
     p.radii[i] = radius;
     p.tiles[i] = ntiles;
     p.rect[2 * i] = rx; p.rect[2 * i + 1] = ry;
+    p.tmask[i] = tmask;
     p.depths[i] = depth;
     p.clamped[i] = clampbits;
     if (!p.cov3D_precomp) {
@@ -205,7 +265,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
     out[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
     out[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
     // depth sort input: positive float bits order like the floats; culled Gaussians sort last
-    p.sort_key[i] = alive ? __float_as_uint(depth) : 0xFFFFFFFFu;
+    // Gaussians without any tile (culled, or fully tile-culled) sort last and emit nothing
+    p.sort_key[i] = (alive && ntiles > 0) ? __float_as_uint(depth) : 0xFFFFFFFFu;
     p.sort_val[i] = (uint32_t)i;
 }
 
@@ -225,7 +286,9 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     p.shs = a.shs; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
     p.scale_modifier = a.scale_modifier; p.depth_only = a.render_depth_only;
     p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.rect = g.rect;
-    p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0];
+    p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0]; p.tmask = g.tmask;
+    // depth-only with a 1-slot buffer depends on list positions (the per-round 'break' of forward.cu:484-488)
+    p.cull = !(a.flags & IBGS_FLAG_NO_TILE_CULL) && !(a.render_depth_only && a.buffer_length == 1);
     const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     const int blocks = (a.P + 255) / 256;
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p, cam);

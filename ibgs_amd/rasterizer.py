@@ -29,6 +29,8 @@ M_SRC = _lib.MAX_SRC
 
 # Tests may flip this to emulate the CUDA texture unit's 8-bit filter weights.
 TEX_QUANT = False
+# Exact tile culling (shorter per-tile lists, identical outputs).  False reproduces the reference's AABB lists.
+TILE_CULL = True
 
 _tex_scratch = {}
 
@@ -150,7 +152,8 @@ class _CModule:
                 a.ref_to_src = _ptr(r2s_c); a.src_cam_pos = _ptr(scp_c); a.src_images = _ptr(simg_c); a.src_depths = _ptr(sdep_c)
                 a.buffer_length = int(buffer_length); a.depth_error_threshold = float(depth_error_threshold)
                 a.prefiltered = int(bool(prefiltered)); a.render_geo = int(render_geo); a.render_depth_only = int(render_depth_only)
-                a.flags = (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL))
                 a.geom = geomBuffer.data_ptr(); a.geom_bytes = geomBuffer.numel()
                 a.img = imgBuffer.data_ptr(); a.img_bytes = imgBuffer.numel()
                 a.binning_alloc = cb; a.binning_user = None

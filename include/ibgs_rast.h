@@ -50,6 +50,8 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
 /* Option flags (ibgs_forward_args.flags / ibgs_backward_args.flags) */
 #define IBGS_FLAG_DEBUG 1u      /* synchronise + check after every stage (auxiliary.h:170-177) */
 #define IBGS_FLAG_TEX_QUANT 2u  /* emulate the CUDA texture unit's 8-bit filter weights */
+#define IBGS_FLAG_NO_TILE_CULL 4u /* emit the reference's full AABB tile lists (rasterizer_impl.cu:205-225) instead of
+                                     dropping tiles that provably fail the alpha >= 1/255 test; outputs are identical */
 
 typedef struct ibgs_forward_args {
     void* stream;

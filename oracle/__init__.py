@@ -81,7 +81,7 @@ def mark_visible(means3D, viewmatrix):
     return out.astype(bool)
 
 
-def forward(inp, tex_quant=False):
+def forward(inp, tex_quant=False, cull=False):
     """Run the full forward.  ``inp`` is a dict of numpy arrays / scalars:
 
     means3D (P,3), opacities (P,) or (P,1), one of {shs (P,M,3) | colors_precomp (P,3)},
@@ -120,6 +120,7 @@ def forward(inp, tex_quant=False):
     st["depths"] = np.zeros(P, np.float32); st["cov3D"] = np.zeros((P, 6), np.float32)
     st["rgb"] = np.zeros((P, 3), np.float32); st["conic_opacity"] = np.zeros((P, 4), np.float32)
     st["tiles_touched"] = np.zeros(P, np.uint32); st["clamped"] = np.zeros((P, 3), np.uint8)
+    st["rect4"] = np.zeros((P, 4), np.int32); st["tmask"] = np.zeros(P, np.uint64)
     out = {
         "color": np.zeros((3, H, W), np.float32), "normal_map": np.zeros((3, H, W), np.float32),
         "median_depth": np.zeros((1, H, W), np.float32), "cam_feat": np.zeros((4 * MAX_SRC, H, W), np.float32),
@@ -138,12 +139,12 @@ def forward(inp, tex_quant=False):
 
     L.orc_preprocess(_ci(P), _ci(D), _ci(M), _p(means3D), _p(scales), _cf(mod), _p(rotations), _p(opac), _p(shs),
                      _p(cov3D_precomp), _p(colors_precomp), _p(vm), _p(pm), _p(campos), _ci(W), _ci(H),
-                     _cf(tanx), _cf(tany), _ci(depth_only),
+                     _cf(tanx), _cf(tany), _ci(depth_only), _ci(bool(cull)),
                      _p(st["radii"]), _p(st["means2D"]), _p(st["depths"]), _p(st["cov3D"]), _p(st["rgb"]),
-                     _p(st["conic_opacity"]), _p(st["tiles_touched"]), _p(st["clamped"]))
+                     _p(st["conic_opacity"]), _p(st["tiles_touched"]), _p(st["clamped"]), _p(st["rect4"]), _p(st["tmask"]))
     R = int(L.orc_bin_count(_ci(P), _p(st["tiles_touched"])))
     st["keys"] = np.zeros(R, np.uint64); st["point_list"] = np.zeros(R, np.uint32)
-    rc = L.orc_bin(_ci(P), ctypes.c_int64(R), _p(st["radii"]), _p(st["means2D"]), _p(st["depths"]), _ci(W), _ci(H),
+    rc = L.orc_bin(_ci(P), ctypes.c_int64(R), _p(st["radii"]), _p(st["rect4"]), _p(st["tmask"]), _p(st["depths"]), _ci(W), _ci(H),
                    _p(st["keys"]), _p(st["point_list"]), _p(st["ranges"]))
     assert rc == 0, "oracle binning failed (%d)" % rc
     feats = colors_precomp if colors_precomp is not None else st["rgb"]

@@ -156,6 +156,66 @@ static int sh_basis(int deg, const float* d, float* B)
     return 16;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * Tile culling (NOT in the reference -- an exactness-preserving optimisation of the HIP path,
+ * restated here so that culled tile lists can be compared bit for bit; cull = 0 gives the
+ * reference's AABB lists).  A Gaussian can only pass the alpha >= 1/255 test of the blend
+ * (forward.cu:424-425) where  q = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 o).  Tiles of the
+ * reference rectangle whose 16x16 pixel-centre box lies entirely outside that ellipse (with a
+ * 0.1 % + 1e-3 safety margin, far above fp32 rounding of `power`) are dropped.  All arithmetic
+ * is +,-,*,/,sqrt in fp32 so that gcc and hipcc (-ffp-contract=off) agree exactly.
+ * ---------------------------------------------------------------------------------------- */
+static float ln_portable(float x)           /* |error| < 2e-6 for x >= 1; basic IEEE ops only */
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    const int e = (int)(u >> 23) - 127;
+    u = (u & 0x007FFFFFu) | 0x3F800000u;
+    float m; memcpy(&m, &u, 4);
+    const float s = (m - 1.0f) / (m + 1.0f), z = s * s;
+    const float poly = 1.0f + z * (0.33333334f + z * (0.2f + z * (0.14285715f + z * 0.11111111f)));
+    return (float)e * 0.6931472f + 2.0f * s * poly;
+}
+
+static inline float clampf_(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* In: pixel centre, cov2D diagonal (with the 0.3), conic, opacity, reference rectangle.
+ * Out: tightened rectangle, bit mask of surviving tiles (row-major inside the tightened rectangle,
+ * only when it has <= 64 tiles; otherwise every tile of it survives). Returns the tile count. */
+static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, float B, float C, float o,
+                          int* x0, int* y0, int* x1, int* y1, uint64_t* mask)
+{
+    *mask = ~0ull;
+    const float x255 = 255.0f * o;
+    if (!(x255 >= 1.0f)) { *x1 = *x0; *y1 = *y0; *mask = 0; return 0; }
+    const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
+    const float hx = sqrtf(qmax * sxx), hy = sqrtf(qmax * syy);
+    int tx0 = (int)ceilf((px - hx - 15.0f) / 16.0f), tx1 = (int)floorf((px + hx) / 16.0f) + 1;
+    int ty0 = (int)ceilf((py - hy - 15.0f) / 16.0f), ty1 = (int)floorf((py + hy) / 16.0f) + 1;
+    tx0 = imax(tx0, *x0); tx1 = imin(tx1, *x1); ty0 = imax(ty0, *y0); ty1 = imin(ty1, *y1);
+    if (tx1 <= tx0 || ty1 <= ty0) { *x1 = *x0; *y1 = *y0; *mask = 0; return 0; }
+    *x0 = tx0; *x1 = tx1; *y0 = ty0; *y1 = ty1;
+    const int w = tx1 - tx0, h = ty1 - ty0;
+    if (w * h > 64 || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
+    uint64_t m = 0; uint32_t cnt = 0;
+    for (int ty = ty0; ty < ty1; ty++) for (int tx = tx0; tx < tx1; tx++) {
+        const float X0 = (float)(tx * 16) - px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
+        int keep;
+        if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) keep = 1;
+        else {
+            float qmin, t, q;
+            t = clampf_(-B * X0 / C, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
+            t = clampf_(-B * X1 / C, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = q < qmin ? q : qmin;
+            t = clampf_(-B * Y0 / A, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = q < qmin ? q : qmin;
+            t = clampf_(-B * Y1 / A, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
+            keep = !(qmin > qmax);
+        }
+        if (keep) { m |= 1ull << ((ty - ty0) * w + (tx - tx0)); cnt++; }
+    }
+    *mask = m;
+    return cnt;
+}
+
 /* ------------------------------------------------------------------------------------------
  * A1  preprocess (forward.cu:193-295, auxiliary.h:143-168). All outputs are zero for culled
  * Gaussians (the reference leaves them uninitialised).
@@ -166,9 +226,10 @@ int orc_preprocess(int P, int D, int M,
                    const float* rotations, const float* opacities, const float* shs,
                    const float* cov3D_precomp, const float* colors_precomp,
                    const float* vm, const float* pm, const float* campos,
-                   int W, int H, float tanfovx, float tanfovy, int render_depth_only,
+                   int W, int H, float tanfovx, float tanfovy, int render_depth_only, int cull,
                    int32_t* radii, float* means2D, float* depths, float* cov3D, float* rgb,
-                   float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped)
+                   float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped,
+                   int32_t* rect4 /* P x 4: x0,y0,x1,y1 */, uint64_t* tmask)
 {
     const float fy = H / (2.0f * tanfovy), fx = W / (2.0f * tanfovx); /* rasterizer_impl.cu:362-363 */
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -176,6 +237,7 @@ int orc_preprocess(int P, int D, int M,
 #pragma omp parallel for schedule(static) reduction(+ : visible)
     for (int i = 0; i < P; i++) {
         radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
+        rect4[4 * i] = rect4[4 * i + 1] = rect4[4 * i + 2] = rect4[4 * i + 3] = 0; tmask[i] = 0;
         means2D[2 * i] = means2D[2 * i + 1] = 0.f;
         for (int k = 0; k < 6; k++) cov3D[6 * i + k] = 0.f;
         for (int k = 0; k < 3; k++) { rgb[3 * i + k] = 0.f; clamped[3 * i + k] = 0; }
@@ -230,7 +292,11 @@ int orc_preprocess(int P, int D, int M,
         conic_opacity[4 * i + 1] = -b * det_inv;
         conic_opacity[4 * i + 2] = a * det_inv;
         conic_opacity[4 * i + 3] = opacities[i];
-        tiles_touched[i] = (uint32_t)((y1 - y0) * (x1 - x0));
+        uint32_t nt = (uint32_t)((y1 - y0) * (x1 - x0));
+        uint64_t mk = ~0ull;
+        if (cull) nt = tile_cull(px, py, a, c, c * det_inv, -b * det_inv, a * det_inv, opacities[i], &x0, &y0, &x1, &y1, &mk);
+        tiles_touched[i] = nt; tmask[i] = mk;
+        rect4[4 * i] = x0; rect4[4 * i + 1] = y0; rect4[4 * i + 2] = x1; rect4[4 * i + 3] = y1;
         visible++;
     }
     return visible;
@@ -256,7 +322,7 @@ int64_t orc_bin_count(int P, const uint32_t* tiles_touched)
     return R;
 }
 
-int orc_bin(int P, int64_t R, const int32_t* radii, const float* means2D, const float* depths,
+int orc_bin(int P, int64_t R, const int32_t* radii, const int32_t* rect4, const uint64_t* tmask, const float* depths,
             int W, int H, uint64_t* keys_sorted, uint32_t* point_list, uint32_t* ranges /* tiles*2 */)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -270,10 +336,11 @@ int orc_bin(int P, int64_t R, const int32_t* radii, const float* means2D, const 
     int64_t off = 0;
     for (int i = 0; i < P; i++) {
         if (radii[i] <= 0) continue;
-        int x0, y0, x1, y1;
-        tile_rect(means2D[2 * i], means2D[2 * i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
+        const int x0 = rect4[4 * i], y0 = rect4[4 * i + 1], x1 = rect4[4 * i + 2], y1 = rect4[4 * i + 3];
+        const int w = x1 - x0, dense = (w * (y1 - y0) > 64);
         uint32_t dbits; memcpy(&dbits, depths + i, 4);
         for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
+            if (!dense && !((tmask[i] >> ((y - y0) * w + (x - x0))) & 1ull)) continue;
             k0[off] = ((uint64_t)(y * gx + x) << 32) | dbits;
             v0[off] = (uint32_t)i;
             off++;

@@ -45,7 +45,10 @@ def main():
         inp.update(render_geo=True, n_src=3, ref_to_src=r2s, src_cam_pos=scp,
                    src_images=rng.uniform(0, 1, (3, 3, H, W)).astype(np.float32),
                    src_depths=np.full((3, 1, H, W), 4.0, np.float32))
-    t = time.time(); ref = oracle.forward(inp); print("oracle fwd %.2fs R=%d" % (time.time() - t, ref["num_rendered"]))
+    cull = "--nocull" not in sys.argv
+    from ibgs_amd import rasterizer
+    rasterizer.TILE_CULL = cull
+    t = time.time(); ref = oracle.forward(inp, cull=cull); print("oracle fwd %.2fs R=%d" % (time.time() - t, ref["num_rendered"]))
     outs, leaves, st = hipref.run_forward(inp, debug=True)
     torch.cuda.synchronize()
     ist = hipref.internal_state(outs, inp)

@@ -19,6 +19,9 @@ def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 5
     fwd_only = "--fwd" in sys.argv
     opacity = "trained" if "--trained" in sys.argv else "init"
+    if "--nocull" in sys.argv:
+        from ibgs_amd import rasterizer
+        rasterizer.TILE_CULL = False
     c = syn.CONFIGS[cfg]
     inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"], opacity=opacity)
     dev = "cuda"

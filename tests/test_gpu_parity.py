@@ -70,9 +70,15 @@ def check_color(o, ist, ref, frac_contrib=2e-4):
     assert abs(psnr(o["color"], tgt)[0] - psnr(ref["color"], tgt)[0]) <= 0.05
 
 
-def run(inp, grads=None, debug=True):
-    ref = oracle.forward(inp, tex_quant=rasterizer.TEX_QUANT)
-    outs, leaves, _ = hipref.run_forward(inp, debug=debug)
+def run(inp, grads=None, debug=True, cull=True):
+    """HIP and oracle with the same tile-list mode (cull=False: the reference's AABB lists)."""
+    ref = oracle.forward(inp, tex_quant=rasterizer.TEX_QUANT, cull=cull)
+    old = rasterizer.TILE_CULL
+    try:
+        rasterizer.TILE_CULL = cull
+        outs, leaves, _ = hipref.run_forward(inp, debug=debug)
+    finally:
+        rasterizer.TILE_CULL = old
     ist = hipref.internal_state(outs, inp)
     o = hipref.to_np(outs)
     gb = None
@@ -134,13 +140,36 @@ def test_colour_path_forward_backward(deg, opacity):
         assert o[k].shape == ref[k].shape and not o[k].any()          # untouched outputs: zeros of the reference's shape
 
 
-def test_c1_config_full_size():
-    """BASELINE.json configs[0]: 10k random-init Gaussians, 400x400 (lists > 256 entries per tile)."""
+@pytest.mark.parametrize("cull", [False, True])
+def test_c1_config_full_size(cull):
+    """BASELINE.json configs[0]: 10k random-init Gaussians, 400x400 (lists > 256 entries per tile).
+    cull=False reproduces the reference's AABB tile lists exactly; cull=True the shorter exact lists."""
     c = syn.CONFIGS["C1"]
     inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"])
-    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, c["H"], c["W"]), 2)})
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, c["H"], c["W"]), 2)}, cull=cull)
     assert (ref["ranges"][:, 1] - ref["ranges"][:, 0]).max() > 256
     check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
+@pytest.mark.parametrize("opacity", ["init", "trained"])
+def test_tile_culling_changes_no_result(opacity):
+    """The culled lists are a strict subset of the reference's lists and every public output and
+    gradient is unchanged: HIP with culling vs the oracle WITHOUT culling (reference lists)."""
+    inp = add_sources(scene(P=3000, W=192, H=128, deg=1, seed=41, opacity=opacity, planes=True, scale_mul=1.3), n_src=2, L=4)
+    H, W = inp["H"], inp["W"]
+    grads = {"color": rnd((3, H, W), 7), "normal_map": rnd((3, H, W), 8), "median_depth": rnd((1, H, W), 9),
+             "warped_image": rnd((15, H, W), 10)}
+    full = oracle.forward(inp, cull=False)
+    gfull = oracle.backward(inp, full, grads["color"], grads["normal_map"], grads["median_depth"], grads["warped_image"])
+    culled = oracle.forward(inp, cull=True)
+    assert culled["num_rendered"] < 0.8 * full["num_rendered"]
+    for k in ("color", "normal_map", "median_depth", "cam_feat", "warped_image", "min_depth_diff", "camera_ray", "use_first_src_frame_mask", "radii"):
+        assert np.array_equal(culled[k], full[k]), k                    # oracle vs oracle: bit-identical
+    ref, o, ist, leaves, _ = run(inp, grads, cull=True)
+    assert ist["R"] == culled["num_rendered"]
+    assert l1(o["color"], full["color"]) < 1e-6 and np.array_equal(o["radii"], full["radii"])
+    assert l1(o["normal_map"], full["normal_map"]) < 1e-6
+    check_grads(leaves, gfull, tol=5e-3)
 
 
 def test_precomputed_colour_and_covariance_inputs():
@@ -234,7 +263,7 @@ def test_depth_only_pass(L):
     inp["scales"] = (inp["scales"] * 2.5).astype(np.float32)          # > 256 entries per tile: exercises the per-round 'break'
     inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
     inp.update(render_depth_only=True, buffer_length=L)
-    ref = oracle.forward(inp)
+    ref = oracle.forward(inp)            # reference (AABB) lists; the HIP path culls (except for L == 1) -- same image
     assert (ref["ranges"][:, 1] - ref["ranges"][:, 0]).max() > 256
     outs, _, _ = hipref.run_forward(inp, debug=True, requires_grad=False)
     o = hipref.to_np(outs)
