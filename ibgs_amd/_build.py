@@ -33,16 +33,18 @@ def _newest_dep():
 
 
 def needs_build():
-    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_dep()
+    if not os.path.exists(LIB):
+        return True
+    newest = _newest_dep()
+    objs = [os.path.join(OBJ, n + ".o") for n in SOURCES]
+    return any((not os.path.exists(o)) or os.path.getmtime(o) < newest for o in objs) or os.path.getmtime(LIB) < newest
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    hdr_time = max(os.path.getmtime(os.path.join(CSRC, "common.h")),
-                   os.path.getmtime(os.path.join(HERE, "..", "include", "ibgs_rast.h")))
+    hdr_time = max([os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")]
+                   + [os.path.getmtime(os.path.join(HERE, "..", "include", "ibgs_rast.h"))])
 
     def compile_one(name):
         src = os.path.join(CSRC, name + ".hip")
@@ -57,10 +59,11 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    if force or (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return LIB
 
 

@@ -18,8 +18,9 @@ constexpr int GACC_FLOATS = 16;  // one 64-byte gradient accumulation row per Ga
 enum RecField { R_X = 0, R_Y = 1, R_OP = 2, R_PAD0 = 3, R_CA = 4, R_CB = 5, R_CC = 6, R_DIST = 7,
                 R_R = 8, R_G = 9, R_B = 10, R_PAD1 = 11, R_NX = 12, R_NY = 13, R_NZ = 14, R_PAD2 = 15 };
 
-// Columns of the gradient accumulation row (render backward -> preprocess backward).
-enum GaccField { G_MX = 0, G_MY = 1, G_AX = 2, G_AY = 3, G_CA = 4, G_CB = 5, G_CC = 6, G_OP = 7,
+// Columns of the gradient accumulation row (render backward -> preprocess backward): pixel sums of
+// moments of q = o*G*dL/dalpha (d = Gaussian centre - pixel, l = conic * d), colour and plane gradients.
+enum GaccField { G_SX = 0, G_SY = 1, G_AX = 2, G_AY = 3, G_SXX = 4, G_SXY = 5, G_SYY = 6, G_S0 = 7,
                  G_R = 8, G_G = 9, G_B = 10, G_NX = 11, G_NY = 12, G_NZ = 13, G_DIST = 14, G_PAD = 15 };
 
 struct Carver {   // 128-byte aligned carve-up of a caller-owned arena (or size computation with base==0)

@@ -23,7 +23,8 @@ struct PreBwdParams {
     const float* means3D; const int32_t* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; float scale_modifier;
     const float* cov3D;        // precomputed input or the forward's computed one
-    const float* gacc;         // P x 16
+    const float* gacc;         // P x 16 moment rows written by render_bwd.hip
+    const float* rec;          // P x 16 forward records (conic, opacity)
     float* dL_dmean2D; float* dL_dmean2D_abs; float* dL_dconic; float* dL_dopacity; float* dL_dcolors;
     float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
@@ -36,14 +37,21 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam
 
     const float4* grow = reinterpret_cast<const float4*>(p.gacc + (size_t)i * GACC_FLOATS);
     const float4 g0 = grow[0], g1 = grow[1], g2 = grow[2], g3 = grow[3];
-    const float g2x = g0.x, g2y = g0.y;            // dL/dmean2D
-    const float gcx = g1.x, gcy = g1.y, gcz = g1.z; // dL/dconic (a, b, c)
+    const float4* rrow = reinterpret_cast<const float4*>(p.rec + (size_t)i * REC_FLOATS);
+    const float4 r0 = rrow[0], r1 = rrow[1];
+    // Moments of q = o*G*dL/dalpha over all pixels (render_bwd.hip) -> the reference's quantities
+    // (backward.cu:786-804): dG/ddelx = -G (a dx + b dy), conic grads -0.5 G d d^T, dL/do = G dL/dalpha.
+    const float ddelx_dx = (float)(0.5 * cam.W), ddely_dy = (float)(0.5 * cam.H);
+    const float ca2 = r1.x, cb2 = r1.y, cc2 = r1.z, opa = r0.z;
+    const float g2x = -ddelx_dx * (ca2 * g0.x + cb2 * g0.y);   // dL/dmean2D
+    const float g2y = -ddely_dy * (cc2 * g0.y + cb2 * g0.x);
+    const float gcx = -0.5f * g1.x, gcy = -0.5f * g1.y, gcz = -0.5f * g1.z; // dL/dconic (a, b, c)
     const float gcol[3] = {g2.x, g2.y, g2.z};
 
     p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y;
-    p.dL_dmean2D_abs[3 * i] = g0.z; p.dL_dmean2D_abs[3 * i + 1] = g0.w;
+    p.dL_dmean2D_abs[3 * i] = ddelx_dx * g0.z; p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * g0.w;
     if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 3] = gcz; }
-    p.dL_dopacity[i] = g1.w;
+    p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
     p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2];
     if (p.dL_dall_map) {
         p.dL_dall_map[5 * i] = g2.w; p.dL_dall_map[5 * i + 1] = g3.x; p.dL_dall_map[5 * i + 2] = g3.y;
@@ -239,7 +247,7 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
     p.means3D = a.means3D; p.radii = a.radii; p.shs = a.shs; p.clamped = g.clamped;
     p.scales = a.scales; p.rotations = a.rotations; p.scale_modifier = a.scale_modifier;
     p.cov3D = a.cov3D_precomp ? a.cov3D_precomp : g.cov3D;
-    p.gacc = a.grad_acc;
+    p.gacc = a.grad_acc; p.rec = g.rec;
     p.dL_dmean2D = a.dL_dmean2D; p.dL_dmean2D_abs = a.dL_dmean2D_abs; p.dL_dconic = a.dL_dconic;
     p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
     p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;

@@ -7,20 +7,26 @@
 // they arrive as contiguous 64-byte requests (MI355X_MICROARCH.md "Global float atomics"), so here:
 //
 //   * one wave owns a 16x16 tile (PPL = 4) or an 8x8 quadrant (PPL = 1, geo variant); a lane first
-//     sums its own pixels' contributions in registers,
-//   * the 64 lanes are reduced with DPP row operations + readlane (no LDS traffic, no LDS atomics),
-//   * the wave then issues ONE atomic instruction per Gaussian whose lanes 0..15 add the 16 floats of
-//     that Gaussian's 64-byte accumulation row (grad_acc[P][16]) -- one 64-byte memory-side request
-//     per (Gaussian, tile) instead of 11-16 scattered dword atomics per (Gaussian, pixel);
-//   * Gaussians that no pixel of the wave uses (ballot == 0, or behind every pixel's last
-//     contributor) cost a handful of VALU instructions and no memory traffic.
+//     sums its own pixels' contributions in registers;
+//   * what is summed per pixel are MOMENTS of q = o*G*dL/dalpha -- sum q, q dx, q dy, q dx^2, q dx dy,
+//     q dy^2, |q lx|, |q ly| -- instead of the reference's eight final quantities; the per-Gaussian
+//     constants (conic, opacity, 0.5*W) are factored out of the pixel sums and applied once per Gaussian
+//     in preprocess_bwd.hip.  Same mathematics (the sums are linear), ~2x fewer VALU ops per pair;
+//   * the 16 per-lane partial sums are reduced over the 64 lanes with a butterfly TRANSPOSE-reduce
+//     (v_permlane32_swap, v_permlane16_swap, DPP row rotates, quad_perm): 38 VALU ops for all 16 values,
+//     after which lane 4j holds the wave total of value j -- no LDS traffic, no LDS atomics;
+//   * the wave then issues ONE atomic instruction per Gaussian: 16 lanes add the 16 floats of that
+//     Gaussian's 64-byte accumulation row (grad_acc[P][16]) -- one 64-byte memory-side request per
+//     (Gaussian, tile) instead of 11-16 scattered dword atomics per (Gaussian, pixel);
+//   * Gaussians that no pixel of the wave uses (ballot == 0, or behind every pixel's last contributor)
+//     cost a few VALU instructions and no memory traffic.
 //
-// preprocess_bwd.hip later converts the accumulation rows into the reference's output layout.
-//
-// Deviation (documented in DESIGN.md): alpha is recomputed with the same fast exp as the forward
-// (the reference uses __expf forward / exp backward), so T/(1-alpha) retraces the
-// forward transmittance exactly.
+// Deviations (documented in DESIGN.md): alpha is recomputed with the same fast exp2 as the forward
+// (the reference uses __expf forward / exp backward) so that T/(1-alpha) retraces the
+// forward transmittance; 1/(1-alpha) is a hardware reciprocal refined by one Newton step instead of an
+// IEEE division.
 #include "common.h"
+#include "wave_reduce.h"
 
 namespace ibgs {
 
@@ -57,22 +63,6 @@ __device__ __forceinline__ float4 tex_rgba_b(const float4* __restrict__ img, int
     return r;
 }
 
-// Sum over the 64 lanes of a wave; result valid in every lane.
-// DPP within rows of 16 (quad_perm / row_half_mirror / row_mirror), then the four row totals are
-// combined through readlane (SGPR broadcast).
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)); // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)); // row_mirror
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
 #pragma unroll
@@ -84,6 +74,12 @@ __device__ __forceinline__ int xcd_band_map_b(int b, int n)
 {
     const int per = (n + 7) >> 3;
     return (b & 7) * per + (b >> 3);
+}
+
+__device__ __forceinline__ float fast_rcp(float x)
+{   // v_rcp_f32 (1 ulp) + one Newton step
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
 }
 
 template <bool GEO, int PPL>
@@ -104,15 +100,14 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
     const size_t HW = (size_t)W * H;
     const float fx = p.cam.fx, fy = p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    const float LOG2E = 1.4426950408889634f;
 
     float pxf[PPL], pyf[PPL];
     size_t pixid[PPL];
-    bool inside[PPL];
-    float T[PPL], T_final[PPL], last_alpha[PPL], last_color[PPL][3], accum_rec[PPL][3], g_pix[PPL][3], bg_dot[PPL];
+    float T[PPL], Tfbg[PPL], last_alpha[PPL], last_cg[PPL], S[PPL], g_pix[PPL][3];
     uint32_t ncontrib[PPL];
     // geo
-    float last_n[PPL][3], accum_n[PPL][3], g_n[PPL][3], g_d[PPL], rayx[PPL], rayy[PPL];
+    float g_n[PPL][3], g_d[PPL], rayx[PPL], rayy[PPL];
     uint32_t min_med[PPL], max_med[PPL];
 
     uint32_t nmax = 0;
@@ -121,28 +116,26 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
         const int qq = quad0 + q;
         const int px = tx0 + (qq & 1) * 8 + (lane & 7), py = ty0 + (qq >> 1) * 8 + (lane >> 3);
         pxf[q] = (float)px; pyf[q] = (float)py;
-        inside[q] = px < W && py < H;
+        const bool inside = px < W && py < H;
         pixid[q] = (size_t)py * W + px;
-        T_final[q] = inside[q] ? p.final_T[pixid[q]] : 0.f;
-        T[q] = T_final[q];
-        ncontrib[q] = inside[q] ? p.n_contrib[pixid[q]] : 0u;
+        const float T_final = inside ? p.final_T[pixid[q]] : 0.f;
+        T[q] = T_final;
+        ncontrib[q] = inside ? p.n_contrib[pixid[q]] : 0u;
         nmax = max(nmax, ncontrib[q]);
-        last_alpha[q] = 0.f; bg_dot[q] = 0.f;
+        last_alpha[q] = 0.f; last_cg[q] = 0.f; S[q] = 0.f;
+        float bg_dot = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            last_color[q][ch] = 0.f; accum_rec[q][ch] = 0.f;
-            g_pix[q][ch] = (inside[q] && p.dL_dcolor) ? p.dL_dcolor[ch * HW + pixid[q]] : 0.f;
-            bg_dot[q] += p.cam.bg[ch] * g_pix[q][ch];
+            g_pix[q][ch] = (inside && p.dL_dcolor) ? p.dL_dcolor[ch * HW + pixid[q]] : 0.f;
+            bg_dot += p.cam.bg[ch] * g_pix[q][ch];
         }
+        Tfbg[q] = -T_final * bg_dot;
         if (GEO) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                last_n[q][ch] = 0.f; accum_n[q][ch] = 0.f;
-                g_n[q][ch] = (inside[q] && p.dL_dnormal) ? p.dL_dnormal[ch * HW + pixid[q]] : 0.f;
-            }
-            g_d[q] = (inside[q] && p.dL_ddepth) ? p.dL_ddepth[pixid[q]] : 0.f;
-            min_med[q] = inside[q] ? p.low_high[2 * pixid[q]] : 0u;
-            max_med[q] = inside[q] ? p.low_high[2 * pixid[q] + 1] : 0u;
+            for (int ch = 0; ch < 3; ch++) g_n[q][ch] = (inside && p.dL_dnormal) ? p.dL_dnormal[ch * HW + pixid[q]] : 0.f;
+            g_d[q] = (inside && p.dL_ddepth) ? p.dL_ddepth[pixid[q]] : 0.f;
+            min_med[q] = inside ? p.low_high[2 * pixid[q]] : 0u;
+            max_med[q] = inside ? p.low_high[2 * pixid[q] + 1] : 0u;
             // dbl: backward.cu:545 evaluates (pix - W*0.5)/fx in double
             rayx[q] = (float)(((double)pxf[q] - W * 0.5) / (double)fx);
             rayy[q] = (float)(((double)pyf[q] - H * 0.5) / (double)fy);
@@ -155,59 +148,58 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
 
     while (top > 0) {
         const int count = min(WAVE, top);
-        {   // stage in processing order: slot l holds entry top-1-l
-            if (lane < count) {
-                const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
-                const float4* r = p.rec + (size_t)id * 4;
-                s_id[lane] = id;
-                s_rec[0][lane] = r[0]; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
-                if (GEO) s_rec[3][lane] = r[3];
-            }
+        if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
+            const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
+            const float4* r = p.rec + (size_t)id * 4;
+            s_id[lane] = id;
+            s_rec[0][lane] = r[0]; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
+            if constexpr (GEO) s_rec[3][lane] = r[3];
         }
         __syncthreads();
         for (int j = 0; j < count; j++) {
             const uint32_t k = (uint32_t)(top - 1 - j);          // 0-based position in the tile list
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
             float4 q3 = q2;
-            if (GEO) q3 = s_rec[3][j];
-            float s_mx = 0.f, s_my = 0.f, s_ax = 0.f, s_ay = 0.f, s_ca = 0.f, s_cb = 0.f, s_cc = 0.f, s_op = 0.f;
-            float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_nx = 0.f, s_ny = 0.f, s_nz = 0.f, s_dist = 0.f;
+            if constexpr (GEO) q3 = s_rec[3][j];
+            const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
+            // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist, 15 unused
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = 0.f;
             bool any = false;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
                 const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];
-                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(0.99f, q0.z * G);
+                const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
+                const float power = -0.5f * (dx * lx + dy * ly);
+                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float oG = op * G;
+                const float alpha = fminf(0.99f, oG);
                 const bool ok = (k < ncontrib[q]) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(ok) != 0ull) {
                     any = true;
                     if (ok) {
-                        T[q] = T[q] / (1.f - alpha);
+                        const float rinv = fast_rcp(1.f - alpha);
+                        T[q] = T[q] * rinv;
                         const float w = alpha * T[q];
-                        float dL_dalpha = 0.0f;
-                        const float col[3] = {q2.x, q2.y, q2.z};
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            accum_rec[q][ch] = last_alpha[q] * last_color[q][ch] + (1.f - last_alpha[q]) * accum_rec[q][ch];
-                            last_color[q][ch] = col[ch];
-                            dL_dalpha += (col[ch] - accum_rec[q][ch]) * g_pix[q][ch];
-                        }
-                        s_r += w * g_pix[q][0]; s_g += w * g_pix[q][1]; s_b += w * g_pix[q][2];
+                        // colour behind this Gaussian, projected on the pixel gradient (scalar form of the
+                        // reference's per-channel accum_rec recurrence, backward.cu:665-669)
+                        const float cg = q2.x * g_pix[q][0] + q2.y * g_pix[q][1] + q2.z * g_pix[q][2];
+                        S[q] = last_alpha[q] * last_cg[q] + (1.f - last_alpha[q]) * S[q];
+                        last_cg[q] = cg;
+                        float dL_dalpha = cg - S[q];
+                        v[8] += w * g_pix[q][0]; v[9] += w * g_pix[q][1]; v[10] += w * g_pix[q][2];
                         if (GEO) {
-                            const float nrm[3] = {q3.x, q3.y, q3.z};
-                            float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f, gm4 = 0.f;
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++) {
-                                accum_n[q][ch] = last_alpha[q] * last_n[q][ch] + (1.f - last_alpha[q]) * accum_n[q][ch];
-                                last_n[q][ch] = nrm[ch];
-                                dL_dalpha += (nrm[ch] - accum_n[q][ch]) * g_n[q][ch];
-                            }
-                            gm0 += w * g_n[q][0]; gm1 += w * g_n[q][1]; gm2 += w * g_n[q][2];
+                            // the normal channels are blended like three more colour channels: fold them into the same scalars
+                            const float ng = q3.x * g_n[q][0] + q3.y * g_n[q][1] + q3.z * g_n[q][2];
+                            // NOTE: S / last_cg carry colour + normal together (both recurrences share last_alpha)
+                            dL_dalpha += ng;      // + (n . g_n); the matching "- accum" part is inside S via last_cg below
+                            last_cg[q] += ng;
+                            float gm0 = w * g_n[q][0], gm1 = w * g_n[q][1], gm2 = w * g_n[q][2], gm4 = 0.f;
                             // unsigned comparison: min_med == 0 disables the branch
                             if ((k >= (uint32_t)((int)min_med[q] - 1)) && (k <= (uint32_t)((int)max_med[q] - 1))) {
                                 const float dist = q1.w;
-                                const float dotn = nrm[0] * rayx[q] + nrm[1] * rayy[q] + nrm[2];
+                                const float dotn = q3.x * rayx[q] + q3.y * rayy[q] + q3.z;
                                 const float tmp = (float)((double)dotn + 1.0e-8);                 // dbl, backward.cu:697
                                 const float tmp2 = dist / (tmp * tmp);
                                 const float dep = (float)(-(double)dist / ((double)dotn + 1.0e-8));  // dbl, backward.cu:699
@@ -223,18 +215,18 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
                                         const float tx = r[0] * X + r[1] * Y + r[2] * Z + r[3];
                                         const float ty = r[4] * X + r[5] * Y + r[6] * Z + r[7];
                                         const float tz = r[8] * X + r[9] * Y + r[10] * Z + r[11];
-                                        const float u = (tx * fx / tz) + cx, v = (ty * fy / tz) + cy;
-                                        if (u >= 0 && u <= W - 1 && v >= 0 && v <= H - 1) {
+                                        const float u = (tx * fx / tz) + cx, vv_ = (ty * fy / tz) + cy;
+                                        if (u >= 0 && u <= W - 1 && vv_ >= 0 && vv_ <= H - 1) {
                                             const float4* img = p.src_rgba + (size_t)si * HW;
-                                            const float4 c4 = tex_rgba_b(img, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
-                                            const float cc[3] = {c4.x, c4.y, c4.z};
+                                            const float4 c4 = tex_rgba_b(img, W, H, u + 0.5f, vv_ + 0.5f, p.tex_quant);
+                                            const float cc3[3] = {c4.x, c4.y, c4.z};
                                             const float sw = p.valid_w[(size_t)m * HW + pixid[q]];
                                             float gc[3];
 #pragma unroll
                                             for (int ch = 0; ch < 3; ch++) {
                                                 const float gw = p.dL_dwarped ? p.dL_dwarped[((size_t)m * 3 + ch) * HW + pixid[q]] : 0.f;
                                                 gc[ch] = gw * w / sw;
-                                                dL_dalpha += gw * (cc[ch] - p.warped_pixels[((size_t)m * 3 + ch) * HW + pixid[q]]) / sw;
+                                                dL_dalpha += gw * (cc3[ch] - p.warped_pixels[((size_t)m * 3 + ch) * HW + pixid[q]]) / sw;
                                             }
                                             const float Av = (pxf[q] - cx) / fx, Bv = (pyf[q] - cy) / fy;
                                             const float U = r[0] * Av + r[1] * Bv + r[2];
@@ -244,9 +236,9 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
                                             const float dpx = fx * (U * r[11] - Wc * r[3]) / (den * den);
                                             const float dpy = fy * (V * r[11] - Wc * r[7]) / (den * den);
                                             // four linear-filtered fetches at integer coordinates
-                                            const float uu = u + 0.5f, vv = v + 0.5f;
-                                            const int u0 = (int)floorf(uu), v0 = (int)floorf(vv);
-                                            const float fu = uu - (float)u0, fv = vv - (float)v0, fu1 = 1.0f - fu, fv1 = 1.0f - fv;
+                                            const float uu = u + 0.5f, vv2 = vv_ + 0.5f;
+                                            const int u0 = (int)floorf(uu), v0 = (int)floorf(vv2);
+                                            const float fu = uu - (float)u0, fv = vv2 - (float)v0, fu1 = 1.0f - fu, fv1 = 1.0f - fv;
                                             const float4 I00 = tex_rgba_b(img, W, H, (float)u0, (float)v0, p.tex_quant);
                                             const float4 I01 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)v0, p.tex_quant);
                                             const float4 I10 = tex_rgba_b(img, W, H, (float)u0, (float)(v0 + 1), p.tex_quant);
@@ -269,41 +261,23 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
                                     }
                                 }
                             }
-                            s_nx += gm0; s_ny += gm1; s_nz += gm2; s_dist += gm4;
+                            v[11] += gm0; v[12] += gm1; v[13] += gm2; v[14] += gm4;
                         }
-                        dL_dalpha *= T[q];
+                        dL_dalpha = dL_dalpha * T[q] + Tfbg[q] * rinv;
                         last_alpha[q] = alpha;
-                        dL_dalpha += (-T_final[q] / (1.f - alpha)) * bg_dot[q];
-                        const float dL_dG = q0.z * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * q1.x - gdy * q1.y;
-                        const float dG_ddely = -gdy * q1.z - gdx * q1.y;
-                        const float mx = dL_dG * dG_ddelx * ddelx_dx, my = dL_dG * dG_ddely * ddely_dy;
-                        s_mx += mx; s_my += my; s_ax += fabsf(mx); s_ay += fabsf(my);
-                        s_ca += -0.5f * gdx * dx * dL_dG;
-                        s_cb += -0.5f * gdx * dy * dL_dG;
-                        s_cc += -0.5f * gdy * dy * dL_dG;
-                        s_op += G * dL_dalpha;
+                        const float qq = oG * dL_dalpha;             // dL/dG * G
+                        const float qdx = qq * dx, qdy = qq * dy;
+                        v[0] += qdx; v[1] += qdy;
+                        v[2] += fabsf(qq * lx); v[3] += fabsf(qq * ly);
+                        v[4] += qdx * dx; v[5] += qdx * dy; v[6] += qdy * dy;
+                        v[7] += qq;
                     }
                 }
             }
-            if (any) {   // wave-uniform
-                const float t_mx = wave_sum(s_mx), t_my = wave_sum(s_my), t_ax = wave_sum(s_ax), t_ay = wave_sum(s_ay);
-                const float t_ca = wave_sum(s_ca), t_cb = wave_sum(s_cb), t_cc = wave_sum(s_cc), t_op = wave_sum(s_op);
-                const float t_r = wave_sum(s_r), t_g = wave_sum(s_g), t_b = wave_sum(s_b);
-                float v = 0.f;
-                v = (lane == G_MX) ? t_mx : v; v = (lane == G_MY) ? t_my : v;
-                v = (lane == G_AX) ? t_ax : v; v = (lane == G_AY) ? t_ay : v;
-                v = (lane == G_CA) ? t_ca : v; v = (lane == G_CB) ? t_cb : v; v = (lane == G_CC) ? t_cc : v;
-                v = (lane == G_OP) ? t_op : v;
-                v = (lane == G_R) ? t_r : v; v = (lane == G_G) ? t_g : v; v = (lane == G_B) ? t_b : v;
-                if (GEO) {
-                    const float t_nx = wave_sum(s_nx), t_ny = wave_sum(s_ny), t_nz = wave_sum(s_nz), t_d = wave_sum(s_dist);
-                    v = (lane == G_NX) ? t_nx : v; v = (lane == G_NY) ? t_ny : v; v = (lane == G_NZ) ? t_nz : v;
-                    v = (lane == G_DIST) ? t_d : v;
-                }
+            if (__ballot(any) != 0ull) {   // wave-uniform
+                const float tot = wave_transpose_reduce16(v, lane);
                 const uint32_t id = s_id[j];
-                if (lane < (GEO ? 15 : 11)) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + lane, v);
+                if ((lane & 3) == 0 && (lane >> 2) < (GEO ? 15 : 11)) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + (lane >> 2), tot);
             }
         }
         __syncthreads();

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 s_rec[0][lane] = r[0];
                 s_rec[1][lane] = r[1];
                 if (!DEPTH) s_rec[2][lane] = r[2];
-                if (GEO) s_rec[3][lane] = r[3];
+                if constexpr (GEO) s_rec[3][lane] = r[3];
                 if (DEPTH) s_rec[2][lane] = r[3];
             }
         }
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             const float4 q1 = s_rec[1][j];      // conic a, b, c, plane distance
             const float4 q2 = s_rec[2][j];      // rgb (colour/geo) or normal (depth-only)
             float4 q3 = q2;
-            if (GEO) q3 = s_rec[3][j];          // normal
+            if constexpr (GEO) q3 = s_rec[3][j];          // normal
             const int e = base + j;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
