@@ -12,7 +12,10 @@
 //     per-lane loads and read back as wave-uniform broadcasts (ds_read_b128), i.e. 3 LDS reads per
 //     Gaussian per 256 pixels.
 //   * Each quadrant is skipped with a wave-uniform branch when no lane has alpha >= 1/255 (ballot),
-//     which recovers 8x8 sub-tile culling without changing any result.
+//     which recovers 8x8 sub-tile culling without changing any result.  "Pixel still blending" is a
+//     64-bit lane mask kept in SGPRs (one per quadrant): masks are combined on the scalar unit and
+//     turned back into predicates with inverse_ballot, so the blend itself is branch-free VALU code and
+//     a finished quadrant costs one scalar compare per Gaussian.
 //   * Early termination is per wave: the tile stops fetching as soon as every pixel is done.
 //   * CUDA layered textures do not exist on gfx950; source images are packed to RGBA float4 once per
 //     call and sampled with explicit bilinear gathers that follow the texture unit's addressing rules
@@ -117,7 +120,8 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 
     int px[PPL], py[PPL];
     float pxf[PPL], pyf[PPL];
-    bool inside[PPL], done[PPL];
+    bool inside[PPL];
+    uint64_t live[PPL];          // wave-uniform lane masks (SGPR pairs): pixels of quadrant q still blending
     float T[PPL], C[PPL][3];
     uint32_t lastc[PPL];
 #pragma unroll
@@ -127,12 +131,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         py[q] = ty0 + (qq >> 1) * 8 + (lane >> 3);
         pxf[q] = (float)px[q]; pyf[q] = (float)py[q];
         inside[q] = px[q] < W && py[q] < H;
-        done[q] = !inside[q];
+        live[q] = __ballot(inside[q]);
         T[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.f; lastc[q] = 0;
     }
     const float fx = p.cam.fx, fy = p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
     const float eps = 1.0e-8f;
+    const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E
 
     // geo / depth-only state (PPL == 1 for GEO; DEPTH keeps running sums only plus the ring)
     float Nacc[PPL][3];
@@ -182,63 +187,68 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             const int e = base + j;
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
+                if (live[q] == 0ull) continue;                        // wave-uniform: quadrant finished
                 const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];
-                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                const float alpha = fminf(0.99f, q0.z * __expf(power));
-                bool live = !done[q];
-                if (DEPTH) live = live && (e >= resume[q]);
-                if (DEPTH && live) cnt[q]++;
-                const bool ok = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(ok) != 0ull) {
-                    const float test_T = T[q] * (1.0f - alpha);
-                    const bool fin = ok && (test_T < 0.0001f);
-                    done[q] = done[q] || fin;
-                    const bool acc = ok && !fin;
-                    const float aT = alpha * T[q];
-                    const uint32_t contributor = DEPTH ? cnt[q] : (uint32_t)(e + 1);
-                    if (!DEPTH) {
-                        const float w = acc ? aT : 0.f;
-                        C[q][0] += q2.x * w; C[q][1] += q2.y * w; C[q][2] += q2.z * w;
-                    }
-                    if (GEO || DEPTH) {
-                        const float dep = -q1.w / (q3.x * rayx[q] + q3.y * rayy[q] + q3.z + eps);
-                        if (GEO) {
-                            const float w = acc ? aT : 0.f;
-                            Nacc[q][0] += q3.x * w; Nacc[q][1] += q3.y * w; Nacc[q][2] += q3.z * w;
-                        }
-                        const bool hit = acc && (dep > 0.0f);
-                        const bool front = T[q] > 0.5f;
-                        int slot = -1;
-                        if (hit && front) slot = before_ptr[q];
-                        else if (hit && below_count[q] < below_cap) slot = before_cap + below_count[q];
-                        if (DEPTH && slot >= 0 && front) {
-                            float oldw = 0.f, oldd = 0.f;
-#pragma unroll
-                            for (int s = 0; s < MAXL; s++) if (s == slot) { oldw = bw[q][s]; oldd = bd[q][s]; }
-                            tot_w[q] -= oldw; wd_sum[q] -= oldw * oldd;
-                        }
-                        if (slot >= 0) {
-#pragma unroll
-                            for (int s = 0; s < MAXL; s++) if (s == slot) { bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
-                            if (front) before_ptr[q] = (before_ptr[q] + 1) % before_cap;
-                            else below_count[q]++;
-                            if (DEPTH) { tot_w[q] += aT; wd_sum[q] += aT * dep; }
-                        }
-                        if (DEPTH && hit && below_count[q] == below_cap) {
-                            // forward.cu:484-488: 'break' leaves the current 256-entry round only
-                            resume[q] = (e / 256 + 1) * 256;
-                        }
-                    }
-                    T[q] = acc ? test_T : T[q];
-                    lastc[q] = acc ? contributor : lastc[q];
+                const float lx = q1.x * dx + q1.y * dy, ly = q1.y * dx + q1.z * dy;
+                const float p2 = dx * lx + dy * ly;                   // = -2 * power
+                const float G = __builtin_amdgcn_exp2f(p2 * NHL2E);
+                const float alpha = fminf(0.99f, q0.z * G);
+                uint64_t m = __ballot(!(p2 < 0.0f) && !(alpha < 1.0f / 255.0f)) & live[q];
+                if (DEPTH) {
+                    const uint64_t running = __ballot(e >= resume[q]) & live[q];
+                    if (__builtin_amdgcn_inverse_ballot_w64(running)) cnt[q]++;
+                    m &= running;
                 }
+                if (m == 0ull) continue;                              // wave-uniform: nobody sees this Gaussian
+                const float aeff = __builtin_amdgcn_inverse_ballot_w64(m) ? alpha : 0.f;
+                float aT = aeff * T[q];
+                float test_T = T[q] * (1.0f - aeff);
+                const uint64_t fin = __ballot(test_T < 0.0001f) & m;
+                if (fin != 0ull) {                                    // rare: some pixels terminate here (not blended, Q7)
+                    const bool pf = __builtin_amdgcn_inverse_ballot_w64(fin);
+                    aT = pf ? 0.f : aT;
+                    test_T = pf ? T[q] : test_T;
+                    live[q] &= ~fin;
+                    m &= ~fin;
+                }
+                const bool acc = __builtin_amdgcn_inverse_ballot_w64(m);
+                const uint32_t contributor = DEPTH ? cnt[q] : (uint32_t)(e + 1);
+                if (!DEPTH) { C[q][0] += q2.x * aT; C[q][1] += q2.y * aT; C[q][2] += q2.z * aT; }
+                if (GEO || DEPTH) {
+                    const float dep = -q1.w / (q3.x * rayx[q] + q3.y * rayy[q] + q3.z + eps);
+                    if (GEO) { Nacc[q][0] += q3.x * aT; Nacc[q][1] += q3.y * aT; Nacc[q][2] += q3.z * aT; }
+                    const bool hit = acc && (dep > 0.0f);
+                    const bool front = T[q] > 0.5f;
+                    int slot = -1;
+                    if (hit && front) slot = before_ptr[q];
+                    else if (hit && below_count[q] < below_cap) slot = before_cap + below_count[q];
+                    if (DEPTH && slot >= 0 && front) {
+                        float oldw = 0.f, oldd = 0.f;
+#pragma unroll
+                        for (int s = 0; s < MAXL; s++) if (s == slot) { oldw = bw[q][s]; oldd = bd[q][s]; }
+                        tot_w[q] -= oldw; wd_sum[q] -= oldw * oldd;
+                    }
+                    if (slot >= 0) {
+#pragma unroll
+                        for (int s = 0; s < MAXL; s++) if (s == slot) { bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
+                        if (front) before_ptr[q] = (before_ptr[q] + 1) % before_cap;
+                        else below_count[q]++;
+                        if (DEPTH) { tot_w[q] += aT; wd_sum[q] += aT * dep; }
+                    }
+                    if (DEPTH && hit && below_count[q] == below_cap) {
+                        // forward.cu:484-488: 'break' leaves the current 256-entry round only
+                        resume[q] = (e / 256 + 1) * 256;
+                    }
+                }
+                T[q] = test_T;
+                lastc[q] = acc ? contributor : lastc[q];
             }
         }
         __syncthreads();
-        bool alldone = true;
+        uint64_t anylive = 0ull;
 #pragma unroll
-        for (int q = 0; q < PPL; q++) alldone = alldone && done[q];
-        if (__ballot(!alldone) == 0ull) break;
+        for (int q = 0; q < PPL; q++) anylive |= live[q];
+        if (anylive == 0ull) break;
     }
 
     // ---------------------------------------------------------------- epilogue
