@@ -171,7 +171,7 @@ def main():
                                    "opacity=%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], a.opacity,
                                                                         ", RCCL all-reduce of Gaussian gradients" if world > 1 else ""),
                        "num_rendered": R, "parallelism": "view-parallel x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "render_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "render_bwd_color_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
                          "step_algorithmic_bytes": b_fwd + b_bwd,

@@ -83,7 +83,7 @@ __device__ __forceinline__ float fast_rcp(float x)
 }
 
 template <bool GEO, int PPL>
-__global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
+__device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 {
     constexpr int NQ = GEO ? 4 : 3;
     __shared__ float4 s_rec[NQ][WAVE];
@@ -285,6 +285,11 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(BwdParams p)
     }
 }
 
+// Two entry points so that each variant gets its own register budget: the colour kernel fits 5 waves per
+// SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
+__global__ void __launch_bounds__(64, 5) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
+__global__ void __launch_bounds__(64) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
+
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
                            const ImgState& im, const float4* src_rgba)
 {
@@ -302,10 +307,10 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     const int nt = p.ntiles;
     if (a.render_geo) {
         const int grid = ((nt * 4 + 7) / 8) * 8;
-        hipLaunchKernelGGL((render_bwd_kernel<true, 1>), dim3(grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(render_bwd_geo_kernel, dim3(grid), dim3(64), 0, s, p);
     } else {
         const int grid = ((nt + 7) / 8) * 8;
-        hipLaunchKernelGGL((render_bwd_kernel<false, 4>), dim3(grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(render_bwd_color_kernel, dim3(grid), dim3(64), 0, s, p);
     }
     IBGS_HIP(hipGetLastError());
     return 0;
