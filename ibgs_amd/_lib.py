@@ -14,6 +14,7 @@ MAX_BUFFER_LENGTH = 8
 FLAG_DEBUG = 1
 FLAG_TEX_QUANT = 2
 FLAG_NO_TILE_CULL = 4
+FLAG_CLEAR_GRAD_ACC = 8
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 

@@ -222,13 +222,33 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
                             }
                         }
                     }
+                    // All coefficient loads are issued back to back (compile-time unrolled, 16-B vector loads
+                    // when rows are 16-B aligned) so that they overlap instead of one dependent wait per term.
+                    float shv[48];
                     const float* sh = p.shs + (size_t)i * p.M * 3;
+                    const int need = 3 * nb;
+                    if (p.M == 16) {
+                        const float4* r4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+                        for (int v = 0; v < 12; v++) {
+                            if (4 * v < need) {
+                                const float4 q = r4[v];
+                                shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 48; k++) if (k < need) shv[k] = sh[k];
+                    }
                     float col[3];
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) col[ch] = B[0] * sh[ch];
-                    for (int k = 1; k < nb; k++) {
+                    for (int ch = 0; ch < 3; ch++) col[ch] = B[0] * shv[ch];
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++) col[ch] = col[ch] + B[k] * sh[3 * k + ch];
+                    for (int k = 1; k < 16; k++) {
+                        if (k < nb) {
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++) col[ch] = col[ch] + B[k] * shv[3 * k + ch];
+                        }
                     }
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {

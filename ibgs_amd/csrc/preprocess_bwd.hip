@@ -23,20 +23,50 @@ struct PreBwdParams {
     const float* means3D; const int32_t* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; float scale_modifier;
     const float* cov3D;        // precomputed input or the forward's computed one
-    const float* gacc;         // P x 16 moment rows written by render_bwd.hip
+    float* gacc;               // P x 16 moment rows written by render_bwd.hip (re-zeroed here when clear_gacc)
+    int clear_gacc;
     const float* rec;          // P x 16 forward records (conic, opacity)
     float* dL_dmean2D; float* dL_dmean2D_abs; float* dL_dconic; float* dL_dopacity; float* dL_dcolors;
     float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
 };
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam cam)
+// FAST16 (M == 16, the layout of max SH degree 3): one wave per workgroup; the 192-B SH rows are read
+// with 16-B vector loads and dL/dsh leaves through an LDS transpose so that the wave stores its contiguous
+// 12 KB block with fully coalesced 16-B writes (a per-lane row store is 48 instructions that each touch 64
+// different cache lines).
+template <bool FAST16>
+__global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBwdParams p, Cam cam)
 {
+    __shared__ float4 s_t[FAST16 ? 64 * 13 : 1];     // row stride 13 quads: conflict-free b128 access
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.P) return;
-    if (!(p.radii[i] > 0)) return;      // outputs arrive zeroed
+    const bool valid = i < p.P;
+    const bool vis = valid && (p.radii[i] > 0);
+    float gv[FAST16 ? 48 : 1];
+    if (FAST16) {
+#pragma unroll
+        for (int k = 0; k < 48; k++) gv[k] = 0.f;
+    }
+    if (valid && !vis) {
+        // invisible Gaussian: every gradient is zero; written explicitly so that callers need no memset
+        p.dL_dmean2D[3 * i] = 0.f; p.dL_dmean2D[3 * i + 1] = 0.f; p.dL_dmean2D[3 * i + 2] = 0.f;
+        p.dL_dmean2D_abs[3 * i] = 0.f; p.dL_dmean2D_abs[3 * i + 1] = 0.f; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
+        if (p.dL_dconic) { p.dL_dconic[4 * i] = 0.f; p.dL_dconic[4 * i + 1] = 0.f; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = 0.f; }
+        p.dL_dopacity[i] = 0.f;
+        p.dL_dcolors[3 * i] = 0.f; p.dL_dcolors[3 * i + 1] = 0.f; p.dL_dcolors[3 * i + 2] = 0.f;
+        if (p.dL_dall_map) for (int k = 0; k < 5; k++) p.dL_dall_map[5 * i + k] = 0.f;
+        p.dL_dmean3D[3 * i] = 0.f; p.dL_dmean3D[3 * i + 1] = 0.f; p.dL_dmean3D[3 * i + 2] = 0.f;
+        for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
+        if (!FAST16 && p.shs) { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
+        if (p.scales) {
+            p.dL_dscale[3 * i] = 0.f; p.dL_dscale[3 * i + 1] = 0.f; p.dL_dscale[3 * i + 2] = 0.f;
+            p.dL_drot[4 * i] = 0.f; p.dL_drot[4 * i + 1] = 0.f; p.dL_drot[4 * i + 2] = 0.f; p.dL_drot[4 * i + 3] = 0.f;
+        }
+    }
+    if (vis) {
 
-    const float4* grow = reinterpret_cast<const float4*>(p.gacc + (size_t)i * GACC_FLOATS);
+    float4* grow = reinterpret_cast<float4*>(p.gacc + (size_t)i * GACC_FLOATS);
     const float4 g0 = grow[0], g1 = grow[1], g2 = grow[2], g3 = grow[3];
+    if (p.clear_gacc) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); grow[0] = z; grow[1] = z; grow[2] = z; grow[3] = z; }
     const float4* rrow = reinterpret_cast<const float4*>(p.rec + (size_t)i * REC_FLOATS);
     const float4 r0 = rrow[0], r1 = rrow[1];
     // Moments of q = o*G*dL/dalpha over all pixels (render_bwd.hip) -> the reference's quantities
@@ -48,14 +78,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam
     const float gcx = -0.5f * g1.x, gcy = -0.5f * g1.y, gcz = -0.5f * g1.z; // dL/dconic (a, b, c)
     const float gcol[3] = {g2.x, g2.y, g2.z};
 
-    p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y;
-    p.dL_dmean2D_abs[3 * i] = ddelx_dx * g0.z; p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * g0.w;
-    if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 3] = gcz; }
+    p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y; p.dL_dmean2D[3 * i + 2] = 0.f;
+    p.dL_dmean2D_abs[3 * i] = ddelx_dx * g0.z; p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * g0.w; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
+    if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }
     p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
     p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2];
     if (p.dL_dall_map) {
         p.dL_dall_map[5 * i] = g2.w; p.dL_dall_map[5 * i + 1] = g3.x; p.dL_dall_map[5 * i + 2] = g3.y;
-        p.dL_dall_map[5 * i + 4] = g3.z;
+        p.dL_dall_map[5 * i + 3] = 0.f; p.dL_dall_map[5 * i + 4] = g3.z;
     }
 
     const float* __restrict__ vm = cam.vm; const float* __restrict__ pm = cam.pm;
@@ -144,8 +174,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam
         const float dorig[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
         const float len = sqrtf(dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2]);
         const float x = dorig[0] / len, y = dorig[1] / len, z = dorig[2] / len;
-        const float* sh = p.shs + (size_t)i * p.M * 3;
+        const float* shg = p.shs + (size_t)i * p.M * 3;
         float* gsh = p.dL_dsh + (size_t)i * p.M * 3;
+        float shv[FAST16 ? 48 : 1];
+        if (FAST16) {
+            const float4* r4 = reinterpret_cast<const float4*>(shg);
+#pragma unroll
+            for (int v = 0; v < 12; v++) { const float4 q = r4[v]; shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w; }
+        }
         const uint8_t cb = p.clamped[i];
         float g[3];
 #pragma unroll
@@ -169,13 +205,21 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam
                 }
             }
         }
-        for (int k = 0; k < nb; k++) {
-            gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2];
+        if (FAST16) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < nb) { gv[3 * k] = B[k] * g[0]; gv[3 * k + 1] = B[k] * g[1]; gv[3 * k + 2] = B[k] * g[2]; }
+            }
+        } else {
+            for (int k = 0; k < nb; k++) {
+                gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2];
+            }
+            for (int k = 3 * nb; k < 3 * p.M; k++) gsh[k] = 0.f;      // coefficients above the active degree
         }
         float gd[3] = {0, 0, 0};
         if (D > 0) {
             float dx3[3], dy3[3], dz3[3];
-#define SHK(k, ch) sh[3 * (k) + (ch)]
+#define SHK(k, ch) (FAST16 ? shv[3 * (k) + (ch)] : shg[3 * (k) + (ch)])
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 dx3[ch] = -bC1 * SHK(3, ch); dy3[ch] = -bC1 * SHK(1, ch); dz3[ch] = bC1 * SHK(2, ch);
@@ -238,6 +282,23 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreBwdParams p, Cam
         p.dL_drot[4 * i + 2] = 2 * x * (G[1][0] + G[0][1]) + 2 * r_ * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
         p.dL_drot[4 * i + 3] = 2 * r_ * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
     }
+    }   // vis
+
+    if (FAST16 && p.shs) {
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < 12; v++) s_t[lane * 13 + v] = make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
+        __syncthreads();
+        const int i0 = blockIdx.x * 64;
+        const int nrows = min(64, p.P - i0);
+        float4* dst = reinterpret_cast<float4*>(p.dL_dsh + (size_t)i0 * 48);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int f = lane + 64 * k;          // quad index inside the block's contiguous 64 x 48 floats
+            const int r = f / 12, c = f - 12 * r;
+            if (r < nrows) dst[f] = s_t[r * 13 + c];
+        }
+    }
 }
 
 int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g)
@@ -247,12 +308,13 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
     p.means3D = a.means3D; p.radii = a.radii; p.shs = a.shs; p.clamped = g.clamped;
     p.scales = a.scales; p.rotations = a.rotations; p.scale_modifier = a.scale_modifier;
     p.cov3D = a.cov3D_precomp ? a.cov3D_precomp : g.cov3D;
-    p.gacc = a.grad_acc; p.rec = g.rec;
+    p.gacc = a.grad_acc; p.rec = g.rec; p.clear_gacc = (a.flags & IBGS_FLAG_CLEAR_GRAD_ACC) ? 1 : 0;
     p.dL_dmean2D = a.dL_dmean2D; p.dL_dmean2D_abs = a.dL_dmean2D_abs; p.dL_dconic = a.dL_dconic;
     p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
     p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;
     const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+    if (a.shs && a.M == 16) hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
+    else hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,7 @@ TEX_QUANT = False
 TILE_CULL = True
 
 _tex_scratch = {}
+_gacc_scratch = {}   # (device index, P) -> [zeroed P x 16 tensor, dirty flag]; ibgs_backward re-zeroes what it consumed
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -62,6 +63,20 @@ def _tex(device, nbytes):
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _tex_scratch[key] = buf
     return buf
+
+
+def _gacc(device, P):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), P)
+    ent = _gacc_scratch.get(key)
+    if ent is None:
+        if len(_gacc_scratch) > 8:
+            _gacc_scratch.clear()
+        ent = [torch.zeros(P, 16, dtype=torch.float32, device=device), False]
+        _gacc_scratch[key] = ent
+    elif ent[1]:            # a previous backward died between accumulation and clean-up
+        ent[0].zero_()
+    ent[1] = True
+    return ent
 
 
 def _zero_plane(c, H, W, device, dtype=torch.float32):
@@ -100,9 +115,13 @@ class _CModule:
             r2s_c = _dev_f32(ref_to_src_list, device); scp_c = _dev_f32(src_cam_pos, device)
             simg_c = _dev_f32(src_images, device); sdep_c = _dev_f32(src_rendered_depths, device)
 
-            radii = torch.zeros(P, dtype=torch.int32, device=device)
+            # radii and the colour planes are written for every Gaussian / pixel by the kernels: no memset needed
+            radii = torch.empty(P, dtype=torch.int32, device=device)
             write_color = not render_depth_only
-            out_color = torch.zeros(NUM_CHANNELS, H, W, device=device) if write_color else _zero_plane(NUM_CHANNELS, H, W, device)
+            if write_color:
+                out_color = (torch.empty if P != 0 else torch.zeros)(NUM_CHANNELS, H, W, dtype=torch.float32, device=device)
+            else:
+                out_color = _zero_plane(NUM_CHANNELS, H, W, device)
             if render_geo:
                 out_normal = torch.zeros(NUM_NORMAL_CHANNELS, H, W, device=device)
                 out_depth = torch.zeros(1, H, W, device=device)
@@ -113,7 +132,10 @@ class _CModule:
                 out_mask = torch.zeros(1, H, W, dtype=torch.int32, device=device)
             else:
                 out_normal = _zero_plane(NUM_NORMAL_CHANNELS, H, W, device)
-                out_depth = torch.zeros(1, H, W, device=device) if render_depth_only else _zero_plane(1, H, W, device)
+                if render_depth_only:
+                    out_depth = (torch.empty if P != 0 else torch.zeros)(1, H, W, dtype=torch.float32, device=device)
+                else:
+                    out_depth = _zero_plane(1, H, W, device)
                 out_cam_feat = _zero_plane(4 * M_SRC, H, W, device)
                 out_warped = _zero_plane(3 * M_SRC, H, W, device)
                 out_min_depth_diff = _zero_plane(1, H, W, device)
@@ -201,12 +223,16 @@ class _CModule:
             sh_c = _dev_f32(sh, device)
             M = int(sh.size(1)) if sh.dim() == 3 else 0     # keeps (0, M, 3) for P == 0 so autograd accepts the shape
             opts = dict(dtype=torch.float32, device=device)
-            dL_dmeans3D = torch.zeros(P, 3, **opts); dL_dmeans2D = torch.zeros(P, 3, **opts)
-            dL_dmeans2D_abs = torch.zeros(P, 3, **opts); dL_dcolors = torch.zeros(P, NUM_CHANNELS, **opts)
-            dL_dall_map = torch.zeros(P, NUM_PLANE_PARAMS, **opts)
-            dL_dopacity = torch.zeros(P, 1, **opts); dL_dcov3D = torch.zeros(P, 6, **opts)
-            dL_dsh = torch.zeros(P, M, 3, **opts); dL_dscales = torch.zeros(P, 3, **opts)
-            dL_drotations = torch.zeros(P, 4, **opts)
+            # ibgs_backward overwrites every element of its outputs (zeros for invisible Gaussians): no memsets
+            have_sr = scales is not None and scales.numel() != 0
+            new = torch.empty if P != 0 else torch.zeros
+            dL_dmeans3D = new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
+            dL_dmeans2D_abs = new(P, 3, **opts); dL_dcolors = new(P, NUM_CHANNELS, **opts)
+            dL_dall_map = (new if (render_geo and all_maps.numel() != 0) else torch.zeros)(P, NUM_PLANE_PARAMS, **opts)
+            dL_dopacity = new(P, 1, **opts); dL_dcov3D = new(P, 6, **opts)
+            dL_dsh = new(P, M, 3, **opts)
+            dL_dscales = (new if have_sr else torch.zeros)(P, 3, **opts)
+            dL_drotations = (new if have_sr else torch.zeros)(P, 4, **opts)
             if P != 0:
                 means3D_c = _dev_f32(means3D, device); colors_c = _dev_f32(colors, device)
                 scales_c = _dev_f32(scales, device); rot_c = _dev_f32(rotations, device)
@@ -221,7 +247,8 @@ class _CModule:
                 g_warp = _dev_f32(dL_dout_warped_image, device) if render_geo else None
                 depth_c = _dev_f32(intersected_depth_pixels, device) if render_geo else None
                 warped_c = _dev_f32(warped_image_pixels, device) if render_geo else None
-                grad_acc = torch.zeros(P, 16, **opts)
+                gacc_ent = _gacc(device, P)
+                grad_acc = gacc_ent[0]
                 radii_c = radii.contiguous()
                 a = _lib.BackwardArgs()
                 a.stream = stream
@@ -251,10 +278,12 @@ class _CModule:
                 a.dL_dscale = dL_dscales.data_ptr(); a.dL_drot = dL_drotations.data_ptr()
                 a.dL_dall_map = dL_dall_map.data_ptr()
                 a.render_geo = int(render_geo)
-                a.flags = (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                           | _lib.FLAG_CLEAR_GRAD_ACC)
                 rc = lib.ibgs_backward(ctypes.byref(a))
                 if rc < 0:
                     raise RuntimeError("ibgs_backward failed (%d): %s" % (rc, _lib.last_error()))
+                gacc_ent[1] = False
         return (dL_dmeans2D, dL_dmeans2D_abs, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                 dL_dscales, dL_drotations, dL_dall_map)
 

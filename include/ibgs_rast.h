@@ -20,7 +20,9 @@
  *   - scratch arenas (geom / binning / img) are owned by the caller and must stay alive and
  *     unmodified between a forward and its backward (the reference keeps them in the autograd
  *     ctx, DPR/diff_plane_rasterization/__init__.py:133-140); the library keeps no state;
- *   - gradient outputs of ibgs_backward must arrive ZEROED (rasterize_points.cu:209-219);
+ *   - ibgs_backward overwrites EVERY element of every gradient output it is given (zeros for Gaussians
+ *     with radius 0), so they need not be cleared first (the reference zero-fills them,
+ *     rasterize_points.cu:209-219); only the grad_acc scratch must arrive zeroed;
  *   - return value: >= 0 on success (ibgs_forward: the number of rendered (Gaussian, tile)
  *     instances R), < 0 = -(IBGS_ERR_*). ibgs_last_error() returns a static message.
  */
@@ -50,6 +52,8 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
 /* Option flags (ibgs_forward_args.flags / ibgs_backward_args.flags) */
 #define IBGS_FLAG_DEBUG 1u      /* synchronise + check after every stage (auxiliary.h:170-177) */
 #define IBGS_FLAG_TEX_QUANT 2u  /* emulate the CUDA texture unit's 8-bit filter weights */
+#define IBGS_FLAG_CLEAR_GRAD_ACC 8u /* ibgs_backward re-zeroes every grad_acc row it consumed, so a caller may keep ONE
+                                      zeroed scratch alive across steps instead of clearing P x 64 B per call */
 #define IBGS_FLAG_NO_TILE_CULL 4u /* emit the reference's full AABB tile lists (rasterizer_impl.cu:205-225) instead of
                                      dropping tiles that provably fail the alpha >= 1/255 test; outputs are identical */
 
@@ -145,7 +149,7 @@ typedef struct ibgs_backward_args {
     const float* dL_dwarped;  /* 15 x H x W */
     /* scratch: P x 16 floats, ZEROED by the caller (per-Gaussian accumulation rows) */
     float* grad_acc;
-    /* gradient outputs, zeroed by the caller */
+    /* gradient outputs: fully overwritten (dL_dscale / dL_drot only when scales is given, dL_dsh only when shs is) */
     float* dL_dmean2D;     /* P x 3 */
     float* dL_dmean2D_abs; /* P x 3 */
     float* dL_dconic;      /* P x 4 (x,y,w used) */
