@@ -175,10 +175,11 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                 const float G = __builtin_amdgcn_exp2f(power * LOG2E);
                 const float oG = op * G;
                 const float alpha = fminf(0.99f, oG);
-                const bool ok = (k < ncontrib[q]) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                if (__ballot(ok) != 0ull) {
+                const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                                     __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+                if (okm != 0ull) {
                     any = true;
-                    if (ok) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(okm)) {
                         const float rinv = fast_rcp(1.f - alpha);
                         T[q] = T[q] * rinv;
                         const float w = alpha * T[q];
@@ -274,7 +275,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                     }
                 }
             }
-            if (__ballot(any) != 0ull) {   // wave-uniform
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
                 const float tot = wave_transpose_reduce16(v, lane);
                 const uint32_t id = s_id[j];
                 if ((lane & 3) == 0 && (lane >> 2) < (GEO ? 15 : 11)) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + (lane >> 2), tot);

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         py[q] = ty0 + (qq >> 1) * 8 + (lane >> 3);
         pxf[q] = (float)px[q]; pyf[q] = (float)py[q];
         inside[q] = px[q] < W && py[q] < H;
-        live[q] = __ballot(inside[q]);
+        live[q] = __builtin_amdgcn_ballot_w64(inside[q]);
         T[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.f; lastc[q] = 0;
     }
     const float fx = p.cam.fx, fy = p.cam.fy;
@@ -193,9 +193,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 const float p2 = dx * lx + dy * ly;                   // = -2 * power
                 const float G = __builtin_amdgcn_exp2f(p2 * NHL2E);
                 const float alpha = fminf(0.99f, q0.z * G);
-                uint64_t m = __ballot(!(p2 < 0.0f) && !(alpha < 1.0f / 255.0f)) & live[q];
+                // one ballot per compare: a ballot of an AND of compares is lowered through a VGPR 0/1 round trip
+                uint64_t m = __builtin_amdgcn_ballot_w64(!(p2 < 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & live[q];
                 if (DEPTH) {
-                    const uint64_t running = __ballot(e >= resume[q]) & live[q];
+                    const uint64_t running = __builtin_amdgcn_ballot_w64(e >= resume[q]) & live[q];
                     if (__builtin_amdgcn_inverse_ballot_w64(running)) cnt[q]++;
                     m &= running;
                 }
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 const float aeff = __builtin_amdgcn_inverse_ballot_w64(m) ? alpha : 0.f;
                 float aT = aeff * T[q];
                 float test_T = T[q] * (1.0f - aeff);
-                const uint64_t fin = __ballot(test_T < 0.0001f) & m;
+                const uint64_t fin = __builtin_amdgcn_ballot_w64(test_T < 0.0001f) & m;
                 if (fin != 0ull) {                                    // rare: some pixels terminate here (not blended, Q7)
                     const bool pf = __builtin_amdgcn_inverse_ballot_w64(fin);
                     aT = pf ? 0.f : aT;
