@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=list(syn.CONFIGS))
     ap.add_argument("--opacity", default="init", choices=["init", "trained"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--geo", action="store_true", help="second line of SURVEY 8(d): render_geo=True, n_src=4, L=4")
     a = ap.parse_args()
 
     rank, world, local_rank = vdist.init_from_env()
@@ -101,8 +102,29 @@ def main():
     _lib.load()
 
     inp, leaves, st, c = build_inputs(a.config, rank % 8, dev, a.opacity)
-    rast = GaussianRasterizer(st)
     H, W, P = c["H"], c["W"], c["P"]
+    if a.geo:
+        # sources = the 4 nearest other orbit views; their images / depth maps are this op's own renders (untimed)
+        tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
+        ref_cam = inp["_cam"]
+        src_ids = [(rank + d) % 8 for d in (1, 7, 2, 6)]
+        src_cams = [syn.make_camera(W, H, azimuth_deg=45.0 * k) for k in src_ids]
+        imgs, deps = [], []
+        with torch.no_grad():
+            for sc in src_cams:
+                am = tt(syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], sc))
+                for depth_only in (False, True):
+                    sst = st._replace(viewmatrix=tt(sc["viewmatrix"]), projmatrix=tt(sc["projmatrix"]), campos=tt(sc["campos"]),
+                                      render_depth_only=depth_only)
+                    o = GaussianRasterizer(sst)(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
+                                                opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"],
+                                                rotations=leaves["rotations"], all_map=am)
+                    (deps if depth_only else imgs).append(o[3].clone() if depth_only else o[0].clone())
+        r2s, scp = syn.ref_to_src(ref_cam, src_cams)
+        leaves["all_map"] = tt(syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], ref_cam)).requires_grad_(True)
+        st = st._replace(ref_to_src_list=tt(r2s), src_cam_pos=tt(scp), src_images=torch.stack(imgs), src_rendered_depths=torch.stack(deps),
+                         nb_src_images=4, buffer_length=4, depth_error_threshold=0.01, render_geo=True)
+    rast = GaussianRasterizer(st)
     target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     params = [leaves[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
     bucket = vdist.GradBucket(params) if world > 1 else None
@@ -112,8 +134,11 @@ def main():
         for v in leaves.values():
             v.grad = None
         outs = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
-                    opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+                    opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
+                    all_map=leaves.get("all_map"))
         loss = (outs[0] - target).abs().mean()
+        if a.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
+            loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
         R_seen[0] = outs[0].grad_fn.num_rendered
         loss.backward()
         if world > 1:
@@ -168,10 +193,10 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer fwd+bwd, L1 loss vs fixed random target, "
-                                   "opacity=%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], a.opacity,
+                                   "opacity=%s%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], a.opacity, ", render_geo n_src=4 L=4" if a.geo else "",
                                                                         ", RCCL all-reduce of Gaussian gradients" if world > 1 else ""),
                        "num_rendered": R, "parallelism": "view-parallel x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "render_bwd_color_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "render_bwd_geo_kernel" if a.geo else "render_bwd_color_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
                          "step_algorithmic_bytes": b_fwd + b_bwd,

@@ -12,6 +12,8 @@ import torch
 
 from . import synthetic as syn
 
+__all__ = ['SimpleNamespace']
+
 
 class SimpleCamera:
     def __init__(self, cam, uid=0, device="cpu"):
