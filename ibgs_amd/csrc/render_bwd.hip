@@ -167,11 +167,21 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = 0.f;
             bool any = false;
+            // same evaluation of p2 = d^T conic d as the forward (render_fwd.hip): once per lane, shifted to the
+            // other three quadrants, so both passes take identical alpha decisions
+            const float dx0 = q0.x - pxf[0], dy0 = q0.y - pyf[0];
+            const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
+            const float P0 = dx0 * lx0 + dy0 * ly0;
+            float p2q[PPL];
+            p2q[0] = P0;
+            if (PPL == 4) {
+                p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
+                p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
+                p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
+            }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];
-                const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
-                const float power = -0.5f * (dx * lx + dy * ly);
+                const float power = -0.5f * p2q[q];
                 const float G = __builtin_amdgcn_exp2f(power * LOG2E);
                 const float oG = op * G;
                 const float alpha = fminf(0.99f, oG);
@@ -180,6 +190,8 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                 if (okm != 0ull) {
                     any = true;
                     if (__builtin_amdgcn_inverse_ballot_w64(okm)) {
+                        const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];          // only the moments need d and conic*d per quadrant
+                        const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
                         const float rinv = fast_rcp(1.f - alpha);
                         T[q] = T[q] * rinv;
                         const float w = alpha * T[q];

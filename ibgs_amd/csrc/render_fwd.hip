@@ -185,12 +185,23 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];          // normal
             const int e = base + j;
+            // p2 = d^T conic d = -2 * power.  With 4 pixels per lane the quadratic form is evaluated once for the
+            // lane's pixel in quadrant 0 and shifted to the other three (pixel offsets (8,0), (0,8), (8,8)):
+            // p2(d - s) = p2(d) - 2 s^T conic d + s^T conic s -- 14 VALU ops for four pixels instead of 32.
+            const float dx0 = q0.x - pxf[0], dy0 = q0.y - pyf[0];
+            const float lx0 = q1.x * dx0 + q1.y * dy0, ly0 = q1.y * dx0 + q1.z * dy0;
+            const float P0 = dx0 * lx0 + dy0 * ly0;
+            float p2q[PPL];
+            p2q[0] = P0;
+            if (PPL == 4) {
+                p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * q1.x);
+                p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
+                p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * q1.y + 64.0f * q1.z));
+            }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
                 if (live[q] == 0ull) continue;                        // wave-uniform: quadrant finished
-                const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];
-                const float lx = q1.x * dx + q1.y * dy, ly = q1.y * dx + q1.z * dy;
-                const float p2 = dx * lx + dy * ly;                   // = -2 * power
+                const float p2 = p2q[q];                              // = -2 * power
                 const float G = __builtin_amdgcn_exp2f(p2 * NHL2E);
                 const float alpha = fminf(0.99f, q0.z * G);
                 // one ballot per compare: a ballot of an AND of compares is lowered through a VGPR 0/1 round trip
