@@ -113,6 +113,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
 int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch,
                        size_t scratch_elems, bool with_total);
 size_t scan_scratch_elems(size_t n);
+void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatter launches per pass
 
 int launch_gather_tiles(hipStream_t s, int P, const GeomState& g);   // tiles in depth order -> offsets input
 int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b);

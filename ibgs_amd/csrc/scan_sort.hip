@@ -10,6 +10,7 @@
 // per-wave LDS counters; scatter is staged through LDS so that global writes are runs of
 // consecutive addresses.
 #include "common.h"
+#include <cstdlib>
 
 namespace ibgs {
 
@@ -236,11 +237,201 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Single-launch-per-pass variant ("onesweep" style): one kernel reads the keys once and builds the global
+// digit histograms of ALL passes; each pass is then ONE kernel in which a workgroup ranks its chunk, publishes
+// its per-digit counts and obtains its exclusive prefix from its predecessors by decoupled look-back
+// (status word = 2 flag bits + 30-bit count, written / polled with agent-scope relaxed atomics = `sc1`
+// stores and loads, MI355X_MICROARCH.md "Valid forms").  Chunks are handed out through an atomic ticket, so a
+// workgroup only ever waits for workgroups that are already running -- no assumption on dispatch order or
+// co-residency.  Replaces hist + 3 scan launches + scatter per pass by one launch per pass.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_INC = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
+constexpr int OS_MAX_PASS = 4;
+
+__global__ void __launch_bounds__(RS_THREADS) onesweep_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npass, int dbits,
+                                                                   uint32_t* __restrict__ ghist /* npass x 256 */)
+{
+    __shared__ uint32_t h[OS_MAX_PASS][RS_MAX_BINS];
+    for (int k = threadIdx.x; k < OS_MAX_PASS * RS_MAX_BINS; k += RS_THREADS) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t mask = (1u << dbits) - 1u;
+    const size_t stride = (size_t)gridDim.x * RS_THREADS;
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = keys[i];
+        for (int p = 0; p < npass; p++) atomicAdd(&h[p][(k >> (p * dbits)) & mask], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < npass * RS_MAX_BINS; k += RS_THREADS) {
+        const uint32_t c = (&h[0][0])[k];
+        if (c) atomicAdd(&ghist[k], c);
+    }
+}
+
+__global__ void __launch_bounds__(RS_THREADS) onesweep_pass_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                   size_t n, int shift, int nbits, int nbins,
+                                                                   const uint32_t* __restrict__ ghist /* 256, this pass */,
+                                                                   uint32_t* __restrict__ status /* nblocks x 256, zeroed */,
+                                                                   uint32_t* __restrict__ ticket, uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t wcnt[4][RS_MAX_BINS];
+    __shared__ uint32_t dstart[RS_MAX_BINS];
+    __shared__ uint32_t delta[RS_MAX_BINS];
+    __shared__ uint32_t lds_wave[4];
+    __shared__ uint32_t skey[RS_CHUNK];
+    __shared__ uint32_t sval[RS_CHUNK];
+    __shared__ uint32_t s_bid;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    for (int k = threadIdx.x; k < 4 * RS_MAX_BINS; k += RS_THREADS) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t bid = s_bid;
+
+    const size_t base = (size_t)bid * RS_CHUNK;
+    const uint32_t mask = (uint32_t)nbins - 1;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
+        const bool valid = idx < n;
+        key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[k] = valid ? vals_in[idx] : 0u;
+        const uint32_t d = (key[k] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit && valid);
+            peers &= bit ? bal : ~bal;
+        }
+        uint32_t r = 0;
+        if (valid) {
+            volatile uint32_t* wc = &wcnt[wave][0];
+            const uint32_t pre = wc[d];
+            r = pre + (uint32_t)__popcll(peers & lt_mask);
+            const int leader = __ffsll((unsigned long long)peers) - 1;
+            if (lane == leader) wc[d] = pre + (uint32_t)__popcll(peers);
+        }
+        rank[k] = r;
+    }
+    __syncthreads();
+
+    uint32_t tot = 0;
+    if (threadIdx.x < nbins) {
+        const uint32_t c0 = wcnt[0][threadIdx.x], c1 = wcnt[1][threadIdx.x], c2 = wcnt[2][threadIdx.x], c3 = wcnt[3][threadIdx.x];
+        wcnt[0][threadIdx.x] = 0; wcnt[1][threadIdx.x] = c0; wcnt[2][threadIdx.x] = c0 + c1; wcnt[3][threadIdx.x] = c0 + c1 + c2;
+        tot = c0 + c1 + c2 + c3;
+        // publish this chunk's count, then walk back over the predecessors
+        uint32_t* mine = status + (size_t)bid * RS_MAX_BINS + threadIdx.x;
+        __hip_atomic_store(mine, (bid == 0 ? OS_FLAG_INC : OS_FLAG_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // exclusive scan over digits of the GLOBAL histogram (every workgroup recomputes these 256 values) and of the local totals
+    uint32_t gtotal, ltotal;
+    const uint32_t gstart = block_exclusive_scan_256(threadIdx.x < nbins ? ghist[threadIdx.x] : 0u, &gtotal, lds_wave);
+    const uint32_t ds = block_exclusive_scan_256(tot, &ltotal, lds_wave);
+    if (threadIdx.x < nbins) {
+        uint32_t excl = 0;
+        if (bid > 0) {
+            int64_t b = (int64_t)bid - 1;
+            uint32_t spins = 0;
+            while (b >= 0) {
+                const uint32_t st = __hip_atomic_load(status + (size_t)b * RS_MAX_BINS + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = st & ~OS_VAL_MASK;
+                if (flag == 0u) {
+                    if (++spins > (1u << 26)) { *err = 1u; break; }      // bounded: never hang the device
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += st & OS_VAL_MASK;
+                if (flag == OS_FLAG_INC) break;
+                b--;
+            }
+            __hip_atomic_store(status + (size_t)bid * RS_MAX_BINS + threadIdx.x, OS_FLAG_INC | ((excl + tot) & OS_VAL_MASK),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        dstart[threadIdx.x] = ds;
+        delta[threadIdx.x] = gstart + excl - ds;
+    }
+    __syncthreads();
+
+    const size_t remaining = n - base;
+    const uint32_t count = remaining < (size_t)RS_CHUNK ? (uint32_t)remaining : (uint32_t)RS_CHUNK;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[k] >> shift) & mask;
+            const uint32_t lpos = dstart[d] + wcnt[wave][d] + rank[k];
+            skey[lpos] = key[k];
+            sval[lpos] = val[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const uint32_t l = (uint32_t)k * RS_THREADS + threadIdx.x;
+        if (l < count) {
+            const uint32_t kk = skey[l];
+            const uint32_t d = (kk >> shift) & mask;
+            const uint32_t dst = l + delta[d];
+            keys_out[dst] = kk;
+            vals_out[dst] = sval[l];
+        }
+    }
+}
+
+// Measured on MI355X (C3): depth sort (P = 1M, 245 chunks) 0.154 -> 0.135 ms, tile sort (R = 12.5M, 3052 chunks)
+// 0.189 -> 0.254 ms: when ~1000 workgroups start together their look-back walks hundreds of AGGREGATE rows before
+// the first INCLUSIVE prefix appears.  Net loss, so it stays an opt-in experiment (IBGS_RADIX_ONESWEEP=1).
+static bool g_use_onesweep = (getenv("IBGS_RADIX_ONESWEEP") != nullptr);
+void radix_set_onesweep(bool on) { g_use_onesweep = on; }
+
+static size_t onesweep_elems(size_t n)
+{
+    const size_t nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    return (size_t)OS_MAX_PASS * RS_MAX_BINS + 64 + (size_t)OS_MAX_PASS * (nblocks ? nblocks : 1) * RS_MAX_BINS;
+}
+
+static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
+                                     uint32_t* scratch, size_t scratch_elems)
+{
+    const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
+    const int nbins = 1 << dbits;
+    const size_t need = (size_t)OS_MAX_PASS * RS_MAX_BINS + 64 + (size_t)npass * nblocks * RS_MAX_BINS;
+    if (scratch_elems < need) { set_error("onesweep scratch too small"); return -IBGS_ERR_ALLOC; }
+    uint32_t* ghist = scratch;                                  // OS_MAX_PASS x 256
+    uint32_t* tickets = scratch + OS_MAX_PASS * RS_MAX_BINS;      // per pass ticket counters, [32] = error flag
+    uint32_t* status = tickets + 64;
+    IBGS_HIP(hipMemsetAsync(scratch, 0, need * sizeof(uint32_t), s));
+    const unsigned hblocks = nblocks < 1024u ? nblocks : 1024u;
+    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(RS_THREADS), 0, s, keys[0], n, npass, dbits, ghist);
+    IBGS_HIP(hipGetLastError());
+    int cur = 0;
+    for (int pass = 0; pass < npass; pass++) {
+        hipLaunchKernelGGL(onesweep_pass_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                           n, pass * dbits, dbits, nbins, ghist + pass * RS_MAX_BINS, status + (size_t)pass * nblocks * RS_MAX_BINS,
+                           tickets + pass, tickets + 32);
+        IBGS_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    if (cur != 0) {
+        IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
 size_t radix_hist_elems(size_t n)
 {
     const size_t nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
     const size_t hist = (size_t)RS_MAX_BINS * (nblocks ? nblocks : 1) + 1;
-    return hist + 64 + scan_scratch_elems(hist);
+    const size_t classic = hist + 64 + scan_scratch_elems(hist);
+    const size_t os = onesweep_elems(n);
+    return classic > os ? classic : os;
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
@@ -251,6 +442,8 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int npass = (nbits_total + 7) / 8;
     const int dbits = (nbits_total + npass - 1) / npass;
     const int nbins = 1 << dbits;
+    if (g_use_onesweep && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;
