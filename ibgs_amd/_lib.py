@@ -77,6 +77,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_forward", "ibgs_backward", "ibgs_mark_visible",
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
+           "ibgs_required_knn", "ibgs_knn_mean_dist2",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -128,6 +129,10 @@ def load():
     lib.ibgs_timing_enable.argtypes = [ctypes.c_uint32]
     lib.ibgs_timing_collect.restype = ctypes.c_int32
     lib.ibgs_timing_collect.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.ibgs_required_knn.restype = ctypes.c_size_t
+    lib.ibgs_required_knn.argtypes = [ctypes.c_int32]
+    lib.ibgs_knn_mean_dist2.restype = ctypes.c_int32
+    lib.ibgs_knn_mean_dist2.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ibgs_sizeof_forward_args.restype = ctypes.c_size_t
     lib.ibgs_sizeof_backward_args.restype = ctypes.c_size_t
     if (lib.ibgs_sizeof_forward_args() != ctypes.sizeof(ForwardArgs)

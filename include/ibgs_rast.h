@@ -175,6 +175,13 @@ int32_t ibgs_backward(const ibgs_backward_args* args);
 int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                           const float* projmatrix, uint8_t* present /* P bools */);
 
+/* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
+ * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other
+ * points (exact).  `scratch` >= ibgs_required_knn(P) bytes, caller-owned, transient. */
+size_t ibgs_required_knn(int32_t P);
+int32_t ibgs_knn_mean_dist2(void* stream, int32_t P, const float* points /* P x 3 */, float* out /* P */,
+                            char* scratch, size_t scratch_bytes);
+
 /* Introspection for tests: byte offsets of the named sub-arrays inside the arenas.
  * Returns -1 for an unknown name. Names: see DESIGN.md "Arena layout". */
 int64_t ibgs_geom_offset(int32_t P, const char* name);

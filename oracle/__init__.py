@@ -232,3 +232,11 @@ def eval_sh(deg, shs, dirs):
     out = np.zeros((N, 3), np.float32)
     lib().orc_eval_sh(_ci(N), _ci(deg), _ci(M), _p(dirs), _p(shs), _p(out))
     return out
+
+
+def knn_mean_dist2(points):
+    """(P,3) -> (P,) mean squared distance to the 3 nearest other points (brute force)."""
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32)).reshape(-1, 3)
+    out = np.zeros(pts.shape[0], np.float32)
+    lib().orc_knn_mean_dist2(_ci(pts.shape[0]), _p(pts), _p(out))
+    return out

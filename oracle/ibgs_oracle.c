@@ -950,3 +950,24 @@ void orc_eval_sh(int N, int D, int M, const float* dirs, const float* shs /* N x
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * distCUDA2 (submodules/simple-knn/simple_knn.cu:132-183, spatial.cu:15-26): mean of the three
+ * smallest squared distances to the other points.  The reference's Morton boxes only prune; the
+ * result is the exact 3-NN answer, restated here as a brute-force scan (O(P^2), small P only).
+ * ---------------------------------------------------------------------------------------- */
+void orc_knn_mean_dist2(int P, const float* pts, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        float best[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+        const float* p = pts + 3 * i;
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            const float dx = pts[3 * j] - p[0], dy = pts[3 * j + 1] - p[1], dz = pts[3 * j + 2] - p[2];
+            float d = dx * dx + dy * dy + dz * dz;
+            for (int k = 0; k < 3; k++) if (best[k] > d) { const float t = best[k]; best[k] = d; d = t; }
+        }
+        out[i] = (best[0] + best[1] + best[2]) / 3.0f;
+    }
+}
