@@ -146,12 +146,6 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
     const int n = (int)(r1 - r0);
     int top = min((int)nmax, n);           // entries >= top contribute to no pixel of this wave
 
-    // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist, 15 unused.
-    // Kept zero between Gaussians: only the ones that were actually accumulated into are cleared again.
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = 0.f;
-
     while (top > 0) {
         const int count = min(WAVE, top);
         if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
@@ -168,6 +162,10 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];
             const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
+            // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist, 15 unused
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = 0.f;
             bool any = false;
             // same evaluation of p2 = d^T conic d as the forward (render_fwd.hip): once per lane, shifted to the
             // other three quadrants, so both passes take identical alpha decisions
@@ -293,8 +291,6 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                 const float tot = wave_transpose_reduce16(v, lane);
                 const uint32_t id = s_id[j];
                 if ((lane & 3) == 0 && (lane >> 2) < (GEO ? 15 : 11)) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + (lane >> 2), tot);
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = 0.f;
             }
         }
         __syncthreads();

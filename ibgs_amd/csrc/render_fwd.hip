@@ -99,13 +99,14 @@ __device__ __forceinline__ int xcd_band_map(int b, int n)
     return (b & 7) * per + (b >> 3);
 }
 
-template <int MODE, int PPL>
+// MAXL = compile-time capacity of the per-pixel median buffer (4 covers the reference's default
+// buffer_length = 4 with half the select chains of 8).
+template <int MODE, int PPL, int MAXL>
 __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 {
     constexpr bool GEO = (MODE == MODE_GEO);
     constexpr bool DEPTH = (MODE == MODE_DEPTH);
     constexpr int NQ = GEO ? 4 : 3;          // record quads staged per Gaussian
-    constexpr int MAXL = IBGS_MAX_BUFFER_LENGTH;
     __shared__ float4 s_rec[NQ][WAVE];
 
     const int lane = threadIdx.x;
@@ -227,9 +228,15 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 const uint32_t contributor = DEPTH ? cnt[q] : (uint32_t)(e + 1);
                 if (!DEPTH) { C[q][0] += q2.x * aT; C[q][1] += q2.y * aT; C[q][2] += q2.z * aT; }
                 if (GEO || DEPTH) {
-                    const float dep = -q1.w / (q3.x * rayx[q] + q3.y * rayy[q] + q3.z + eps);
+                    // ray/plane depth = -dist / denom (forward.cu:439-442).  The geo pass only needs its SIGN inside the
+                    // loop (the "depth > 0" gate); the value is recomputed in the epilogue for the <= L buffered entries,
+                    // so neither the division nor a depth ring lives in the hot loop.
+                    const float denom = q3.x * rayx[q] + q3.y * rayy[q] + q3.z + eps;
+                    float dep = 0.f;
+                    if (DEPTH) dep = -q1.w / denom;
                     if (GEO) { Nacc[q][0] += q3.x * aT; Nacc[q][1] += q3.y * aT; Nacc[q][2] += q3.z * aT; }
-                    const bool hit = acc && (dep > 0.0f);
+                    const bool pos = DEPTH ? (dep > 0.0f) : ((q1.w > 0.f && denom < 0.f) || (q1.w < 0.f && denom > 0.f));
+                    const bool hit = acc && pos;
                     const bool front = T[q] > 0.5f;
                     int slot = -1;
                     if (hit && front) slot = before_ptr[q];
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     }
                     if (slot >= 0) {
 #pragma unroll
-                        for (int s = 0; s < MAXL; s++) if (s == slot) { bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
+                        for (int s = 0; s < MAXL; s++) if (s == slot) { if (DEPTH) bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
                         if (front) before_ptr[q] = (before_ptr[q] + 1) % before_cap;
                         else below_count[q]++;
                         if (DEPTH) { tot_w[q] += aT; wd_sum[q] += aT * dep; }
@@ -250,6 +257,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     if (DEPTH && hit && below_count[q] == below_cap) {
                         // forward.cu:484-488: 'break' leaves the current 256-entry round only
                         resume[q] = (e / 256 + 1) * 256;
+                    }
+                    if (DEPTH && below_cap > 0) {
+                        // Once the below-half is full the weighted sums can no longer change (T <= 0.5 from here on), so
+                        // the pixel is finished.  The reference keeps blending until T < 1e-4 for nothing; only the
+                        // internal final_T / n_contrib of a depth-only pass differ, its output does not.
+                        live[q] &= ~__builtin_amdgcn_ballot_w64(hit && below_count[q] == below_cap);
                     }
                 }
                 T[q] = test_T;
@@ -287,8 +300,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             for (int s = 0; s < L; s++) {
                 float w = 0.f, d = 0.f; uint32_t c = 0;
 #pragma unroll
-                for (int k = 0; k < MAXL; k++) if (k == s) { w = bw[q][k]; d = bd[q][k]; c = bc[q][k]; }
+                for (int k = 0; k < MAXL; k++) if (k == s) { w = bw[q][k]; c = bc[q][k]; }
                 if (w == 0.0f) continue;
+                {   // depth of buffered contributor c (1-based list position): same expression as the blend loop would use
+                    const uint32_t gid = p.point_list[r0 + c - 1u];
+                    const float4 g1 = p.rec[(size_t)gid * 4 + 1], g3 = p.rec[(size_t)gid * 4 + 3];
+                    d = -g1.w / (g3.x * rayx[q] + g3.y * rayy[q] + g3.z + eps);
+                }
                 const float X = pdx * d * inv_fx, Y = pdy * d * inv_fy, Z = d;
 #pragma unroll
                 for (int si = 0; si < IBGS_MAX_SRC; si++) {
@@ -382,14 +400,16 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     const int nt = p.ntiles;
     if (a.render_depth_only && !a.render_geo) {
         const int grid = ((nt + 7) / 8) * 8;
-        hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4>), dim3(grid), dim3(64), 0, s, p);
+        if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 4>), dim3(grid), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 8>), dim3(grid), dim3(64), 0, s, p);
     } else if (a.render_geo) {
         const int items = nt * 4;
         const int grid = ((items + 7) / 8) * 8;
-        hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1>), dim3(grid), dim3(64), 0, s, p);
+        if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), dim3(grid), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), dim3(grid), dim3(64), 0, s, p);
     } else {
         const int grid = ((nt + 7) / 8) * 8;
-        hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4>), dim3(grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), dim3(grid), dim3(64), 0, s, p);
     }
     IBGS_HIP(hipGetLastError());
     return 0;
