@@ -89,14 +89,17 @@ def main():
     ap.add_argument("--config", default="C3", choices=list(syn.CONFIGS))
     ap.add_argument("--opacity", default="init", choices=["init", "trained"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="factored", choices=["factored", "dense"],
+                    help="N > 1: factored = all-gather 3-float dL/dRGB per view + local SH expansion (default); dense = all-reduce of every gradient")
     ap.add_argument("--geo", action="store_true", help="second line of SURVEY 8(d): render_geo=True, n_src=4, L=4")
     a = ap.parse_args()
 
-    rank, world, local_rank = vdist.init_from_env()
+    rank, world, local_rank = vdist.init_from_env(backend=os.environ.get("IBGS_DIST_BACKEND"))   # default: nccl (= RCCL)
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local_rank %= max(torch.cuda.device_count(), 1)      # lets a 1-GPU box run the N > 1 code path over gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.load()
@@ -128,6 +131,7 @@ def main():
     target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     params = [leaves[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
     bucket = vdist.GradBucket(params) if world > 1 else None
+    reducer = vdist.ViewParallelReducer(params, sh=leaves["shs"], means3D=leaves["means3D"]) if (world > 1 and a.exchange == "factored") else None
     R_seen = [0]
 
     def step():
@@ -140,9 +144,14 @@ def main():
         if a.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
             loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
         R_seen[0] = outs[0].grad_fn.num_rendered
-        loss.backward()
-        if world > 1:
-            vdist.allreduce_gradients(params, bucket)
+        if reducer is not None:
+            with reducer.capture():
+                loss.backward()
+            reducer.reduce()
+        else:
+            loss.backward()
+            if world > 1:
+                vdist.allreduce_gradients(params, bucket)
 
     def fence():
         if world > 1:
@@ -194,7 +203,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer fwd+bwd, L1 loss vs fixed random target, "
                                    "opacity=%s%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], a.opacity, ", render_geo n_src=4 L=4" if a.geo else "",
-                                                                        ", RCCL all-reduce of Gaussian gradients" if world > 1 else ""),
+                                                                        (", RCCL gradient exchange (%s)" % a.exchange) if world > 1 else ""),
                        "num_rendered": R, "parallelism": "view-parallel x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "render_bwd_geo_kernel" if a.geo else "render_bwd_color_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,

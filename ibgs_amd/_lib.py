@@ -15,6 +15,7 @@ FLAG_DEBUG = 1
 FLAG_TEX_QUANT = 2
 FLAG_NO_TILE_CULL = 4
 FLAG_CLEAR_GRAD_ACC = 8
+FLAG_SH_FACTORED = 16
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 
@@ -77,7 +78,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_forward", "ibgs_backward", "ibgs_mark_visible",
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
-           "ibgs_required_knn", "ibgs_knn_mean_dist2",
+           "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -131,6 +132,8 @@ def load():
     lib.ibgs_timing_collect.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.ibgs_required_knn.restype = ctypes.c_size_t
     lib.ibgs_required_knn.argtypes = [ctypes.c_int32]
+    lib.ibgs_sh_grad_from_views.restype = ctypes.c_int32
+    lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 4
     lib.ibgs_knn_mean_dist2.restype = ctypes.c_int32
     lib.ibgs_knn_mean_dist2.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ibgs_sizeof_forward_args.restype = ctypes.c_size_t

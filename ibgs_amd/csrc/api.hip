@@ -265,7 +265,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     if (!a.dL_dmean2D || !a.dL_dmean2D_abs || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmean3D || !a.dL_dcov3D) {
         set_error("missing gradient output"); return -IBGS_ERR_INVALID;
     }
-    if (a.shs && !a.dL_dsh) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
+    if (a.shs && !a.dL_dsh && !(a.flags & IBGS_FLAG_SH_FACTORED)) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
     if (a.scales && (!a.dL_dscale || !a.dL_drot)) { set_error("dL_dscale / dL_drot required"); return -IBGS_ERR_INVALID; }
     if (a.render_geo) {
         if (!a.all_map || !a.dL_dall_map || !a.out_depth || !a.out_warped || !a.ref_to_src || !a.src_images) { set_error("geo backward inputs missing"); return -IBGS_ERR_INVALID; }
@@ -288,6 +288,15 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     { StageTimer t(s, IBGS_STAGE_PREPROCESS_BWD); if ((rc = launch_preprocess_backward(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess backward"))) return rc;
     return 0;
+}
+
+int32_t ibgs_sh_grad_from_views(void* stream, int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,
+                                const float* camposes, const float* dcolor, float* dL_dsh)
+{
+    if (P <= 0 || M <= 0) return 0;
+    if (D < 0 || D > 3 || (D + 1) * (D + 1) > M || n_views < 0) { set_error("bad SH degree / view count"); return -IBGS_ERR_INVALID; }
+    if (!means3D || !dL_dsh || (n_views > 0 && (!camposes || !dcolor))) { set_error("null pointer"); return -IBGS_ERR_INVALID; }
+    return launch_sh_grad_from_views(reinterpret_cast<hipStream_t>(stream), P, D, M, n_views, means3D, camposes, dcolor, dL_dsh);
 }
 
 int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

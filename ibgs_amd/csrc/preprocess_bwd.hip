@@ -34,15 +34,42 @@ struct PreBwdParams {
 // with 16-B vector loads and dL/dsh leaves through an LDS transpose so that the wave stores its contiguous
 // 12 KB block with fully coalesced 16-B writes (a per-lane row store is 48 instructions that each touch 64
 // different cache lines).
-template <bool FAST16>
+// Real SH basis values for the unit direction (x, y, z), degree 0..D (forward.cu:20-70 / backward.cu:114-160
+// use the same polynomials); returns how many of the 16 entries are active.
+__device__ __forceinline__ int sh_basis(int D, float x, float y, float z, float (&B)[16])
+{
+    int nb = 1;
+    B[0] = bC0;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    if (D > 0) {
+        B[1] = -bC1 * y; B[2] = bC1 * z; B[3] = -bC1 * x; nb = 4;
+        if (D > 1) {
+            B[4] = bC2[0] * xy; B[5] = bC2[1] * yz; B[6] = bC2[2] * (2.0f * zz - xx - yy);
+            B[7] = bC2[3] * xz; B[8] = bC2[4] * (xx - yy); nb = 9;
+            if (D > 2) {
+                B[9] = bC3[0] * y * (3.0f * xx - yy); B[10] = bC3[1] * xy * z;
+                B[11] = bC3[2] * y * (4.0f * zz - xx - yy);
+                B[12] = bC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                B[13] = bC3[4] * x * (4.0f * zz - xx - yy); B[14] = bC3[5] * z * (xx - yy);
+                B[15] = bC3[6] * x * (xx - 3.0f * yy); nb = 16;
+            }
+        }
+    }
+    return nb;
+}
+
+// WRITE_SH = false is the view-parallel "factored" mode (IBGS_FLAG_SH_FACTORED): dL/dsh of one view is the
+// outer product basis(dir) x dL/dRGB, so only the clamp-masked dL/dRGB (3 floats instead of 3 M) leaves this
+// kernel, in dL_dcolors; ibgs_sh_grad_from_views (below) rebuilds the summed dL/dsh after the exchange.
+template <bool FAST16, bool WRITE_SH>
 __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBwdParams p, Cam cam)
 {
     __shared__ float4 s_t[FAST16 ? 64 * 13 : 1];     // row stride 13 quads: conflict-free b128 access
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < p.P;
     const bool vis = valid && (p.radii[i] > 0);
-    float gv[FAST16 ? 48 : 1];
-    if (FAST16) {
+    float gv[(FAST16 && WRITE_SH) ? 48 : 1];
+    if (FAST16 && WRITE_SH) {
 #pragma unroll
         for (int k = 0; k < 48; k++) gv[k] = 0.f;
     }
@@ -56,7 +83,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         if (p.dL_dall_map) for (int k = 0; k < 5; k++) p.dL_dall_map[5 * i + k] = 0.f;
         p.dL_dmean3D[3 * i] = 0.f; p.dL_dmean3D[3 * i + 1] = 0.f; p.dL_dmean3D[3 * i + 2] = 0.f;
         for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
-        if (!FAST16 && p.shs) { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
+        if (!FAST16 && WRITE_SH && p.shs) { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
         if (p.scales) {
             p.dL_dscale[3 * i] = 0.f; p.dL_dscale[3 * i + 1] = 0.f; p.dL_dscale[3 * i + 2] = 0.f;
             p.dL_drot[4 * i] = 0.f; p.dL_drot[4 * i + 1] = 0.f; p.dL_drot[4 * i + 2] = 0.f; p.dL_drot[4 * i + 3] = 0.f;
@@ -82,7 +109,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     p.dL_dmean2D_abs[3 * i] = ddelx_dx * g0.z; p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * g0.w; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
     if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }
     p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
-    p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2];
+    if (WRITE_SH || !p.shs) { p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2]; }
     if (p.dL_dall_map) {
         p.dL_dall_map[5 * i] = g2.w; p.dL_dall_map[5 * i + 1] = g3.x; p.dL_dall_map[5 * i + 2] = g3.y;
         p.dL_dall_map[5 * i + 3] = 0.f; p.dL_dall_map[5 * i + 4] = g3.z;
@@ -186,26 +213,13 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         float g[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) g[ch] = gcol[ch] * (((cb >> ch) & 1) ? 0.f : 1.f);
+        if (!WRITE_SH) { p.dL_dcolors[3 * i] = g[0]; p.dL_dcolors[3 * i + 1] = g[1]; p.dL_dcolors[3 * i + 2] = g[2]; }
         float B[16];
-        int nb = 1;
-        B[0] = bC0;
         const int D = p.D;
+        const int nb = sh_basis(D, x, y, z, B);
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        if (D > 0) {
-            B[1] = -bC1 * y; B[2] = bC1 * z; B[3] = -bC1 * x; nb = 4;
-            if (D > 1) {
-                B[4] = bC2[0] * xy; B[5] = bC2[1] * yz; B[6] = bC2[2] * (2.0f * zz - xx - yy);
-                B[7] = bC2[3] * xz; B[8] = bC2[4] * (xx - yy); nb = 9;
-                if (D > 2) {
-                    B[9] = bC3[0] * y * (3.0f * xx - yy); B[10] = bC3[1] * xy * z;
-                    B[11] = bC3[2] * y * (4.0f * zz - xx - yy);
-                    B[12] = bC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-                    B[13] = bC3[4] * x * (4.0f * zz - xx - yy); B[14] = bC3[5] * z * (xx - yy);
-                    B[15] = bC3[6] * x * (xx - 3.0f * yy); nb = 16;
-                }
-            }
-        }
-        if (FAST16) {
+        if (!WRITE_SH) {
+        } else if (FAST16) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < nb) { gv[3 * k] = B[k] * g[0]; gv[3 * k + 1] = B[k] * g[1]; gv[3 * k + 2] = B[k] * g[2]; }
@@ -284,7 +298,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     }
     }   // vis
 
-    if (FAST16 && p.shs) {
+    if (FAST16 && WRITE_SH && p.shs) {
         const int lane = threadIdx.x;
 #pragma unroll
         for (int v = 0; v < 12; v++) s_t[lane * 13 + v] = make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
@@ -313,8 +327,74 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
     p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
     p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;
     const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
-    if (a.shs && a.M == 16) hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
-    else hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+    const bool factored = a.shs && (a.flags & IBGS_FLAG_SH_FACTORED);
+    if (a.shs && a.M == 16) {
+        if (factored) hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<true, true>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
+    } else {
+        if (factored) hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+    }
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+// dL/dsh summed over the views of a view-parallel step, rebuilt from the exchanged factors:
+// dL_dsh[i][k][c] = sum_v basis_k(normalise(mean_i - campos_v)) * dcolor[v][i][c]   (k < (D+1)^2, zero above).
+// One thread per Gaussian; views in index order on every rank, so all ranks hold bit-identical sums.
+// M == 16: the 192-B rows leave through the same LDS transpose as preprocess_bwd_kernel<true, true>.
+template <bool FAST16>
+__global__ void __launch_bounds__(FAST16 ? 64 : 256) sh_grad_from_views_kernel(int P, int D, int M, int n_views, const float* __restrict__ means3D,
+                                                                                const float* __restrict__ camposes, const float* __restrict__ dcolor,
+                                                                                float* __restrict__ dL_dsh)
+{
+    __shared__ float4 s_t[FAST16 ? 64 * 13 : 1];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) acc[k] = 0.f;
+    if (i < P) {
+        const float mx = means3D[3 * i], my = means3D[3 * i + 1], mz = means3D[3 * i + 2];
+        for (int v = 0; v < n_views; v++) {
+            const float* g = dcolor + ((size_t)v * P + i) * 3;
+            const float g0 = g[0], g1 = g[1], g2 = g[2];
+            const float dx = mx - camposes[3 * v], dy = my - camposes[3 * v + 1], dz = mz - camposes[3 * v + 2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            float B[16];
+            const int nb = sh_basis(D, dx / len, dy / len, dz / len, B);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < nb) { acc[3 * k] += B[k] * g0; acc[3 * k + 1] += B[k] * g1; acc[3 * k + 2] += B[k] * g2; }
+            }
+        }
+    }
+    if (FAST16) {
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < 12; v++) s_t[lane * 13 + v] = make_float4(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
+        __syncthreads();
+        const int i0 = blockIdx.x * 64;
+        const int nrows = min(64, P - i0);
+        float4* dst = reinterpret_cast<float4*>(dL_dsh + (size_t)i0 * 48);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int f = lane + 64 * k;
+            const int r = f / 12, c = f - 12 * r;
+            if (r < nrows) dst[f] = s_t[r * 13 + c];
+        }
+    } else if (i < P) {
+        float* gsh = dL_dsh + (size_t)i * M * 3;
+        const int nact = min(M, 16);
+        for (int k = 0; k < nact; k++) { gsh[3 * k] = acc[3 * k]; gsh[3 * k + 1] = acc[3 * k + 1]; gsh[3 * k + 2] = acc[3 * k + 2]; }
+        for (int k = 3 * nact; k < 3 * M; k++) gsh[k] = 0.f;
+    }
+}
+
+int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, const float* means3D, const float* camposes,
+                              const float* dcolor, float* dL_dsh)
+{
+    if (M == 16) hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3((P + 63) / 64), dim3(64), 0, s, P, D, M, n_views, means3D, camposes, dcolor, dL_dsh);
+    else hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, n_views, means3D, camposes, dcolor, dL_dsh);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

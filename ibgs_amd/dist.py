@@ -89,6 +89,64 @@ def allreduce_gradients(params, bucket=None, group=None, average=False):
     return bucket
 
 
+class ViewParallelReducer:
+    """Gradient exchange of one view-parallel step, sized for xGMI (point-to-point links: bytes per rank are
+    what costs).  For SH degree 3 the SH coefficients are 48 of the 59 gradient floats per Gaussian, but the
+    dL/dsh of ONE view is rank one -- basis(direction to that camera) x dL/dRGB (reference backward.cu:114-160)
+    -- so ranks all-gather the 3-float dL/dRGB of their views (plus the camera centres) and every rank rebuilds
+    the summed dL/dsh locally (`ibgs_sh_grad_from_views`); only the remaining parameters go through the flat
+    all-reduce.  Per rank at P = 1M, 8 ranks: ~77 MB + 84 MB on the links instead of ~413 MB.
+
+        red = ViewParallelReducer(params, sh=shs_param, means3D=xyz_param)
+        with red.capture():            # one or more backward passes (views) per rank
+            loss.backward()
+        red.reduce()                   # every p.grad now holds the sum over all ranks' views
+
+    The result equals the sequential accumulation of the single-view gradients (summation order differs)."""
+
+    def __init__(self, params, sh=None, means3D=None, group=None, expand=None):
+        self.sh, self.means3D, self.group = sh, means3D, group
+        self.dense = [p for p in params if p is not sh]
+        self.bucket = None
+        self.items = None
+        self._expand = expand
+
+    def capture(self):
+        from . import rasterizer
+        red = self
+
+        class _Ctx(rasterizer.capture_sh_factors):
+            def __enter__(self):
+                red.items = super().__enter__()
+                return red.items
+        return _Ctx()
+
+    def reduce(self, average=False):
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            self.bucket = allreduce_gradients(self.dense, self.bucket, self.group, average)
+        items, self.items = self.items or [], None
+        if self.sh is None or not items:
+            return
+        expand = self._expand
+        if expand is None:
+            from .shgrad import sh_grad_from_views as expand
+        degree, M = items[0]["degree"], items[0]["M"]
+        dcolor = torch.stack([it["dcolor"] for it in items])                   # (n_local, P, 3)
+        campos = torch.stack([it["campos"].to(dcolor.device) for it in items])  # (n_local, 3)
+        if world > 1:
+            all_d = torch.empty((world * dcolor.shape[0],) + tuple(dcolor.shape[1:]), dtype=dcolor.dtype, device=dcolor.device)
+            all_c = torch.empty((world * campos.shape[0], 3), dtype=campos.dtype, device=campos.device)
+            dist.all_gather_into_tensor(all_d, dcolor.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(all_c, campos.contiguous(), group=self.group)
+            dcolor, campos = all_d, all_c
+        g = expand(self.means3D.detach(), campos, dcolor, degree, M)
+        if average:
+            g = g / world
+        g = g.view_as(self.sh)
+        self.sh.grad = g if self.sh.grad is None else self.sh.grad + g
+
+
 def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None):
     """Per-view statistics consumed by GaussianModel.add_densification_stats
     (scene/gaussian_model.py:600-604; train.py:400-410), reduced over the views of this step:

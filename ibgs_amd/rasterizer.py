@@ -32,6 +32,26 @@ TEX_QUANT = False
 # Exact tile culling (shorter per-tile lists, identical outputs).  False reproduces the reference's AABB lists.
 TILE_CULL = True
 
+# View-parallel training (ibgs_amd/dist.py): while a `capture_sh_factors()` block is active the backward leaves
+# dL/dsh unwritten (returns None for it) and records the per-view factors -- clamp-masked dL/dRGB (P, 3), camera
+# centre, active degree -- so that ranks exchange 3 floats per Gaussian instead of 3 M (include/ibgs_rast.h,
+# IBGS_FLAG_SH_FACTORED / ibgs_sh_grad_from_views).
+_sh_factor_sink = None
+
+
+class capture_sh_factors:
+    def __enter__(self):
+        global _sh_factor_sink
+        self._prev, self.items = _sh_factor_sink, []
+        _sh_factor_sink = self.items
+        return self.items
+
+    def __exit__(self, *exc):
+        global _sh_factor_sink
+        _sh_factor_sink = self._prev
+        return False
+
+
 _tex_scratch = {}
 _gacc_scratch = {}   # (device index, P) -> [zeroed P x 16 tensor, dirty flag]; ibgs_backward re-zeroes what it consumed
 
@@ -230,7 +250,8 @@ class _CModule:
             dL_dmeans2D_abs = new(P, 3, **opts); dL_dcolors = new(P, NUM_CHANNELS, **opts)
             dL_dall_map = (new if (render_geo and all_maps.numel() != 0) else torch.zeros)(P, NUM_PLANE_PARAMS, **opts)
             dL_dopacity = new(P, 1, **opts); dL_dcov3D = new(P, 6, **opts)
-            dL_dsh = new(P, M, 3, **opts)
+            factored = _sh_factor_sink is not None and M != 0 and P != 0
+            dL_dsh = None if factored else new(P, M, 3, **opts)
             dL_dscales = (new if have_sr else torch.zeros)(P, 3, **opts)
             dL_drotations = (new if have_sr else torch.zeros)(P, 4, **opts)
             if P != 0:
@@ -274,16 +295,18 @@ class _CModule:
                 a.dL_dconic = None
                 a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr()
                 a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr()
-                a.dL_dsh = dL_dsh.data_ptr() if M else None
+                a.dL_dsh = dL_dsh.data_ptr() if (M and not factored) else None
                 a.dL_dscale = dL_dscales.data_ptr(); a.dL_drot = dL_drotations.data_ptr()
                 a.dL_dall_map = dL_dall_map.data_ptr()
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | _lib.FLAG_CLEAR_GRAD_ACC)
+                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0))
                 rc = lib.ibgs_backward(ctypes.byref(a))
                 if rc < 0:
                     raise RuntimeError("ibgs_backward failed (%d): %s" % (rc, _lib.last_error()))
                 gacc_ent[1] = False
+                if factored:
+                    _sh_factor_sink.append({"dcolor": dL_dcolors, "campos": campos_c.reshape(3), "degree": int(degree), "M": M})
         return (dL_dmeans2D, dL_dmeans2D_abs, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                 dL_dscales, dL_drotations, dL_dall_map)
 

@@ -57,6 +57,11 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
 #define IBGS_FLAG_NO_TILE_CULL 4u /* emit the reference's full AABB tile lists (rasterizer_impl.cu:205-225) instead of
                                      dropping tiles that provably fail the alpha >= 1/255 test; outputs are identical */
 
+#define IBGS_FLAG_SH_FACTORED 16u /* ibgs_backward only, view-parallel training: dL/dsh of ONE view is the outer product
+                                     basis(dir) x dL/dRGB (backward.cu:114-160), so leave dL_dsh unwritten (may be NULL) and
+                                     write the clamp-masked dL/dRGB (P x 3) to dL_dcolors; after the ranks exchanged those
+                                     3 floats instead of 3 M, ibgs_sh_grad_from_views rebuilds the summed dL/dsh */
+
 typedef struct ibgs_forward_args {
     void* stream;
     /* problem size */
@@ -174,6 +179,13 @@ int64_t ibgs_forward(const ibgs_forward_args* args);
 int32_t ibgs_backward(const ibgs_backward_args* args);
 int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                           const float* projmatrix, uint8_t* present /* P bools */);
+
+/* View-parallel step, SURVEY 8(e): dL_dsh[i][k][c] = sum over views v of basis_k(normalise(means3D[i] - camposes[v]))
+ * * dcolor[v][i][c] for k < (D+1)^2, zero for the other coefficients; dL_dsh (P x M x 3) is fully overwritten.
+ * `dcolor` = the dL_dcolors outputs of n_views ibgs_backward calls made with IBGS_FLAG_SH_FACTORED, stacked
+ * (n_views x P x 3); `camposes` = their camera centres (n_views x 3).  No reference counterpart (single GPU). */
+int32_t ibgs_sh_grad_from_views(void* stream, int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,
+                                const float* camposes, const float* dcolor, float* dL_dsh);
 
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other

@@ -61,3 +61,67 @@ def test_single_process_is_a_noop():
     b = vdist.GradBucket(p)
     flat = b.pack([p[0].grad])
     assert flat.numel() == 4 and torch.all(b.unpack()[0] == 2.0)
+
+
+def _expand_ref(means3D, camposes, dcolor, degree, M):
+    """Independent restatement of ibgs_sh_grad_from_views through autograd of the renderer's eval_sh."""
+    from ibgs_amd.renderer import eval_sh
+    P = means3D.shape[0]
+    out = torch.zeros(P, M, 3)
+    for v in range(camposes.shape[0]):
+        d = means3D - camposes[v]
+        d = d / d.norm(dim=1, keepdim=True)
+        sh0 = torch.zeros(P, 3, M, requires_grad=True)
+        col = eval_sh(degree, sh0, d)
+        (g,) = torch.autograd.grad(col, sh0, grad_outputs=dcolor[v])
+        out += g.transpose(1, 2)
+    return out
+
+
+def _worker_factored(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(0)
+    P, M, deg = 40, 16, 2
+    xyz = torch.randn(P, 3, generator=g).requires_grad_(True)
+    shs = torch.randn(P, M, 3, generator=g).requires_grad_(True)
+    opa = torch.rand(P, 1, generator=g).requires_grad_(True)
+    red = vdist.ViewParallelReducer([xyz, shs, opa], sh=shs, means3D=xyz, expand=_expand_ref)
+    gr = torch.Generator().manual_seed(100 + rank)
+    items = []
+    with red.capture() as sink:                    # two local views per rank; the HIP backward would fill `sink`
+        for v in range(2):
+            it = {"dcolor": torch.randn(P, 3, generator=gr), "campos": torch.randn(3, generator=gr) * 4.0, "degree": deg, "M": M}
+            sink.append(it); items.append(it)
+    xyz.grad = torch.randn(P, 3, generator=gr); opa.grad = torch.randn(P, 1, generator=gr)
+    local = {"xyz": xyz.grad.clone(), "opa": opa.grad.clone()}
+    red.reduce()
+    torch.save({"items": items, "local": local, "xyz": xyz.grad.clone(), "opa": opa.grad.clone(), "shs": shs.grad.clone(),
+                "means": xyz.detach().clone()}, os.path.join(out_dir, "f%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factored_sh_exchange_over_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker_factored, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "f%d.pt" % r)) for r in range(world)]
+    campos = torch.stack([it["campos"] for r in res for it in r["items"]])          # rank-major view order
+    dcolor = torch.stack([it["dcolor"] for r in res for it in r["items"]])
+    want = _expand_ref(res[0]["means"], campos, dcolor, 2, 16)
+    for r in res:
+        np.testing.assert_allclose(r["shs"].numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+        assert not r["shs"][:, 9:].any()                                             # above the active degree
+        np.testing.assert_allclose(r["xyz"].numpy(), (res[0]["local"]["xyz"] + res[1]["local"]["xyz"]).numpy(), rtol=1e-6)
+        np.testing.assert_allclose(r["opa"].numpy(), (res[0]["local"]["opa"] + res[1]["local"]["opa"]).numpy(), rtol=1e-6)
+    assert torch.equal(res[0]["shs"], res[1]["shs"])                                 # every rank holds the same bits
+
+
+def test_capture_restores_previous_sink():
+    from ibgs_amd import rasterizer
+    assert rasterizer._sh_factor_sink is None
+    with rasterizer.capture_sh_factors() as outer:
+        with rasterizer.capture_sh_factors() as inner:
+            assert rasterizer._sh_factor_sink is inner
+        assert rasterizer._sh_factor_sink is outer
+    assert rasterizer._sh_factor_sink is None
