@@ -13,8 +13,8 @@
 //     constants (conic, opacity, 0.5*W) are factored out of the pixel sums and applied once per Gaussian
 //     in preprocess_bwd.hip.  Same mathematics (the sums are linear), ~2x fewer VALU ops per pair;
 //   * the 16 per-lane partial sums are reduced over the 64 lanes with a butterfly TRANSPOSE-reduce
-//     (v_permlane32_swap, v_permlane16_swap, DPP row rotates, quad_perm): 38 VALU ops for all 16 values,
-//     after which lane 4j holds the wave total of value j -- no LDS traffic, no LDS atomics;
+//     (v_permlane32_swap, v_permlane16_swap, DPP row rotates / mirrors, quad_perm): 31 VALU ops for the 12 values of
+//     the colour variant (40 for 16), after which one lane per value holds its wave total -- no LDS traffic;
 //   * the wave then issues ONE atomic instruction per Gaussian: 16 lanes add the 16 floats of that
 //     Gaussian's 64-byte accumulation row (grad_acc[P][16]) -- one 64-byte memory-side request per
 //     (Gaussian, tile) instead of 11-16 scattered dword atomics per (Gaussian, pixel);
@@ -86,10 +86,14 @@ template <bool GEO, int PPL>
 __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 {
     constexpr int NQ = GEO ? 4 : 3;
+    constexpr int NV = GEO ? 16 : 12;     // per-lane partial sums handed to the transpose-reduce
     __shared__ float4 s_rec[NQ][WAVE];
     __shared__ uint32_t s_id[WAVE];
 
     const int lane = threadIdx.x;
+    // the lane that ends up with the wave total of grad_acc column `col` after the reduce (-1: none)
+    int col = GEO ? reduce16_column(lane) : reduce12_column(lane);
+    if (col >= (GEO ? 15 : 11)) col = -1;
     const int nitems = p.ntiles * (PPL == 4 ? 1 : 4);
     const int item = xcd_band_map_b(blockIdx.x, nitems);
     if (item >= nitems) return;
@@ -104,7 +108,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 
     float pxf[PPL], pyf[PPL];
     size_t pixid[PPL];
-    float T[PPL], Tfbg[PPL], last_alpha[PPL], last_cg[PPL], S[PPL], g_pix[PPL][3];
+    float T[PPL], Tfbg[PPL], S[PPL], g_pix[PPL][3];
     uint32_t ncontrib[PPL];
     // geo
     float g_n[PPL][3], g_d[PPL], rayx[PPL], rayy[PPL];
@@ -122,7 +126,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
         T[q] = T_final;
         ncontrib[q] = inside ? p.n_contrib[pixid[q]] : 0u;
         nmax = max(nmax, ncontrib[q]);
-        last_alpha[q] = 0.f; last_cg[q] = 0.f; S[q] = 0.f;
+        S[q] = 0.f;
         float bg_dot = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -162,10 +166,10 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];
             const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
-            // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist, 15 unused
-            float v[16];
+            // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist (= grad_acc columns)
+            float v[NV];
 #pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = 0.f;
+            for (int i = 0; i < NV; i++) v[i] = 0.f;
             bool any = false;
             // same evaluation of p2 = d^T conic d as the forward (render_fwd.hip): once per lane, shifted to the
             // other three quadrants, so both passes take identical alpha decisions
@@ -195,19 +199,16 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                         const float rinv = fast_rcp(1.f - alpha);
                         T[q] = T[q] * rinv;
                         const float w = alpha * T[q];
-                        // colour behind this Gaussian, projected on the pixel gradient (scalar form of the
-                        // reference's per-channel accum_rec recurrence, backward.cu:665-669)
-                        const float cg = q2.x * g_pix[q][0] + q2.y * g_pix[q][1] + q2.z * g_pix[q][2];
-                        S[q] = last_alpha[q] * last_cg[q] + (1.f - last_alpha[q]) * S[q];
-                        last_cg[q] = cg;
+                        // S = (colour behind this Gaussian) . (pixel gradient): scalar form of the reference's per-channel
+                        // accum_rec / last_color / last_alpha recurrence (backward.cu:665-669), folded into one fma:
+                        // behind_k = alpha_k c_k + (1 - alpha_k) behind_{k+1} = behind_{k+1} + alpha_k (c_k - behind_{k+1})
+                        float cg = q2.x * g_pix[q][0] + q2.y * g_pix[q][1] + q2.z * g_pix[q][2];
+                        // the normal channels are blended like three more colour channels: they share S
+                        if (GEO) cg += q3.x * g_n[q][0] + q3.y * g_n[q][1] + q3.z * g_n[q][2];
                         float dL_dalpha = cg - S[q];
+                        S[q] = fmaf(alpha, dL_dalpha, S[q]);
                         v[8] += w * g_pix[q][0]; v[9] += w * g_pix[q][1]; v[10] += w * g_pix[q][2];
                         if (GEO) {
-                            // the normal channels are blended like three more colour channels: fold them into the same scalars
-                            const float ng = q3.x * g_n[q][0] + q3.y * g_n[q][1] + q3.z * g_n[q][2];
-                            // NOTE: S / last_cg carry colour + normal together (both recurrences share last_alpha)
-                            dL_dalpha += ng;      // + (n . g_n); the matching "- accum" part is inside S via last_cg below
-                            last_cg[q] += ng;
                             float gm0 = w * g_n[q][0], gm1 = w * g_n[q][1], gm2 = w * g_n[q][2], gm4 = 0.f;
                             // unsigned comparison: min_med == 0 disables the branch
                             if ((k >= (uint32_t)((int)min_med[q] - 1)) && (k <= (uint32_t)((int)max_med[q] - 1))) {
@@ -277,7 +278,6 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                             v[11] += gm0; v[12] += gm1; v[13] += gm2; v[14] += gm4;
                         }
                         dL_dalpha = dL_dalpha * T[q] + Tfbg[q] * rinv;
-                        last_alpha[q] = alpha;
                         const float qq = oG * dL_dalpha;             // dL/dG * G
                         const float qdx = qq * dx, qdy = qq * dy;
                         v[0] += qdx; v[1] += qdy;
@@ -288,9 +288,10 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                 }
             }
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
-                const float tot = wave_transpose_reduce16(v, lane);
+                float tot;
+                if constexpr (GEO) tot = wave_transpose_reduce16(v, lane); else tot = wave_transpose_reduce12(v, lane);
                 const uint32_t id = s_id[j];
-                if ((lane & 3) == 0 && (lane >> 2) < (GEO ? 15 : 11)) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + (lane >> 2), tot);
+                if (col >= 0) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
             }
         }
         __syncthreads();
