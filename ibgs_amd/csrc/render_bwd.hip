@@ -86,9 +86,9 @@ template <bool GEO, int PPL>
 __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 {
     constexpr int NQ = GEO ? 4 : 3;
+    constexpr bool SEL = !GEO;            // branch-free blend step (see the active block)
     constexpr int NV = GEO ? 16 : 12;     // per-lane partial sums handed to the transpose-reduce
     __shared__ float4 s_rec[NQ][WAVE];
-    __shared__ uint32_t s_id[WAVE];
 
     const int lane = threadIdx.x;
     // the lane that ends up with the wave total of grad_acc column `col` after the reduce (-1: none)
@@ -155,8 +155,9 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
         if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
             const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
             const float4* r = p.rec + (size_t)id * 4;
-            s_id[lane] = id;
-            s_rec[0][lane] = r[0]; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
+            float4 ra = r[0];
+            ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
+            s_rec[0][lane] = ra; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
             if constexpr (GEO) s_rec[3][lane] = r[3];
         }
         __syncthreads();
@@ -193,12 +194,17 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                                      __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
                 if (okm != 0ull) {
                     any = true;
-                    if (__builtin_amdgcn_inverse_ballot_w64(okm)) {
+                    // Colour variant: no per-lane branch.  Lanes that fail the test run the same instructions with
+                    // alpha = o G = 0, which leaves T and S unchanged (1/(1-0) = 1 exactly) and adds zeros.
+                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
+                    const float oGs = (SEL && !ok) ? 0.f : oG;
+                    const float alpha_s = (SEL && !ok) ? 0.f : alpha;
+                    if (SEL || ok) {
                         const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];          // only the moments need d and conic*d per quadrant
                         const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
-                        const float rinv = fast_rcp(1.f - alpha);
+                        const float rinv = fast_rcp(1.f - alpha_s);
                         T[q] = T[q] * rinv;
-                        const float w = alpha * T[q];
+                        const float w = alpha_s * T[q];
                         // S = (colour behind this Gaussian) . (pixel gradient): scalar form of the reference's per-channel
                         // accum_rec / last_color / last_alpha recurrence (backward.cu:665-669), folded into one fma:
                         // behind_k = alpha_k c_k + (1 - alpha_k) behind_{k+1} = behind_{k+1} + alpha_k (c_k - behind_{k+1})
@@ -206,7 +212,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                         // the normal channels are blended like three more colour channels: they share S
                         if (GEO) cg += q3.x * g_n[q][0] + q3.y * g_n[q][1] + q3.z * g_n[q][2];
                         float dL_dalpha = cg - S[q];
-                        S[q] = fmaf(alpha, dL_dalpha, S[q]);
+                        S[q] = fmaf(alpha_s, dL_dalpha, S[q]);
                         v[8] += w * g_pix[q][0]; v[9] += w * g_pix[q][1]; v[10] += w * g_pix[q][2];
                         if (GEO) {
                             float gm0 = w * g_n[q][0], gm1 = w * g_n[q][1], gm2 = w * g_n[q][2], gm4 = 0.f;
@@ -278,7 +284,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                             v[11] += gm0; v[12] += gm1; v[13] += gm2; v[14] += gm4;
                         }
                         dL_dalpha = dL_dalpha * T[q] + Tfbg[q] * rinv;
-                        const float qq = oG * dL_dalpha;             // dL/dG * G
+                        const float qq = oGs * dL_dalpha;             // dL/dG * G
                         const float qdx = qq * dx, qdy = qq * dy;
                         v[0] += qdx; v[1] += qdy;
                         v[2] += fabsf(qq * lx); v[3] += fabsf(qq * ly);
@@ -290,7 +296,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
                 float tot;
                 if constexpr (GEO) tot = wave_transpose_reduce16(v, lane); else tot = wave_transpose_reduce12(v, lane);
-                const uint32_t id = s_id[j];
+                const uint32_t id = __float_as_uint(q0.w);
                 if (col >= 0) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
             }
         }
