@@ -44,6 +44,7 @@ class ForwardArgs(ctypes.Structure):
         ("out_color", c_float_p), ("radii", ctypes.c_void_p), ("out_normal", c_float_p), ("out_depth", c_float_p),
         ("out_cam_feat", c_float_p), ("out_warped", c_float_p), ("out_min_depth_diff", c_float_p),
         ("out_camera_ray", c_float_p), ("out_mask", ctypes.c_void_p),
+        ("rendered_hint", ctypes.c_int64),
     ]
 
 

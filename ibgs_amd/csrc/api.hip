@@ -76,9 +76,12 @@ BinState BinState::carve(char* base, size_t R, int W, int H, size_t* total)
     (void)W; (void)H;
     Carver c(base);
     BinState b;
-    b.keys[0] = c.take<uint32_t>(R); b.keys[1] = c.take<uint32_t>(R);
-    b.vals[0] = c.take<uint32_t>(R); b.vals[1] = c.take<uint32_t>(R);
+    // The sorted Gaussian ids come first: their offset does not depend on R, so ibgs_backward finds them
+    // whether the forward carved the arena for the exact R or for a larger rendered_hint.
+    b.vals[0] = c.take<uint32_t>(R);
     b.point_list = b.vals[0];            // the tile sort leaves its result in buffer 0
+    b.keys[0] = c.take<uint32_t>(R); b.keys[1] = c.take<uint32_t>(R);
+    b.vals[1] = c.take<uint32_t>(R);
     b.hist_elems = radix_hist_elems(R);
     b.hist = c.take<uint32_t>(b.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -176,6 +179,20 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
 }
 #undef OFF
 
+// Pinned host word + event for the R read-back, one per calling thread (created on first use, never freed).
+struct RSlot { uint32_t* host; hipEvent_t ev; };
+static RSlot* rslot()
+{
+    static thread_local RSlot slot = {nullptr, nullptr};
+    if (!slot.host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
+        if (hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
+        slot.host = static_cast<uint32_t*>(p);
+    }
+    return &slot;
+}
+
 int64_t ibgs_forward(const ibgs_forward_args* ap)
 {
     if (!ap) { set_error("null args"); return -IBGS_ERR_INVALID; }
@@ -224,32 +241,61 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     { StageTimer t(s, IBGS_STAGE_SCAN);
       if ((rc = launch_gather_tiles(s, a.P, g))) return rc;
       if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)a.P, g.hist, g.hist_elems, true))) return rc; }
-    uint32_t R32 = 0;
-    IBGS_HIP(hipMemcpyAsync(&R32, g.offsets + a.P, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    IBGS_HIP(hipStreamSynchronize(s));
-    const int64_t R = (int64_t)R32;
+    // R = total number of (Gaussian, tile) pairs, known only on the device at this point.  It travels to the host
+    // through a pinned word + event.  Without a hint the host waits for it here (the binning arena is sized from
+    // it); with args->rendered_hint the remaining stages are enqueued first, sized for the hint and reading the real
+    // count from device memory, and the host waits only afterwards -- the GPU never idles on the round trip.
+    RSlot* rs = rslot();
+    if (!rs) return -IBGS_ERR_HIP;
+    const uint32_t* R_dev = g.offsets + a.P;
+    IBGS_HIP(hipMemcpyAsync(rs->host, R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    IBGS_HIP(hipEventRecord(rs->ev, s));
+    const bool deferred = a.rendered_hint > 0 && !debug;
+    int64_t R = 0, cap = 0;
+    if (deferred) cap = a.rendered_hint < (int64_t)0xFFFF0000ll ? a.rendered_hint : (int64_t)0xFFFF0000ll;
+    else { IBGS_HIP(hipEventSynchronize(rs->ev)); R = (int64_t)*rs->host; cap = R; }
 
-    char* bin_mem = a.binning_alloc(ibgs_required_binning(R, a.W, a.H), a.binning_user);
-    if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)R); return -IBGS_ERR_ALLOC; }
-    BinState b = BinState::carve(bin_mem, (size_t)R, a.W, a.H, nullptr);
-
-    { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, a.P, R, gx, g, b))) return rc; }
-    if ((rc = stage_check(s, debug, "emit"))) return rc;
     const int bit = (int)higher_msb((uint32_t)(gx * gy));
-    { StageTimer t(s, IBGS_STAGE_TILE_SORT);
-      if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)R, bit, b.hist, b.hist_elems))) return rc; }
-    if ((rc = stage_check(s, debug, "tile sort"))) return rc;
-    { StageTimer t(s, IBGS_STAGE_RANGES); if ((rc = launch_ranges(s, R, gx * gy, b.keys[0], im.ranges))) return rc; }
-    if ((rc = stage_check(s, debug, "ranges"))) return rc;
-
-    const float4* rgba = nullptr;
-    if (a.render_geo) {
-        float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
-        if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
-        rgba = t;
+    auto tail = [&](int64_t n, const uint32_t* n_dev) -> int {
+        int rc;
+        char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, a.H), a.binning_user);
+        if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
+        BinState b = BinState::carve(bin_mem, (size_t)n, a.W, a.H, nullptr);
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, a.P, n, gx, g, b, n_dev))) return rc; }
+        if ((rc = stage_check(s, debug, "emit"))) return rc;
+        { StageTimer t(s, IBGS_STAGE_TILE_SORT);
+          if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)n, bit, b.hist, b.hist_elems, n_dev))) return rc; }
+        if ((rc = stage_check(s, debug, "tile sort"))) return rc;
+        { StageTimer t(s, IBGS_STAGE_RANGES); if ((rc = launch_ranges(s, n, gx * gy, b.keys[0], im.ranges, n_dev))) return rc; }
+        if ((rc = stage_check(s, debug, "ranges"))) return rc;
+        const float4* rgba = nullptr;
+        if (a.render_geo) {
+            float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
+            if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
+            rgba = t;
+        }
+        { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }
+        return stage_check(s, debug, "render");
+    };
+    if ((rc = tail(cap, deferred ? R_dev : nullptr))) return rc;
+    if (deferred) {
+        IBGS_HIP(hipEventSynchronize(rs->ev));
+        R = (int64_t)*rs->host;
+        if (R > cap) {
+            // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be
+            // released by the second callback), restore the caller-zeroed geo planes and redo binning + render
+            // with the exact size.  Same results as without a hint, one wasted pass.
+            IBGS_HIP(hipStreamSynchronize(s));
+            if (a.render_geo) {
+                const size_t hw = (size_t)a.W * a.H * sizeof(float);
+                IBGS_HIP(hipMemsetAsync(a.out_normal, 0, 3 * hw, s)); IBGS_HIP(hipMemsetAsync(a.out_depth, 0, hw, s));
+                IBGS_HIP(hipMemsetAsync(a.out_cam_feat, 0, 4 * IBGS_MAX_SRC * hw, s)); IBGS_HIP(hipMemsetAsync(a.out_warped, 0, 3 * IBGS_MAX_SRC * hw, s));
+                IBGS_HIP(hipMemsetAsync(a.out_min_depth_diff, 0, hw, s)); IBGS_HIP(hipMemsetAsync(a.out_camera_ray, 0, 3 * hw, s));
+                IBGS_HIP(hipMemsetAsync(a.out_mask, 0, hw, s));
+            }
+            if ((rc = tail(R, nullptr))) return rc;
+        }
     }
-    { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }
-    if ((rc = stage_check(s, debug, "render"))) return rc;
     return R;
 }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t wave_search_le(const uint32_t* __restrict__ 
     return lo;
 }
 
-__global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R, int gx,
+__global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R, const uint32_t* __restrict__ R_dev, int gx,
                                                           const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ offs /* P+1 */,
                                                           const uint32_t* __restrict__ rect,
@@ -60,7 +60,9 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
 {
     __shared__ uint32_t win[EM_CHUNK + 2];
     __shared__ uint32_t jrange[2];
+    if (R_dev) R = min(R, *R_dev);          // launch sized for an upper bound, real count on the device (api.hip)
     const uint32_t s0 = blockIdx.x * (uint32_t)EM_CHUNK;
+    if (s0 >= R) return;
     const uint32_t s1 = min(R, s0 + (uint32_t)EM_CHUNK);   // exclusive
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {
@@ -112,19 +114,20 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
     }
 }
 
-int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b)
+int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b, const uint32_t* R_dev)
 {
     if (R <= 0) return 0;
     const unsigned nblocks = (unsigned)((R + EM_CHUNK - 1) / EM_CHUNK);
-    hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(EM_THREADS), 0, s, (uint32_t)P, (uint32_t)R, gx,
+    hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(EM_THREADS), 0, s, (uint32_t)P, (uint32_t)R, R_dev, gx,
                        g.sort_val[0], g.offsets, g.rect, g.tmask, b.keys[0], b.vals[0]);
     IBGS_HIP(hipGetLastError());
     return 0;
 }
 
 // identifyTileRanges, rasterizer_impl.cu:233-255 (ranges pre-zeroed by the caller)
-__global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t* __restrict__ keys, uint32_t* __restrict__ ranges)
+__global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t* __restrict__ R_dev, const uint32_t* __restrict__ keys, uint32_t* __restrict__ ranges)
 {
+    if (R_dev) R = min(R, *R_dev);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const uint32_t cur = keys[i];
@@ -136,11 +139,11 @@ __global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t*
     if (i == R - 1) ranges[2 * cur + 1] = R;
 }
 
-int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges)
+int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev)
 {
     IBGS_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles, s));
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, sorted_keys, ranges);
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, R_dev, sorted_keys, ranges);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

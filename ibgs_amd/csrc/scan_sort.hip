@@ -127,10 +127,13 @@ int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t 
 // ------------------------------------------------------------------------------------------------
 // radix pass
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift, int nbins,
-                                                                uint32_t* __restrict__ hist, unsigned nblocks)
+// `n_dev` (may be NULL): the element count lives in device memory (written by an earlier kernel of the same stream);
+// the launch is then sized for the upper bound `n` and workgroups past the real count find nothing to do.
+__global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev,
+                                                                int shift, int nbins, uint32_t* __restrict__ hist, unsigned nblocks)
 {
     __shared__ uint32_t h[RS_MAX_BINS];
+    if (n_dev) n = min(n, (size_t)*n_dev);
     for (int k = threadIdx.x; k < nbins; k += RS_THREADS) h[k] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * RS_CHUNK;
@@ -149,10 +152,12 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* 
 // 64-element steps, so (earlier wave, earlier step, lower lane) == earlier input position.
 __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                   size_t n, int shift, int nbits, int nbins,
+                                                                   size_t n, const uint32_t* __restrict__ n_dev, int shift, int nbits, int nbins,
                                                                    const uint32_t* __restrict__ hist_scanned, unsigned nblocks)
 {
     __shared__ uint32_t wcnt[4][RS_MAX_BINS];
+    if (n_dev) n = min(n, (size_t)*n_dev);
+    if ((size_t)blockIdx.x * RS_CHUNK >= n) return;        // whole workgroup past the end (device-side count)
     __shared__ uint32_t dstart[RS_MAX_BINS];
     __shared__ uint32_t delta[RS_MAX_BINS];
     __shared__ uint32_t lds_wave[4];
@@ -435,14 +440,14 @@ size_t radix_hist_elems(size_t n)
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems)
+                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int npass = (nbits_total + 7) / 8;
     const int dbits = (nbits_total + npass - 1) / npass;
     const int nbins = 1 << dbits;
-    if (g_use_onesweep && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
+    if (g_use_onesweep && !n_dev && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
         return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
@@ -451,12 +456,12 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
         const int shift = pass * dbits;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, shift, nbins, hist, nblocks);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, n_dev, shift, nbins, hist, nblocks);
         IBGS_HIP(hipGetLastError());
         int rc = exclusive_scan_u32(s, hist, hist, hist_n, scan_scratch, scan_elems, false);
         if (rc) return rc;
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
-                           n, shift, dbits, nbins, hist, nblocks);
+                           n, n_dev, shift, dbits, nbins, hist, nblocks);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }

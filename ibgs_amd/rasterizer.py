@@ -52,6 +52,13 @@ class capture_sh_factors:
         return False
 
 
+# R (the number of (Gaussian, tile) pairs) of the previous forward with the same (device, P, W, H, mode): the next call
+# passes 1.25 x that as ibgs_forward_args.rendered_hint so that the host does not stall the GPU while R travels back
+# (include/ibgs_rast.h).  RENDERED_HINT = False restores the reference's synchronous sizing.
+RENDERED_HINT = True
+_last_rendered = {}
+LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent forward carved its binning arena for
+
 _tex_scratch = {}
 _gacc_scratch = {}   # (device index, P) -> [zeroed P x 16 tensor, dirty flag]; ibgs_backward re-zeroes what it consumed
 
@@ -215,12 +222,20 @@ class _CModule:
                     a.out_mask = out_mask.data_ptr()
                 elif render_depth_only:
                     a.out_depth = out_depth.data_ptr()
+                hkey = (device.index, P, W, H, render_geo, render_depth_only)
+                prev = _last_rendered.get(hkey, 0) if (RENDERED_HINT and not debug) else 0
+                a.rendered_hint = (prev + prev // 4 + 4096) if prev > 0 else 0
                 rc = lib.ibgs_forward(ctypes.byref(a))
                 if rc < 0:
                     if "err" in holder:
                         raise holder["err"]
                     raise RuntimeError("ibgs_forward failed (%d): %s" % (rc, _lib.last_error()))
                 rendered = int(rc)
+                if len(_last_rendered) > 64:
+                    _last_rendered.clear()
+                _last_rendered[hkey] = rendered
+                global LAST_BINNING_CAPACITY
+                LAST_BINNING_CAPACITY = max(rendered, int(a.rendered_hint)) if a.rendered_hint else rendered
                 binningBuffer = holder.get("t", binningBuffer)
         return (rendered, out_color, radii, out_normal, out_depth, out_cam_feat, out_warped, out_min_depth_diff,
                 out_camera_ray, out_mask, geomBuffer, binningBuffer, imgBuffer)

@@ -101,7 +101,7 @@ typedef struct ibgs_forward_args {
     /* scratch arenas */
     char* geom;  size_t geom_bytes;    /* >= ibgs_required_geom(P) */
     char* img;   size_t img_bytes;     /* >= ibgs_required_img(W, H) */
-    ibgs_alloc_fn binning_alloc;       /* called once with ibgs_required_binning(R, W, H) */
+    ibgs_alloc_fn binning_alloc;       /* called with ibgs_required_binning(R, W, H) (or of rendered_hint, see below) */
     void* binning_user;
     char* tex;   size_t tex_bytes;     /* render_geo only: >= ibgs_required_tex(n_src, W, H); contents are
                                           transient (packed RGBA source images), may be shared between calls */
@@ -116,6 +116,16 @@ typedef struct ibgs_forward_args {
     float* out_min_depth_diff; /* 1 x H x W   (render_geo) */
     float* out_camera_ray;     /* 3 x H x W   (render_geo) */
     int32_t* out_mask;         /* 1 x H x W   (render_geo) */
+    /* Optional upper-bound guess for the return value R (e.g. 1.25 x the R of the previous call with this
+     * camera/scene), 0 = none.  R is produced on the device; the reference (rasterizer_impl.cu:404-410) and this
+     * library without a hint stop the host until it has been copied back, because the binning arena is sized from
+     * it.  With a hint, binning_alloc is called for the hint right away, binning and rendering are enqueued sized
+     * for it (they read the true count from device memory), and only then does the call wait for R, so the GPU does
+     * not idle during the round trip.  Results are identical.  If the true R exceeds the hint the call drains the
+     * stream, calls binning_alloc again with the exact size and repeats binning + rendering.  Ignored when
+     * IBGS_FLAG_DEBUG is set.  ibgs_backward needs nothing extra: it locates the sorted list independently of
+     * the size the arena was carved for. */
+    int64_t rendered_hint;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {

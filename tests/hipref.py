@@ -95,7 +95,17 @@ def internal_state(outs, inp):
     Rr = int(st["offsets"][P])
     st["R"] = Rr
     if Rr > 0:
-        bo = lambda n: lib.ibgs_binning_offset(Rr, W, H, n.encode())
+        # the arena may have been carved for a rendered_hint >= R (include/ibgs_rast.h): recover that size from its length
+        lo, hi = Rr, 2 * Rr + (1 << 20)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if lib.ibgs_required_binning(mid, W, H) >= bb.size:
+                hi = mid
+            else:
+                lo = mid + 1
+        assert lib.ibgs_required_binning(lo, W, H) == bb.size, "binning arena size matches no capacity"
+        st["binning_capacity"] = lo
+        bo = lambda n: lib.ibgs_binning_offset(lo, W, H, n.encode())
         st["point_list"] = view(bb, bo("point_list"), np.uint32, Rr)
         st["sorted_tile_keys"] = view(bb, bo("sorted_tile_keys"), np.uint32, Rr)
     else:

@@ -1,0 +1,67 @@
+"""ibgs_forward_args.rendered_hint (deferred R read-back, include/ibgs_rast.h): whatever the hint -- absent,
+generous, far too small -- the forward returns the same R, the same sorted lists and bit-identical images, and
+the backward works from an arena carved for a capacity other than R."""
+import numpy as np
+import pytest
+import torch
+
+from ibgs_amd import rasterizer, synthetic as syn
+from tests import hipref
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(inp, hint_state, geo=False):
+    """hint_state: None = synchronous sizing, int = pretend the previous call returned that R."""
+    key_geo = bool(inp.get("render_geo", False))
+    rasterizer._last_rendered.clear()
+    old = rasterizer.RENDERED_HINT
+    rasterizer.RENDERED_HINT = hint_state is not None
+    if hint_state is not None:
+        P, W, H = inp["means3D"].shape[0], int(inp["W"]), int(inp["H"])
+        rasterizer._last_rendered[(torch.cuda.current_device(), P, W, H, key_geo, bool(inp.get("render_depth_only", False)))] = hint_state
+    try:
+        outs, lv, _ = hipref.run_forward(inp)
+        ist = hipref.internal_state(outs, inp)
+    finally:
+        rasterizer.RENDERED_HINT = old
+    return outs, lv, ist
+
+
+@pytest.mark.parametrize("cfg", ["colour", "geo"])
+def test_results_do_not_depend_on_the_hint(cfg):
+    if cfg == "colour":
+        inp = syn.make_scene(20000, 320, 240, sh_degree=3, seed=4, opacity="trained")
+    else:
+        from tests.test_gpu_parity import add_sources, scene
+        inp = add_sources(scene(P=4000, W=192, H=128, deg=2, seed=26, opacity="trained", planes=True, scale_mul=1.5), n_src=3, L=4)
+    base_o, base_l, base = _run(inp, None)
+    R = base["R"]
+    assert base["binning_capacity"] // 32 == R // 32          # synchronous sizing: carved for R itself
+    g = torch.randn_like(base_o["color"])
+    (base_o["color"] * g).sum().backward()
+    for prev in (R, 3 * R, max(R // 10, 1), 1):
+        o, l, st = _run(inp, prev)
+        hint = prev + prev // 4 + 4096
+        assert st["R"] == R and int(o["color"].grad_fn.num_rendered) == R
+        assert st["binning_capacity"] // 32 == max(hint, R) // 32 if hint >= R else st["binning_capacity"] // 32 == R // 32
+        assert np.array_equal(st["point_list"], base["point_list"]) and np.array_equal(st["ranges"], base["ranges"])
+        for k in ("color", "median_depth", "normal_map", "warped_image", "cam_feat", "use_first_src_frame_mask"):
+            assert torch.equal(o[k], base_o[k]), (k, prev)
+        (o["color"] * g).sum().backward()
+        for k in ("means3D", "opacities", "scales"):
+            a, b = l[k].grad, base_l[k].grad
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max()) + 1e-12), (k, prev)
+
+
+def test_hint_follows_the_previous_call():
+    inp = syn.make_scene(5000, 160, 120, sh_degree=1, seed=2)
+    rasterizer._last_rendered.clear()
+    o1, _, _ = hipref.run_forward(inp, requires_grad=False)
+    assert rasterizer.LAST_BINNING_CAPACITY == rasterizer._last_rendered[next(iter(rasterizer._last_rendered))]
+    R = rasterizer.LAST_BINNING_CAPACITY
+    o2, _, _ = hipref.run_forward(inp, requires_grad=False)
+    assert rasterizer.LAST_BINNING_CAPACITY == R + R // 4 + 4096 and torch.equal(o1["color"], o2["color"])
+    # debug mode keeps the reference's stage-by-stage synchronous behaviour
+    o3, _, _ = hipref.run_forward(inp, debug=True, requires_grad=False)
+    assert rasterizer.LAST_BINNING_CAPACITY == R and torch.equal(o1["color"], o3["color"])
