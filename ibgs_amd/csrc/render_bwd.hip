@@ -25,6 +25,7 @@
 // (the reference uses __expf forward / exp backward) so that T/(1-alpha) retraces the
 // forward transmittance; 1/(1-alpha) is a hardware reciprocal refined by one Newton step instead of an
 // IEEE division.
+#include <cstdlib>
 #include "common.h"
 #include "wave_reduce.h"
 
@@ -88,7 +89,13 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
     constexpr int NQ = GEO ? 4 : 3;
     constexpr bool SEL = !GEO;            // branch-free blend step (see the active block)
     constexpr int NV = GEO ? 16 : 12;     // per-lane partial sums handed to the transpose-reduce
-    __shared__ float4 s_rec[NQ][WAVE];
+    // Colour variant: 8 waves per SIMD (<= 64 VGPRs, <= 5 KB LDS per wave) keep all tiles of a 1080p frame resident
+    // at once -- no second, half-empty round of workgroups.  To get there the per-pixel loss gradient lives in a
+    // per-lane LDS slot instead of 12 registers and records are staged 32 at a time.
+    constexpr int CHUNK = GEO ? WAVE : 32;
+    constexpr bool GLDS = !GEO;
+    __shared__ float4 s_rec[NQ][CHUNK];
+    __shared__ float s_gpix[GLDS ? PPL : 1][GLDS ? WAVE : 1][3];
 
     const int lane = threadIdx.x;
     // the lane that ends up with the wave total of grad_acc column `col` after the reduce (-1: none)
@@ -104,11 +111,11 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
     const size_t HW = (size_t)W * H;
     const float fx = p.cam.fx, fy = p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
-    const float LOG2E = 1.4426950408889634f;
+    const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E, the forward's constant
 
     float pxf[PPL], pyf[PPL];
     size_t pixid[PPL];
-    float T[PPL], Tfbg[PPL], S[PPL], g_pix[PPL][3];
+    float T[PPL], Tfbg[PPL], S[PPL], g_pix[GLDS ? 1 : PPL][3];
     uint32_t ncontrib[PPL];
     // geo
     float g_n[PPL][3], g_d[PPL], rayx[PPL], rayy[PPL];
@@ -130,8 +137,9 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
         float bg_dot = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            g_pix[q][ch] = (inside && p.dL_dcolor) ? p.dL_dcolor[ch * HW + pixid[q]] : 0.f;
-            bg_dot += p.cam.bg[ch] * g_pix[q][ch];
+            const float gp = (inside && p.dL_dcolor) ? p.dL_dcolor[ch * HW + pixid[q]] : 0.f;
+            if (GLDS) s_gpix[q][lane][ch] = gp; else g_pix[q][ch] = gp;
+            bg_dot += p.cam.bg[ch] * gp;
         }
         Tfbg[q] = -T_final * bg_dot;
         if (GEO) {
@@ -151,7 +159,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
     int top = min((int)nmax, n);           // entries >= top contribute to no pixel of this wave
 
     while (top > 0) {
-        const int count = min(WAVE, top);
+        const int count = min(CHUNK, top);
         if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
             const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
             const float4* r = p.rec + (size_t)id * 4;
@@ -186,21 +194,23 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                const float power = -0.5f * p2q[q];
-                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                // power > 0 <=> p2 < 0;  min(0.99, oG) < 1/255 <=> oG < 1/255: same decisions as the forward, fewer instructions
+                const float G = __builtin_amdgcn_exp2f(p2q[q] * NHL2E);
                 const float oG = op * G;
-                const float alpha = fminf(0.99f, oG);
-                const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
-                                     __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+                const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(!(p2q[q] < 0.0f)) &
+                                     __builtin_amdgcn_ballot_w64(!(oG < 1.0f / 255.0f));
                 if (okm != 0ull) {
                     any = true;
+                    const float alpha = min_099(oG);
                     // Colour variant: no per-lane branch.  Lanes that fail the test run the same instructions with
                     // alpha = o G = 0, which leaves T and S unchanged (1/(1-0) = 1 exactly) and adds zeros.
                     const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
-                    const float oGs = (SEL && !ok) ? 0.f : oG;
-                    const float alpha_s = (SEL && !ok) ? 0.f : alpha;
+                    const float oGs = SEL ? select_or_zero(okm, oG) : oG;
+                    const float alpha_s = SEL ? select_or_zero(okm, alpha) : alpha;
                     if (SEL || ok) {
-                        const float dx = q0.x - pxf[q], dy = q0.y - pyf[q];          // only the moments need d and conic*d per quadrant
+                        // only the moments need d and conic*d per quadrant; the lane's other pixels sit 8 px right / down
+                        const float dx = (PPL == 4) ? dx0 - ((q & 1) ? 8.0f : 0.0f) : q0.x - pxf[q];
+                        const float dy = (PPL == 4) ? dy0 - ((q >> 1) ? 8.0f : 0.0f) : q0.y - pyf[q];
                         const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
                         const float rinv = fast_rcp(1.f - alpha_s);
                         T[q] = T[q] * rinv;
@@ -208,12 +218,15 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                         // S = (colour behind this Gaussian) . (pixel gradient): scalar form of the reference's per-channel
                         // accum_rec / last_color / last_alpha recurrence (backward.cu:665-669), folded into one fma:
                         // behind_k = alpha_k c_k + (1 - alpha_k) behind_{k+1} = behind_{k+1} + alpha_k (c_k - behind_{k+1})
-                        float cg = q2.x * g_pix[q][0] + q2.y * g_pix[q][1] + q2.z * g_pix[q][2];
+                        float gp0, gp1, gp2;
+                        if (GLDS) { gp0 = s_gpix[q][lane][0]; gp1 = s_gpix[q][lane][1]; gp2 = s_gpix[q][lane][2]; }
+                        else { gp0 = g_pix[q][0]; gp1 = g_pix[q][1]; gp2 = g_pix[q][2]; }
+                        float cg = q2.x * gp0 + q2.y * gp1 + q2.z * gp2;
                         // the normal channels are blended like three more colour channels: they share S
                         if (GEO) cg += q3.x * g_n[q][0] + q3.y * g_n[q][1] + q3.z * g_n[q][2];
                         float dL_dalpha = cg - S[q];
                         S[q] = fmaf(alpha_s, dL_dalpha, S[q]);
-                        v[8] += w * g_pix[q][0]; v[9] += w * g_pix[q][1]; v[10] += w * g_pix[q][2];
+                        v[8] += w * gp0; v[9] += w * gp1; v[10] += w * gp2;
                         if (GEO) {
                             float gm0 = w * g_n[q][0], gm1 = w * g_n[q][1], gm2 = w * g_n[q][2], gm4 = 0.f;
                             // unsigned comparison: min_med == 0 disables the branch
@@ -307,7 +320,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 
 // Two entry points so that each variant gets its own register budget: the colour kernel fits 5 waves per
 // SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
-__global__ void __launch_bounds__(64, 5) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
+__global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
 __global__ void __launch_bounds__(64) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
 
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
@@ -330,7 +343,8 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         hipLaunchKernelGGL(render_bwd_geo_kernel, dim3(grid), dim3(64), 0, s, p);
     } else {
         const int grid = ((nt + 7) / 8) * 8;
-        hipLaunchKernelGGL(render_bwd_color_kernel, dim3(grid), dim3(64), 0, s, p);
+        static const int pad = getenv("IBGS_BWD_LDS_PAD") ? atoi(getenv("IBGS_BWD_LDS_PAD")) : 0;   // occupancy experiments only
+        hipLaunchKernelGGL(render_bwd_color_kernel, dim3(grid), dim3(64), pad, s, p);
     }
     IBGS_HIP(hipGetLastError());
     return 0;

@@ -8,6 +8,26 @@ namespace ibgs {
 #define IBGS_DPP(old, src, ctrl, bank) \
     __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (old)), __builtin_bit_cast(int, (src)), (ctrl), 0xF, (bank), false))
 
+// Per-lane select on a wave-uniform lane mask held in an SGPR pair: x in the lanes whose bit is set, 0 elsewhere.
+// Written as asm because hipcc routes such masks through VCC and emits the VOP2 form `v_cndmask_b32 v, 0, v, vcc`,
+// which issues at ~23 cycles per wave on gfx950 against ~4 for the VOP3 form with an SGPR pair
+// (tests/csrc/probe_valu_rate.hip).
+__device__ __forceinline__ float select_or_zero(unsigned long long mask, float x)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+
+// min(0.99, x) as one instruction: across a basic-block boundary hipcc puts a canonicalising v_max_f32 x, x in front
+// of fminf (MI355X_MICROARCH.md, "canonicalising v_max").  NaN in -> 0.99 out, like fminf.
+__device__ __forceinline__ float min_099(float x)
+{
+    float r;
+    asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // v_permlane32_swap: lanes [32,63] of `a` <-> lanes [0,31] of `b`; v_permlane16_swap: odd 16-lane rows of
 // `a` <-> even rows of `b` (lane maps verified on hardware by tests/csrc/probe_dpp.hip).  Inline asm because
 // hipcc (ROCm 7.2) mis-assigns the second result of __builtin_amdgcn_permlane{16,32}_swap (it emitted
