@@ -283,16 +283,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         R = (int64_t)*rs->host;
         if (R > cap) {
             // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be
-            // released by the second callback), restore the caller-zeroed geo planes and redo binning + render
-            // with the exact size.  Same results as without a hint, one wasted pass.
+            // released by the second callback) and redo binning + render with the exact size (every output
+            // element is rewritten).  Same results as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
-            if (a.render_geo) {
-                const size_t hw = (size_t)a.W * a.H * sizeof(float);
-                IBGS_HIP(hipMemsetAsync(a.out_normal, 0, 3 * hw, s)); IBGS_HIP(hipMemsetAsync(a.out_depth, 0, hw, s));
-                IBGS_HIP(hipMemsetAsync(a.out_cam_feat, 0, 4 * IBGS_MAX_SRC * hw, s)); IBGS_HIP(hipMemsetAsync(a.out_warped, 0, 3 * IBGS_MAX_SRC * hw, s));
-                IBGS_HIP(hipMemsetAsync(a.out_min_depth_diff, 0, hw, s)); IBGS_HIP(hipMemsetAsync(a.out_camera_ray, 0, 3 * hw, s));
-                IBGS_HIP(hipMemsetAsync(a.out_mask, 0, hw, s));
-            }
             if ((rc = tail(R, nullptr))) return rc;
         }
     }

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             rd0 /= rl; rd1 /= rl; rd2 /= rl;
             p.out_camera_ray[pix] = rd0; p.out_camera_ray[HW + pix] = rd1; p.out_camera_ray[2 * HW + pix] = rd2;
 
-            int nvalid = 0; float min_err = 1.0f;
+            int nvalid = 0, first_ok = 0; float min_err = 1.0f;
 #pragma unroll
             for (int si = 0; si < IBGS_MAX_SRC; si++) {
                 if (si < p.n_src && nvalid < IBGS_MAX_SRC) {
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                         const float sl = sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + eps;
                         s0 /= sl; s1 /= sl; s2 /= sl;
                         p.out_cam_feat[((size_t)nvalid * 4 + 3) * HW + pix] = s0 * rd0 + s1 * rd1 + s2 * rd2;
-                        if (si == 0) p.out_mask[pix] = 1;
+                        if (si == 0) first_ok = 1;
                         p.valid_idx[(size_t)nvalid * HW + pix] = si;
                         p.valid_w[(size_t)nvalid * HW + pix] = tw_src[si];
                         nvalid++;
@@ -375,6 +375,15 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 }
             }
             if (nvalid <= IBGS_MAX_SRC - 1) p.valid_idx[(size_t)nvalid * HW + pix] = -1;
+            // unused source slots and the mask are written too, so the caller needs no 36-plane memset per frame
+            // (the reference zero-fills every output plane on each call, rasterize_points.cu:80-90)
+            for (int k = nvalid; k < IBGS_MAX_SRC; k++) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++) p.out_cam_feat[((size_t)k * 4 + ch) * HW + pix] = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) p.out_warped[((size_t)k * 3 + ch) * HW + pix] = 0.f;
+            }
+            p.out_mask[pix] = first_ok;
             p.out_min_depth_diff[pix] = min_err;
             p.out_depth[pix] = med;
             p.out_normal[pix] = Nacc[q][0]; p.out_normal[HW + pix] = Nacc[q][1]; p.out_normal[2 * HW + pix] = Nacc[q][2];

@@ -106,10 +106,24 @@ def _gacc(device, P):
     return ent
 
 
+_zero_scalar = {}
+
+
+def _zeros_view(shape, device, dtype=torch.float32):
+    """Zeros of the given shape as a zero-stride view of ONE cached element per (device, dtype): no allocation,
+    no fill kernel.  Read-only by construction (PyTorch refuses in-place writes through overlapping views)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), dtype)
+    z = _zero_scalar.get(key)
+    if z is None:
+        z = torch.zeros(1, dtype=dtype, device=device)
+        _zero_scalar[key] = z
+    return z.expand(*shape)
+
+
 def _zero_plane(c, H, W, device, dtype=torch.float32):
     """Outputs that the selected mode never writes: zeros of the reference's shape without the
     reference's per-call memset (rasterize_points.cu:80-90 fills 47 planes every forward)."""
-    return torch.zeros(1, dtype=dtype, device=device).expand(c, H, W)
+    return _zeros_view((c, H, W), device, dtype)
 
 
 class _CModule:
@@ -150,13 +164,15 @@ class _CModule:
             else:
                 out_color = _zero_plane(NUM_CHANNELS, H, W, device)
             if render_geo:
-                out_normal = torch.zeros(NUM_NORMAL_CHANNELS, H, W, device=device)
-                out_depth = torch.zeros(1, H, W, device=device)
-                out_cam_feat = torch.zeros(4 * M_SRC, H, W, device=device)
-                out_warped = torch.zeros(3 * M_SRC, H, W, device=device)
-                out_min_depth_diff = torch.zeros(1, H, W, device=device)
-                out_camera_ray = torch.zeros(3, H, W, device=device)
-                out_mask = torch.zeros(1, H, W, dtype=torch.int32, device=device)
+                # every element of the geo planes is written by the render kernel (unused source slots as zeros)
+                mk = (lambda *shp, **kw: torch.empty(*shp, device=device, **kw)) if P != 0 else (lambda *shp, **kw: torch.zeros(*shp, device=device, **kw))
+                out_normal = mk(NUM_NORMAL_CHANNELS, H, W)
+                out_depth = mk(1, H, W)
+                out_cam_feat = mk(4 * M_SRC, H, W)
+                out_warped = mk(3 * M_SRC, H, W)
+                out_min_depth_diff = mk(1, H, W)
+                out_camera_ray = mk(3, H, W)
+                out_mask = mk(1, H, W, dtype=torch.int32)
             else:
                 out_normal = _zero_plane(NUM_NORMAL_CHANNELS, H, W, device)
                 if render_depth_only:
@@ -263,12 +279,13 @@ class _CModule:
             new = torch.empty if P != 0 else torch.zeros
             dL_dmeans3D = new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
             dL_dmeans2D_abs = new(P, 3, **opts); dL_dcolors = new(P, NUM_CHANNELS, **opts)
-            dL_dall_map = (new if (render_geo and all_maps.numel() != 0) else torch.zeros)(P, NUM_PLANE_PARAMS, **opts)
+            # gradients of inputs the mode does not use: zeros without a fill (the reference memsets them, rasterize_points.cu:196-206)
+            dL_dall_map = new(P, NUM_PLANE_PARAMS, **opts) if (render_geo and all_maps.numel() != 0 and P != 0) else _zeros_view((P, NUM_PLANE_PARAMS), device)
             dL_dopacity = new(P, 1, **opts); dL_dcov3D = new(P, 6, **opts)
             factored = _sh_factor_sink is not None and M != 0 and P != 0
             dL_dsh = None if factored else new(P, M, 3, **opts)
-            dL_dscales = (new if have_sr else torch.zeros)(P, 3, **opts)
-            dL_drotations = (new if have_sr else torch.zeros)(P, 4, **opts)
+            dL_dscales = new(P, 3, **opts) if (have_sr and P != 0) else _zeros_view((P, 3), device)
+            dL_drotations = new(P, 4, **opts) if (have_sr and P != 0) else _zeros_view((P, 4), device)
             if P != 0:
                 means3D_c = _dev_f32(means3D, device); colors_c = _dev_f32(colors, device)
                 scales_c = _dev_f32(scales, device); rot_c = _dev_f32(rotations, device)
@@ -311,8 +328,8 @@ class _CModule:
                 a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr()
                 a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr()
                 a.dL_dsh = dL_dsh.data_ptr() if (M and not factored) else None
-                a.dL_dscale = dL_dscales.data_ptr(); a.dL_drot = dL_drotations.data_ptr()
-                a.dL_dall_map = dL_dall_map.data_ptr()
+                a.dL_dscale = dL_dscales.data_ptr() if have_sr else None; a.dL_drot = dL_drotations.data_ptr() if have_sr else None
+                a.dL_dall_map = dL_dall_map.data_ptr() if (render_geo and all_maps.numel() != 0) else None
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
                            | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0))

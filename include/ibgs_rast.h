@@ -105,8 +105,8 @@ typedef struct ibgs_forward_args {
     void* binning_user;
     char* tex;   size_t tex_bytes;     /* render_geo only: >= ibgs_required_tex(n_src, W, H); contents are
                                           transient (packed RGBA source images), may be shared between calls */
-    /* outputs; planes must arrive zeroed where the mode leaves them untouched.
-     * Pointers the mode does not write may be NULL. */
+    /* outputs: every element of the planes a mode produces is written (unused source slots of out_cam_feat /
+     * out_warped as zeros), nothing needs to arrive zeroed.  Pointers the mode does not write may be NULL. */
     float* out_color;          /* 3 x H x W */
     int32_t* radii;            /* P */
     float* out_normal;         /* 3 x H x W   (render_geo) */
