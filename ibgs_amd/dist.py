@@ -105,8 +105,11 @@ class ViewParallelReducer:
     The result equals the sequential accumulation of the single-view gradients (summation order differs)."""
 
     def __init__(self, params, sh=None, means3D=None, group=None, expand=None):
-        self.sh, self.means3D, self.group = sh, means3D, group
-        self.dense = [p for p in params if p is not sh]
+        # `sh`: the SH tensor handed to the rasterizer, or -- when that is a torch.cat of leaves along dim 1 as in the
+        # reference's GaussianModel.get_features (scene/gaussian_model.py:140-143) -- the list of those leaves
+        self.sh_parts = list(sh) if isinstance(sh, (list, tuple)) else ([sh] if sh is not None else [])
+        self.sh, self.means3D, self.group = (self.sh_parts[0] if self.sh_parts else None), means3D, group
+        self.dense = [p for p in params if not any(p is q for q in self.sh_parts)]
         self.bucket = None
         self.items = None
         self._expand = expand
@@ -143,8 +146,12 @@ class ViewParallelReducer:
         g = expand(self.means3D.detach(), campos, dcolor, degree, M)
         if average:
             g = g / world
-        g = g.view_as(self.sh)
-        self.sh.grad = g if self.sh.grad is None else self.sh.grad + g
+        off = 0
+        for part in self.sh_parts:                      # (P, M_i, 3) slices of the (P, M, 3) result
+            m = part.shape[1]
+            gp = g[:, off:off + m, :].contiguous() if len(self.sh_parts) > 1 else g.view_as(part)
+            part.grad = gp if part.grad is None else part.grad + gp
+            off += m
 
 
 def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None):

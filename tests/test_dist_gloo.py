@@ -84,9 +84,11 @@ def _worker_factored(rank, world, port, out_dir):
     g = torch.Generator().manual_seed(0)
     P, M, deg = 40, 16, 2
     xyz = torch.randn(P, 3, generator=g).requires_grad_(True)
-    shs = torch.randn(P, M, 3, generator=g).requires_grad_(True)
+    # SH split into two leaves like the reference's _features_dc / _features_rest (get_features = cat along dim 1)
+    f_dc = torch.randn(P, 1, 3, generator=g).requires_grad_(True)
+    f_rest = torch.randn(P, M - 1, 3, generator=g).requires_grad_(True)
     opa = torch.rand(P, 1, generator=g).requires_grad_(True)
-    red = vdist.ViewParallelReducer([xyz, shs, opa], sh=shs, means3D=xyz, expand=_expand_ref)
+    red = vdist.ViewParallelReducer([xyz, f_dc, f_rest, opa], sh=[f_dc, f_rest], means3D=xyz, expand=_expand_ref)
     gr = torch.Generator().manual_seed(100 + rank)
     items = []
     with red.capture() as sink:                    # two local views per rank; the HIP backward would fill `sink`
@@ -96,7 +98,7 @@ def _worker_factored(rank, world, port, out_dir):
     xyz.grad = torch.randn(P, 3, generator=gr); opa.grad = torch.randn(P, 1, generator=gr)
     local = {"xyz": xyz.grad.clone(), "opa": opa.grad.clone()}
     red.reduce()
-    torch.save({"items": items, "local": local, "xyz": xyz.grad.clone(), "opa": opa.grad.clone(), "shs": shs.grad.clone(),
+    torch.save({"items": items, "local": local, "xyz": xyz.grad.clone(), "opa": opa.grad.clone(), "shs": torch.cat([f_dc.grad, f_rest.grad], dim=1),
                 "means": xyz.detach().clone()}, os.path.join(out_dir, "f%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
