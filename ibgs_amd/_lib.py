@@ -16,6 +16,7 @@ FLAG_TEX_QUANT = 2
 FLAG_NO_TILE_CULL = 4
 FLAG_CLEAR_GRAD_ACC = 8
 FLAG_SH_FACTORED = 16
+PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 
@@ -45,6 +46,7 @@ class ForwardArgs(ctypes.Structure):
         ("out_cam_feat", c_float_p), ("out_warped", c_float_p), ("out_min_depth_diff", c_float_p),
         ("out_camera_ray", c_float_p), ("out_mask", ctypes.c_void_p),
         ("rendered_hint", ctypes.c_int64),
+        ("plane_normal", c_float_p), ("plane_offset", c_float_p), ("plane_mode", ctypes.c_int32),
     ]
 
 
@@ -71,6 +73,8 @@ class BackwardArgs(ctypes.Structure):
         ("dL_dcolors", c_float_p), ("dL_dmean3D", c_float_p), ("dL_dcov3D", c_float_p), ("dL_dsh", c_float_p),
         ("dL_dscale", c_float_p), ("dL_drot", c_float_p), ("dL_dall_map", c_float_p),
         ("render_geo", ctypes.c_int32), ("flags", ctypes.c_uint32),
+        ("plane_normal", c_float_p), ("plane_offset", c_float_p), ("plane_mode", ctypes.c_int32),
+        ("dL_dplane_normal", c_float_p), ("dL_dplane_offset", c_float_p),
     ]
 
 

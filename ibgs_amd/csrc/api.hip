@@ -212,7 +212,13 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     }
     if (a.shs && (a.D < 0 || a.D > 3 || (a.D + 1) * (a.D + 1) > a.M)) { set_error("bad SH degree D=%d M=%d", a.D, a.M); return -IBGS_ERR_INVALID; }
     if (a.render_geo && a.render_depth_only) { set_error("render_geo together with render_depth_only is not supported"); return -IBGS_ERR_INVALID; }
-    if ((a.render_geo || a.render_depth_only) && !a.all_map) { set_error("all_map is required for render_geo / render_depth_only"); return -IBGS_ERR_INVALID; }
+    if (a.plane_mode != IBGS_PLANE_NONE) {
+        if (a.all_map) { set_error("give either all_map or plane_mode, not both"); return -IBGS_ERR_INVALID; }
+        if (a.plane_mode == IBGS_PLANE_LEARNT ? !a.plane_normal : (a.plane_mode != IBGS_PLANE_SMALLEST_AXIS || !a.scales || !a.rotations)) {
+            set_error("plane_mode %d: plane_normal (learnt) or scales + rotations (smallest axis) required", a.plane_mode); return -IBGS_ERR_INVALID;
+        }
+    }
+    if ((a.render_geo || a.render_depth_only) && !a.all_map && a.plane_mode == IBGS_PLANE_NONE) { set_error("all_map (or plane_mode) is required for render_geo / render_depth_only"); return -IBGS_ERR_INVALID; }
     if (a.render_geo || a.render_depth_only) {
         if (a.buffer_length < 1 || a.buffer_length > IBGS_MAX_BUFFER_LENGTH) { set_error("buffer_length %d outside 1..%d", a.buffer_length, IBGS_MAX_BUFFER_LENGTH); return -IBGS_ERR_INVALID; }
         if (!a.out_depth) { set_error("out_depth required"); return -IBGS_ERR_INVALID; }
@@ -307,7 +313,12 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     if (a.shs && !a.dL_dsh && !(a.flags & IBGS_FLAG_SH_FACTORED)) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
     if (a.scales && (!a.dL_dscale || !a.dL_drot)) { set_error("dL_dscale / dL_drot required"); return -IBGS_ERR_INVALID; }
     if (a.render_geo) {
-        if (!a.all_map || !a.dL_dall_map || !a.out_depth || !a.out_warped || !a.ref_to_src || !a.src_images) { set_error("geo backward inputs missing"); return -IBGS_ERR_INVALID; }
+        if (a.plane_mode == IBGS_PLANE_NONE ? (!a.all_map || !a.dL_dall_map)
+                                            : (a.plane_mode == IBGS_PLANE_LEARNT ? (!a.plane_normal || !a.dL_dplane_normal)
+                                                                                 : (a.plane_mode != IBGS_PLANE_SMALLEST_AXIS || !a.scales || !a.rotations))) {
+            set_error("geo backward: plane inputs / gradient outputs missing"); return -IBGS_ERR_INVALID;
+        }
+        if (!a.out_depth || !a.out_warped || !a.ref_to_src || !a.src_images) { set_error("geo backward inputs missing"); return -IBGS_ERR_INVALID; }
         if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
     }
     int rc;

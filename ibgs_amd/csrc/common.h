@@ -101,6 +101,62 @@ inline Cam make_cam(const float* vm, const float* pm, const float* campos, const
     return c;
 }
 
+
+// ---- fused plane-map glue ------------------------------------------------------------------
+// The reference builds all_map = [n_cam, 1, |d_cam|] with ~10 torch kernels per call (gaussian_renderer/__init__.py:
+// 304-316; scene/gaussian_model.py:156-173).  With plane_mode != 0 the preprocess kernels do it per Gaussian:
+//   mode 1 (learnt normal):  n = raw / |raw|, offset = raw offset            (get_normal)
+//   mode 2 (smallest axis):  n = column argmin(scale) of R(rotation)          (get_normal_w_smallest_axis)
+//   flip n (and the offset) towards the camera; n_cam = n @ V[:3,:3]; d = |-(n . x) + offset - n_cam . V[3,:3]|
+// V = world_view_transform, i.e. the 16 floats of cam.vm read row-major.
+struct PlaneEval {
+    float n[3];        // world normal after the flip
+    float ncam[3];     // camera-frame normal (all_map[0..2])
+    float dist;        // all_map[4]
+    float flip;        // +1 / -1
+    float sgn;         // sign of the signed camera-frame distance (derivative of the abs)
+    float inv_len;     // mode 1: 1 / |raw|
+    int axis;          // mode 2: column index
+};
+
+__device__ __forceinline__ PlaneEval plane_eval(int mode, const float* __restrict__ raw_n, const float* __restrict__ raw_off,
+                                                const float* __restrict__ scales, const float* __restrict__ rot, int i,
+                                                float mx, float my, float mz, const float* __restrict__ campos,
+                                                const float* __restrict__ vm)
+{
+    PlaneEval e;
+    float off = 0.f;
+    e.inv_len = 1.f; e.axis = 0;
+    if (mode == IBGS_PLANE_LEARNT) {
+        const float a = raw_n[3 * i], b = raw_n[3 * i + 1], c = raw_n[3 * i + 2];
+        const float len = sqrtf(a * a + b * b + c * c);
+        e.inv_len = 1.0f / len;
+        e.n[0] = a / len; e.n[1] = b / len; e.n[2] = c / len;
+        off = raw_off ? raw_off[i] : 0.f;
+    } else {
+        const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+        int k = 0; float sm = s0;
+        if (s1 < sm) { sm = s1; k = 1; }
+        if (s2 < sm) { sm = s2; k = 2; }
+        e.axis = k;
+        const float r = rot[4 * i], x = rot[4 * i + 1], y = rot[4 * i + 2], z = rot[4 * i + 3];
+        if (k == 0)      { e.n[0] = 1.f - 2.f * (y * y + z * z); e.n[1] = 2.f * (x * y + r * z);       e.n[2] = 2.f * (x * z - r * y); }
+        else if (k == 1) { e.n[0] = 2.f * (x * y - r * z);       e.n[1] = 1.f - 2.f * (x * x + z * z); e.n[2] = 2.f * (y * z + r * x); }
+        else             { e.n[0] = 2.f * (x * z + r * y);       e.n[1] = 2.f * (y * z - r * x);       e.n[2] = 1.f - 2.f * (x * x + y * y); }
+    }
+    const float tc = e.n[0] * (campos[0] - mx) + e.n[1] * (campos[1] - my) + e.n[2] * (campos[2] - mz);
+    e.flip = (tc < 0.0f) ? -1.f : 1.f;
+    e.n[0] *= e.flip; e.n[1] *= e.flip; e.n[2] *= e.flip; off *= e.flip;
+#pragma unroll
+    for (int j = 0; j < 3; j++) e.ncam[j] = e.n[0] * vm[j] + e.n[1] * vm[4 + j] + e.n[2] * vm[8 + j];
+    float gd = -(e.n[0] * mx + e.n[1] * my + e.n[2] * mz);
+    if (mode == IBGS_PLANE_LEARNT) gd += off;
+    const float sd = gd - (e.ncam[0] * vm[12] + e.ncam[1] * vm[13] + e.ncam[2] * vm[14]);
+    e.sgn = sd > 0.f ? 1.f : (sd < 0.f ? -1.f : 0.f);
+    e.dist = fabsf(sd);
+    return e;
+}
+
 int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g);
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
 

@@ -27,6 +27,7 @@ struct PreParams {
     int P, D, M;
     const float* means3D; const float* scales; const float* rotations; const float* opacities;
     const float* shs; const float* cov3D_precomp; const float* colors_precomp; const float* all_map;
+    const float* plane_normal; const float* plane_offset; int plane_mode;
     float scale_modifier;
     int depth_only;
     int32_t* radii;
@@ -257,7 +258,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
                         rec[R_R + ch] = fmaxf(v, 0.0f);
                     }
                 }
-                if (p.all_map) {
+                if (p.plane_mode) {
+                    const PlaneEval e = plane_eval(p.plane_mode, p.plane_normal, p.plane_offset, p.scales, p.rotations, i, px3, py3, pz3, cam.campos, vm);
+                    rec[R_NX] = e.ncam[0]; rec[R_NY] = e.ncam[1]; rec[R_NZ] = e.ncam[2]; rec[R_DIST] = e.dist;
+                } else if (p.all_map) {
                     rec[R_NX] = p.all_map[5 * i]; rec[R_NY] = p.all_map[5 * i + 1]; rec[R_NZ] = p.all_map[5 * i + 2];
                     rec[R_DIST] = p.all_map[5 * i + 4];
                 }
@@ -304,6 +308,7 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     p.P = a.P; p.D = a.D; p.M = a.M;
     p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
     p.shs = a.shs; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
+    p.plane_normal = a.plane_normal; p.plane_offset = a.plane_offset; p.plane_mode = a.plane_mode;
     p.scale_modifier = a.scale_modifier; p.depth_only = a.render_depth_only;
     p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.rect = g.rect;
     p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0]; p.tmask = g.tmask;

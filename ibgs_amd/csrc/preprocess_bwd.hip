@@ -28,6 +28,8 @@ struct PreBwdParams {
     const float* rec;          // P x 16 forward records (conic, opacity)
     float* dL_dmean2D; float* dL_dmean2D_abs; float* dL_dconic; float* dL_dopacity; float* dL_dcolors;
     float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+    const float* plane_normal; const float* plane_offset; int plane_mode;     // fused plane-map glue (common.h)
+    float* dL_dplane_normal; float* dL_dplane_offset;
 };
 
 // FAST16 (M == 16, the layout of max SH degree 3): one wave per workgroup; the 192-B SH rows are read
@@ -81,6 +83,8 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         p.dL_dopacity[i] = 0.f;
         p.dL_dcolors[3 * i] = 0.f; p.dL_dcolors[3 * i + 1] = 0.f; p.dL_dcolors[3 * i + 2] = 0.f;
         if (p.dL_dall_map) for (int k = 0; k < 5; k++) p.dL_dall_map[5 * i + k] = 0.f;
+        if (p.dL_dplane_normal) { p.dL_dplane_normal[3 * i] = 0.f; p.dL_dplane_normal[3 * i + 1] = 0.f; p.dL_dplane_normal[3 * i + 2] = 0.f; }
+        if (p.dL_dplane_offset) p.dL_dplane_offset[i] = 0.f;
         p.dL_dmean3D[3 * i] = 0.f; p.dL_dmean3D[3 * i + 1] = 0.f; p.dL_dmean3D[3 * i + 2] = 0.f;
         for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
         if (!FAST16 && WRITE_SH && p.shs) { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
@@ -117,6 +121,45 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
 
     const float* __restrict__ vm = cam.vm; const float* __restrict__ pm = cam.pm;
     const float mean[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
+
+    // ---- plane-map glue backward: (dL/dn_cam, dL/ddist) -> raw normal / offset (mode 1) or rotation (mode 2), + mean ----
+    float pgm[3] = {0.f, 0.f, 0.f}, prot[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.plane_mode) {
+        const PlaneEval e = plane_eval(p.plane_mode, p.plane_normal, p.plane_offset, p.scales, p.rotations, i, mean[0], mean[1], mean[2], cam.campos, vm);
+        const float gnc[3] = {g2.w, g3.x, g3.y};
+        const float ggd = e.sgn * g3.z;                                   // dL/d(signed world-frame plane distance)
+        float gl[3], gn0[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) gl[j] = gnc[j] - ggd * vm[12 + j];     // d_cam = gd - n_cam . V[3,:3]
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float gn = gl[0] * vm[4 * k] + gl[1] * vm[4 * k + 1] + gl[2] * vm[4 * k + 2] - ggd * mean[k];   // n_cam = n @ V[:3,:3]; gd = -(n . x)
+            gn0[k] = e.flip * gn;                                          // back through the flip
+            pgm[k] = -ggd * e.n[k];
+        }
+        if (p.plane_mode == IBGS_PLANE_LEARNT) {
+            const float u[3] = {e.n[0] * e.flip, e.n[1] * e.flip, e.n[2] * e.flip};           // raw / |raw|
+            const float dot = u[0] * gn0[0] + u[1] * gn0[1] + u[2] * gn0[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) p.dL_dplane_normal[3 * i + k] = (gn0[k] - u[k] * dot) * e.inv_len;
+            if (p.dL_dplane_offset) p.dL_dplane_offset[i] = e.flip * ggd;
+        } else {
+            // column e.axis of R(q) w.r.t. the given quaternion (r, x, y, z); any component along q is removed by the
+            // caller's normalisation backward, so the unit-quaternion form of R is differentiated as is
+            const float r_ = p.rotations[4 * i], x = p.rotations[4 * i + 1], y = p.rotations[4 * i + 2], z = p.rotations[4 * i + 3];
+            const float a = gn0[0], b = gn0[1], c = gn0[2];
+            if (e.axis == 0) {
+                prot[0] = 2.f * (z * b - y * c); prot[1] = 2.f * (y * b + z * c);
+                prot[2] = -4.f * y * a + 2.f * x * b - 2.f * r_ * c; prot[3] = -4.f * z * a + 2.f * r_ * b + 2.f * x * c;
+            } else if (e.axis == 1) {
+                prot[0] = 2.f * (x * c - z * a); prot[1] = 2.f * y * a - 4.f * x * b + 2.f * r_ * c;
+                prot[2] = 2.f * (x * a + z * c); prot[3] = -2.f * r_ * a - 4.f * z * b + 2.f * y * c;
+            } else {
+                prot[0] = 2.f * (y * a - x * b); prot[1] = 2.f * z * a - 2.f * r_ * b - 4.f * x * c;
+                prot[2] = 2.f * r_ * a + 2.f * z * b - 4.f * y * c; prot[3] = 2.f * (x * a + y * b);
+            }
+        }
+    }
     float c6[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) c6[k] = p.cov3D[6 * i + k];
@@ -264,7 +307,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         gm[1] += (-dorig[0] * dorig[1] * gd[0] + (s2 - dorig[1] * dorig[1]) * gd[1] - dorig[2] * dorig[1] * gd[2]) * inv32;
         gm[2] += (-dorig[0] * dorig[2] * gd[0] - dorig[1] * dorig[2] * gd[1] + (s2 - dorig[2] * dorig[2]) * gd[2]) * inv32;
     }
-    p.dL_dmean3D[3 * i] = gm[0]; p.dL_dmean3D[3 * i + 1] = gm[1]; p.dL_dmean3D[3 * i + 2] = gm[2];
+    p.dL_dmean3D[3 * i] = gm[0] + pgm[0]; p.dL_dmean3D[3 * i + 1] = gm[1] + pgm[1]; p.dL_dmean3D[3 * i + 2] = gm[2] + pgm[2];
 
     // ---- cov3D -> scale / rotation ----
     if (p.scales) {
@@ -291,10 +334,10 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) G[r][cc] = sv[r] * dM[r][cc];
-        p.dL_drot[4 * i + 0] = 2 * z * (G[0][1] - G[1][0]) + 2 * y * (G[2][0] - G[0][2]) + 2 * x * (G[1][2] - G[2][1]);
-        p.dL_drot[4 * i + 1] = 2 * y * (G[1][0] + G[0][1]) + 2 * z * (G[2][0] + G[0][2]) + 2 * r_ * (G[1][2] - G[2][1]) - 4 * x * (G[2][2] + G[1][1]);
-        p.dL_drot[4 * i + 2] = 2 * x * (G[1][0] + G[0][1]) + 2 * r_ * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
-        p.dL_drot[4 * i + 3] = 2 * r_ * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
+        p.dL_drot[4 * i + 0] = prot[0] + 2 * z * (G[0][1] - G[1][0]) + 2 * y * (G[2][0] - G[0][2]) + 2 * x * (G[1][2] - G[2][1]);
+        p.dL_drot[4 * i + 1] = prot[1] + 2 * y * (G[1][0] + G[0][1]) + 2 * z * (G[2][0] + G[0][2]) + 2 * r_ * (G[1][2] - G[2][1]) - 4 * x * (G[2][2] + G[1][1]);
+        p.dL_drot[4 * i + 2] = prot[2] + 2 * x * (G[1][0] + G[0][1]) + 2 * r_ * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
+        p.dL_drot[4 * i + 3] = prot[3] + 2 * r_ * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
     }
     }   // vis
 
@@ -326,6 +369,8 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
     p.dL_dmean2D = a.dL_dmean2D; p.dL_dmean2D_abs = a.dL_dmean2D_abs; p.dL_dconic = a.dL_dconic;
     p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
     p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;
+    p.plane_normal = a.plane_normal; p.plane_offset = a.plane_offset; p.plane_mode = a.plane_mode;
+    p.dL_dplane_normal = a.dL_dplane_normal; p.dL_dplane_offset = a.dL_dplane_offset;
     const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     const bool factored = a.shs && (a.flags & IBGS_FLAG_SH_FACTORED);
     if (a.shs && a.M == 16) {

@@ -134,7 +134,9 @@ class _CModule:
                             cov3D_precomp, all_map, viewmatrix, projmatrix, ref_to_src_list, src_cam_pos,
                             src_images, src_rendered_depths, nb_src_images, buffer_length,
                             depth_error_threshold, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, render_geo, render_depth_only, debug):
+                            campos, prefiltered, render_geo, render_depth_only, debug, plane=None):
+        """The reference's 29 positional arguments; `plane` = (raw_normal or None, raw_offset or None, mode) is this
+        library's extension (fused plane-map glue, include/ibgs_rast.h) and replaces `all_map`."""
         lib = _lib.load()
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:69-71
@@ -210,6 +212,9 @@ class _CModule:
                 a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c)
                 a.opacities = _ptr(opacity_c); a.scales = _ptr(scales_c); a.rotations = _ptr(rot_c)
                 a.cov3D_precomp = _ptr(cov_c); a.all_map = _ptr(all_map_c)
+                if plane is not None and plane[2]:
+                    pn_c, po_c = _dev_f32(plane[0], device), _dev_f32(plane[1], device)
+                    a.plane_normal = _ptr(pn_c); a.plane_offset = _ptr(po_c); a.plane_mode = int(plane[2]); a.all_map = None
                 a.scale_modifier = float(scale_modifier)
                 a.bg = _ptr(bg_c); a.viewmatrix = _ptr(vm_c); a.projmatrix = _ptr(pm_c); a.campos = _ptr(campos_c)
                 a.tanfovx = float(tan_fovx); a.tanfovy = float(tan_fovy)
@@ -263,7 +268,9 @@ class _CModule:
                                      src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
                                      dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, render_geo, debug):
+                                     imageBuffer, render_geo, debug, plane=None):
+        """The reference's 34 positional arguments and 10 results; with `plane` (see rasterize_gaussians) two more
+        results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1)."""
         lib = _lib.load()
         device = means3D.device
         P = int(means3D.size(0))
@@ -280,7 +287,14 @@ class _CModule:
             dL_dmeans3D = new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
             dL_dmeans2D_abs = new(P, 3, **opts); dL_dcolors = new(P, NUM_CHANNELS, **opts)
             # gradients of inputs the mode does not use: zeros without a fill (the reference memsets them, rasterize_points.cu:196-206)
-            dL_dall_map = new(P, NUM_PLANE_PARAMS, **opts) if (render_geo and all_maps.numel() != 0 and P != 0) else _zeros_view((P, NUM_PLANE_PARAMS), device)
+            fused = plane is not None and bool(plane[2])
+            dL_dall_map = new(P, NUM_PLANE_PARAMS, **opts) if (render_geo and all_maps.numel() != 0 and P != 0 and not fused) else _zeros_view((P, NUM_PLANE_PARAMS), device)
+            dL_dplane_normal = dL_dplane_offset = None
+            if fused:
+                learnt = int(plane[2]) == _lib.PLANE_LEARNT
+                want = render_geo and P != 0
+                dL_dplane_normal = (new(P, 3, **opts) if want else _zeros_view((P, 3), device)) if (learnt and plane[0] is not None) else None
+                dL_dplane_offset = (new(P, 1, **opts) if want else _zeros_view((P, 1), device)) if (learnt and plane[1] is not None) else None
             dL_dopacity = new(P, 1, **opts); dL_dcov3D = new(P, 6, **opts)
             factored = _sh_factor_sink is not None and M != 0 and P != 0
             dL_dsh = None if factored else new(P, M, 3, **opts)
@@ -329,7 +343,11 @@ class _CModule:
                 a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr()
                 a.dL_dsh = dL_dsh.data_ptr() if (M and not factored) else None
                 a.dL_dscale = dL_dscales.data_ptr() if have_sr else None; a.dL_drot = dL_drotations.data_ptr() if have_sr else None
-                a.dL_dall_map = dL_dall_map.data_ptr() if (render_geo and all_maps.numel() != 0) else None
+                a.dL_dall_map = dL_dall_map.data_ptr() if (render_geo and all_maps.numel() != 0 and not fused) else None
+                if fused and render_geo:
+                    pn_c, po_c = _dev_f32(plane[0], device), _dev_f32(plane[1], device)
+                    a.plane_normal = _ptr(pn_c); a.plane_offset = _ptr(po_c); a.plane_mode = int(plane[2]); a.all_map = None
+                    a.dL_dplane_normal = _ptr(dL_dplane_normal); a.dL_dplane_offset = _ptr(dL_dplane_offset)
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
                            | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0))
@@ -339,8 +357,9 @@ class _CModule:
                 gacc_ent[1] = False
                 if factored:
                     _sh_factor_sink.append({"dcolor": dL_dcolors, "campos": campos_c.reshape(3), "degree": int(degree), "M": M})
-        return (dL_dmeans2D, dL_dmeans2D_abs, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
-                dL_dscales, dL_drotations, dL_dall_map)
+        res = (dL_dmeans2D, dL_dmeans2D_abs, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+               dL_dscales, dL_drotations, dL_dall_map)
+        return res + (dL_dplane_normal, dL_dplane_offset) if plane is not None else res
 
     @staticmethod
     def mark_visible(means3D, viewmatrix, projmatrix):
@@ -362,15 +381,17 @@ _C = _CModule()
 
 
 def rasterize_gaussians(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
-                        cov3Ds_precomp, all_map, raster_settings):
+                        cov3Ds_precomp, all_map, raster_settings, plane_normal=None, plane_offset=None, plane_mode=0):
     return _RasterizeGaussians.apply(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales,
-                                     rotations, cov3Ds_precomp, all_map, raster_settings)
+                                     rotations, cov3Ds_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, all_maps, raster_settings):
+                cov3Ds_precomp, all_maps, raster_settings, plane_normal=None, plane_offset=None, plane_mode=0):
+        plane = (plane_normal, plane_offset, int(plane_mode)) if plane_mode else None
+        kw = {"plane": plane} if plane is not None else {}
         # argument order of the reference's _C.rasterize_gaussians (reference __init__.py:66-98)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -387,23 +408,26 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
             try:
-                res = _C.rasterize_gaussians(*args)
+                res = _C.rasterize_gaussians(*args, **kw)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            res = _C.rasterize_gaussians(*args)
+            res = _C.rasterize_gaussians(*args, **kw)
         (num_rendered, color, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
          out_min_depth_diff, out_camera_ray, out_use_first_src_frame, geomBuffer, binningBuffer, imgBuffer) = res
 
         ctx.raster_settings = raster_settings
+        ctx.plane_mode = int(plane_mode) if plane is not None else 0
         ctx.num_rendered = num_rendered
         # outputs that the loss does not touch arrive as None instead of freshly zero-filled planes
         ctx.set_materialize_grads(False)
+        none = torch.Tensor([])
         ctx.save_for_backward(out_normal_map, out_median_intersected_depth, out_warped_image, colors_precomp,
-                              all_maps, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
-                              binningBuffer, imgBuffer)
+                              all_maps, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              plane_normal if plane_normal is not None else none, plane_offset if plane_offset is not None else none,
+                              geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii, out_use_first_src_frame)
         return (color, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
                 out_min_depth_diff, out_camera_ray, out_use_first_src_frame)
@@ -415,7 +439,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
         (normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels, colors_precomp, all_maps, means3D,
-         scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+         scales, rotations, cov3Ds_precomp, radii, sh, plane_normal, plane_offset, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+        kw = {}
+        if ctx.plane_mode:
+            kw["plane"] = (plane_normal if plane_normal.numel() else None, plane_offset if plane_offset.numel() else None, ctx.plane_mode)
 
         # argument order of the reference's _C.rasterize_gaussians_backward (reference __init__.py:182-221)
         args = (raster_settings.bg, normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels,
@@ -430,17 +457,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                res = _C.rasterize_gaussians_backward(*args)
+                res = _C.rasterize_gaussians_backward(*args, **kw)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            res = _C.rasterize_gaussians_backward(*args)
+            res = _C.rasterize_gaussians_backward(*args, **kw)
         (grad_means2D, grad_means2D_abs, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
-         grad_sh, grad_scales, grad_rotations, grad_all_map) = res
+         grad_sh, grad_scales, grad_rotations, grad_all_map) = res[:10]
+        grad_plane_normal, grad_plane_offset = (res[10], res[11]) if ctx.plane_mode else (None, None)
         return (grad_means3D, grad_means2D, grad_means2D_abs, grad_sh, grad_colors_precomp, grad_opacities,
-                grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_all_map, None)
+                grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_all_map, None, grad_plane_normal, grad_plane_offset, None)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -480,8 +508,12 @@ class GaussianRasterizer(nn.Module):
         return visible
 
     def forward(self, means3D, means2D, means2D_abs, opacities, shs=None, colors_precomp=None, scales=None,
-                rotations=None, cov3D_precomp=None, all_map=None):
+                rotations=None, cov3D_precomp=None, all_map=None, plane_normal=None, plane_offset=None, plane_mode=0):
+        """Reference signature plus the fused plane-map extension: instead of `all_map` pass the raw `_normal` /
+        `_offset` parameters with plane_mode=1 (learnt normals) or plane_mode=2 (normal = smallest-scale axis)."""
         raster_settings = self.raster_settings
+        if plane_mode and all_map is not None:
+            raise Exception('Please provide either all_map or plane_mode, not both!')
 
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -504,4 +536,4 @@ class GaussianRasterizer(nn.Module):
             all_map = torch.Tensor([])
 
         return rasterize_gaussians(means3D, means2D, means2D_abs, shs, colors_precomp, opacities, scales,
-                                   rotations, cov3D_precomp, all_map, raster_settings)
+                                   rotations, cov3D_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode)

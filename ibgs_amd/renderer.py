@@ -79,6 +79,22 @@ def render_normal(viewpoint_cam, depth, offset=None, normal=None, scale=1):
     return normal_ref.permute(2, 0, 1)
 
 
+# build [n_cam, 1, |d_cam|] inside the preprocess kernels (and its backward inside
+# preprocess_bwd) instead of the ~10 torch kernels + (P, 5) round trip of `_plane_map` below.  False = the
+# reference's glue, kept as the behavioural definition (tests compare the two).
+FUSED_PLANE_MAP = True
+
+
+def _plane_inputs(pc, viewpoint_camera, learnt_normal, means3D, scales, rotations):
+    """kwargs for GaussianRasterizer.forward: either the fused raw plane parameters or the reference's all_map."""
+    if FUSED_PLANE_MAP:      # means3D is pc.get_xyz in both callers, as in the reference (the flip test uses pc._xyz)
+        if learnt_normal and hasattr(pc, "_normal"):
+            return dict(plane_normal=pc._normal, plane_offset=getattr(pc, "_offset", None), plane_mode=1)
+        if not learnt_normal and scales is not None and rotations is not None:
+            return dict(plane_mode=2)
+    return dict(all_map=_plane_map(pc, viewpoint_camera, learnt_normal, means3D))
+
+
 def _plane_map(pc, viewpoint_camera, learnt_normal, means3D):
     """all_map (P,5) = [normal in camera frame, 1, |plane offset in camera frame|]."""
     V = viewpoint_camera.world_view_transform.to(means3D.device)
@@ -159,10 +175,9 @@ def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor
         campos=viewpoint_camera.camera_center, prefiltered=False, render_geo=False, render_depth_only=True,
         debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    input_all_map = _plane_map(pc, viewpoint_camera, learnt_normal, means3D)
     outs = rasterizer(means3D=means3D, means2D=means2D, means2D_abs=means2D_abs, shs=shs,
                       colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
-                      all_map=input_all_map, cov3D_precomp=cov3D_precomp)
+                      cov3D_precomp=cov3D_precomp, **_plane_inputs(pc, viewpoint_camera, learnt_normal, means3D, scales, rotations))
     return outs[3]
 
 
@@ -241,13 +256,13 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
         campos=viewpoint_camera.camera_center, prefiltered=False, render_geo=render_geo,
         render_depth_only=render_depth_only, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    input_all_map = _plane_map(pc, viewpoint_camera, learnt_normal, means3D) if (render_geo or render_depth_only) else None
+    plane_kw = _plane_inputs(pc, viewpoint_camera, learnt_normal, means3D, scales, rotations) if (render_geo or render_depth_only) else {}
 
     (rendered_image, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
      out_min_depth_diff, out_camera_ray, use_first_src_frame_mask) = rasterizer(
         means3D=means3D, means2D=screenspace_points, means2D_abs=screenspace_points_abs, shs=shs,
         colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
-        all_map=input_all_map, cov3D_precomp=cov3D_precomp)
+        cov3D_precomp=cov3D_precomp, **plane_kw)
 
     rendered_normal = out_normal_map[0:3] if render_geo else None
     if return_depth_normal:

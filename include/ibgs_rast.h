@@ -57,6 +57,10 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
 #define IBGS_FLAG_NO_TILE_CULL 4u /* emit the reference's full AABB tile lists (rasterizer_impl.cu:205-225) instead of
                                      dropping tiles that provably fail the alpha >= 1/255 test; outputs are identical */
 
+#define IBGS_PLANE_NONE 0
+#define IBGS_PLANE_LEARNT 1
+#define IBGS_PLANE_SMALLEST_AXIS 2
+
 #define IBGS_FLAG_SH_FACTORED 16u /* ibgs_backward only, view-parallel training: dL/dsh of ONE view is the outer product
                                      basis(dir) x dL/dRGB (backward.cu:114-160), so leave dL_dsh unwritten (may be NULL) and
                                      write the clamp-masked dL/dRGB (P x 3) to dL_dcolors; after the ranks exchanged those
@@ -126,6 +130,14 @@ typedef struct ibgs_forward_args {
      * IBGS_FLAG_DEBUG is set.  ibgs_backward needs nothing extra: it locates the sorted list independently of
      * the size the arena was carved for. */
     int64_t rendered_hint;
+    /* SURVEY 8(f) row 1 -- plane-map glue fused into preprocess.  plane_mode != 0 replaces all_map (which must then
+     * be NULL): the library derives [n_cam, 1, |d_cam|] per Gaussian itself instead of the ~10 torch kernels of
+     * gaussian_renderer/__init__.py:304-316 + scene/gaussian_model.py:156-173.
+     *   IBGS_PLANE_LEARNT:        plane_normal = raw `_normal` (P x 3, not normalised), plane_offset = raw `_offset` (P) or NULL
+     *   IBGS_PLANE_SMALLEST_AXIS: normal = column argmin(scales) of R(rotations); needs scales + rotations */
+    const float* plane_normal;
+    const float* plane_offset;
+    int32_t plane_mode;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {
@@ -178,6 +190,15 @@ typedef struct ibgs_backward_args {
     float* dL_dall_map;    /* P x 5 */
     int32_t render_geo;
     uint32_t flags;
+    /* fused plane-map glue (same meaning as in ibgs_forward_args).  With plane_mode != 0, dL_dall_map may be NULL and
+     * the gradient continues to the raw parameters: dL_dplane_normal (P x 3) and dL_dplane_offset (P, may be NULL) for
+     * IBGS_PLANE_LEARNT; for IBGS_PLANE_SMALLEST_AXIS it is added into dL_drot.  Both modes add the d(distance)/d(mean)
+     * term into dL_dmean3D. */
+    const float* plane_normal;
+    const float* plane_offset;
+    int32_t plane_mode;
+    float* dL_dplane_normal;
+    float* dL_dplane_offset;
 } ibgs_backward_args;
 
 size_t ibgs_required_geom(int32_t P);
