@@ -52,11 +52,14 @@ class capture_sh_factors:
         return False
 
 
-# R (the number of (Gaussian, tile) pairs) of the previous forward with the same (device, P, W, H, mode): the next call
-# passes 1.25 x that as ibgs_forward_args.rendered_hint so that the host does not stall the GPU while R travels back
-# (include/ibgs_rast.h).  RENDERED_HINT = False restores the reference's synchronous sizing.
+# R (the number of (Gaussian, tile) pairs) of recent forwards with the same (device, P, W, H, mode): the next call passes
+# 1.25 x their maximum as ibgs_forward_args.rendered_hint so that the host does not stall the GPU while R travels back
+# (include/ibgs_rast.h).  The maximum over the last RENDERED_WINDOW calls covers a trainer that hops between cameras; a
+# view that still exceeds the hint costs one repeated binning + render pass, never a wrong result.
+# RENDERED_HINT = False restores the reference's synchronous sizing.
 RENDERED_HINT = True
-_last_rendered = {}
+RENDERED_WINDOW = 16
+_last_rendered = {}           # key -> R of the last call, or a list of recent R values
 LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent forward carved its binning arena for
 
 _tex_scratch = {}
@@ -244,7 +247,8 @@ class _CModule:
                 elif render_depth_only:
                     a.out_depth = out_depth.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
-                prev = _last_rendered.get(hkey, 0) if (RENDERED_HINT and not debug) else 0
+                hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
+                prev = (max(hist) if isinstance(hist, list) else int(hist)) if hist else 0
                 a.rendered_hint = (prev + prev // 4 + 4096) if prev > 0 else 0
                 rc = lib.ibgs_forward(ctypes.byref(a))
                 if rc < 0:
@@ -254,7 +258,9 @@ class _CModule:
                 rendered = int(rc)
                 if len(_last_rendered) > 64:
                     _last_rendered.clear()
-                _last_rendered[hkey] = rendered
+                hist = _last_rendered.get(hkey)
+                hist = (hist if isinstance(hist, list) else ([int(hist)] if hist else [])) + [rendered]
+                _last_rendered[hkey] = hist[-RENDERED_WINDOW:]
                 global LAST_BINNING_CAPACITY
                 LAST_BINNING_CAPACITY = max(rendered, int(a.rendered_hint)) if a.rendered_hint else rendered
                 binningBuffer = holder.get("t", binningBuffer)

@@ -58,7 +58,7 @@ def test_hint_follows_the_previous_call():
     inp = syn.make_scene(5000, 160, 120, sh_degree=1, seed=2)
     rasterizer._last_rendered.clear()
     o1, _, _ = hipref.run_forward(inp, requires_grad=False)
-    assert rasterizer.LAST_BINNING_CAPACITY == rasterizer._last_rendered[next(iter(rasterizer._last_rendered))]
+    assert [rasterizer.LAST_BINNING_CAPACITY] == rasterizer._last_rendered[next(iter(rasterizer._last_rendered))]
     R = rasterizer.LAST_BINNING_CAPACITY
     o2, _, _ = hipref.run_forward(inp, requires_grad=False)
     assert rasterizer.LAST_BINNING_CAPACITY == R + R // 4 + 4096 and torch.equal(o1["color"], o2["color"])
