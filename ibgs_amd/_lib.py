@@ -17,6 +17,7 @@ FLAG_NO_TILE_CULL = 4
 FLAG_CLEAR_GRAD_ACC = 8
 FLAG_SH_FACTORED = 16
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
+MAX_VIEWS = 8
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 
@@ -47,6 +48,7 @@ class ForwardArgs(ctypes.Structure):
         ("out_camera_ray", c_float_p), ("out_mask", ctypes.c_void_p),
         ("rendered_hint", ctypes.c_int64),
         ("plane_normal", c_float_p), ("plane_offset", c_float_p), ("plane_mode", ctypes.c_int32),
+        ("n_views", ctypes.c_int32), ("view_tanfovx", ctypes.c_float * 8), ("view_tanfovy", ctypes.c_float * 8),
     ]
 
 

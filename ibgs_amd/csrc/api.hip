@@ -230,30 +230,40 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
     }
     if (!a.render_depth_only && !a.out_color) { set_error("out_color required"); return -IBGS_ERR_INVALID; }
-    if (!a.geom || a.geom_bytes < ibgs_required_geom(a.P)) { set_error("geom arena too small"); return -IBGS_ERR_ALLOC; }
-    if (!a.img || a.img_bytes < ibgs_required_img(a.W, a.H)) { set_error("img arena too small"); return -IBGS_ERR_ALLOC; }
+    // batched depth-only views: one tall tile grid of nv x ceil(H/16) rows, nv x P instances
+    const int nv = a.n_views > 1 ? a.n_views : 1;
+    if (nv > 1) {
+        if (nv > IBGS_MAX_VIEWS || !a.render_depth_only || a.plane_mode == IBGS_PLANE_NONE) {
+            set_error("n_views = %d needs render_depth_only, plane_mode != 0 and n_views <= %d", a.n_views, IBGS_MAX_VIEWS); return -IBGS_ERR_INVALID;
+        }
+        if ((int64_t)nv * a.P > 0x7FFFFFFF) { set_error("n_views x P too large"); return -IBGS_ERR_INVALID; }
+    }
+    const int Pn = nv * a.P;                                      // instances
+    const int Hn = nv > 1 ? nv * TILE * ((a.H + TILE - 1) / TILE) : a.H;   // height of the stacked grid in pixels
+    if (!a.geom || a.geom_bytes < ibgs_required_geom(Pn)) { set_error("geom arena too small"); return -IBGS_ERR_ALLOC; }
+    if (!a.img || a.img_bytes < ibgs_required_img(a.W, Hn)) { set_error("img arena too small"); return -IBGS_ERR_ALLOC; }
     if (!a.binning_alloc) { set_error("binning_alloc callback required"); return -IBGS_ERR_INVALID; }
 
     int rc;
-    GeomState g = GeomState::carve(a.geom, (size_t)a.P, nullptr);
-    ImgState im = ImgState::carve(a.img, a.W, a.H, nullptr);
-    const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
+    GeomState g = GeomState::carve(a.geom, (size_t)Pn, nullptr);
+    ImgState im = ImgState::carve(a.img, a.W, Hn, nullptr);
+    const int gx = (a.W + TILE - 1) / TILE, gy = nv * ((a.H + TILE - 1) / TILE);
 
     { StageTimer t(s, IBGS_STAGE_PREPROCESS); if ((rc = launch_preprocess(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess"))) return rc;
     { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
-      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)a.P, 32, g.hist, g.hist_elems))) return rc; }
+      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
     { StageTimer t(s, IBGS_STAGE_SCAN);
-      if ((rc = launch_gather_tiles(s, a.P, g))) return rc;
-      if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)a.P, g.hist, g.hist_elems, true))) return rc; }
+      if ((rc = launch_gather_tiles(s, Pn, g))) return rc;
+      if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
     // R = total number of (Gaussian, tile) pairs, known only on the device at this point.  It travels to the host
     // through a pinned word + event.  Without a hint the host waits for it here (the binning arena is sized from
     // it); with args->rendered_hint the remaining stages are enqueued first, sized for the hint and reading the real
     // count from device memory, and the host waits only afterwards -- the GPU never idles on the round trip.
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
-    const uint32_t* R_dev = g.offsets + a.P;
+    const uint32_t* R_dev = g.offsets + Pn;
     IBGS_HIP(hipMemcpyAsync(rs->host, R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     IBGS_HIP(hipEventRecord(rs->ev, s));
     const bool deferred = a.rendered_hint > 0 && !debug;
@@ -267,7 +277,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, a.H), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, a.H, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, a.P, n, gx, g, b, n_dev))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, Pn, n, gx, g, b, n_dev))) return rc; }
         if ((rc = stage_check(s, debug, "emit"))) return rc;
         { StageTimer t(s, IBGS_STAGE_TILE_SORT);
           if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)n, bit, b.hist, b.hist_elems, n_dev))) return rc; }

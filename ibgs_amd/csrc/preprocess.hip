@@ -28,6 +28,8 @@ struct PreParams {
     const float* means3D; const float* scales; const float* rotations; const float* opacities;
     const float* shs; const float* cov3D_precomp; const float* colors_precomp; const float* all_map;
     const float* plane_normal; const float* plane_offset; int plane_mode;
+    int inst0;          // batched views: index of this view's first instance in the per-instance outputs (view * P)
+    int tile_row0;      // ... and its first row in the stacked tile grid (view * ceil(H/16))
     float scale_modifier;
     int depth_only;
     int32_t* radii;
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
                 tmask = ~0ull;
                 if (p.cull)
                     ntiles = tile_cull(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, tmask);
-                rx = pack_rect(x0, x1); ry = pack_rect(y0, y1);
+                rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
                 depth = zview;
                 rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
                 rec[R_CA] = cc * det_inv; rec[R_CB] = -cb * det_inv; rec[R_CC] = ca * det_inv;
@@ -273,25 +275,26 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
         for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     }
 
-    p.radii[i] = radius;
-    p.tiles[i] = ntiles;
-    p.rect[2 * i] = rx; p.rect[2 * i + 1] = ry;
-    p.tmask[i] = tmask;
-    p.depths[i] = depth;
-    p.clamped[i] = clampbits;
+    const int o = p.inst0 + i;            // instance slot (= i for a single view)
+    p.radii[o] = radius;
+    p.tiles[o] = ntiles;
+    p.rect[2 * o] = rx; p.rect[2 * o + 1] = ry;
+    p.tmask[o] = tmask;
+    p.depths[o] = depth;
+    p.clamped[o] = clampbits;
     if (!p.cov3D_precomp) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) p.cov3D[6 * i + k] = c6loc[k];   // computed for every Gaussian past the near cull
+        for (int k = 0; k < 6; k++) p.cov3D[6 * o + k] = c6loc[k];   // computed for every Gaussian past the near cull
     }
-    float4* out = reinterpret_cast<float4*>(p.rec + (size_t)i * REC_FLOATS);
+    float4* out = reinterpret_cast<float4*>(p.rec + (size_t)o * REC_FLOATS);
     out[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     out[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     out[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
     out[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
     // depth sort input: positive float bits order like the floats; culled Gaussians sort last
     // Gaussians without any tile (culled, or fully tile-culled) sort last and emit nothing
-    p.sort_key[i] = (alive && ntiles > 0) ? __float_as_uint(depth) : 0xFFFFFFFFu;
-    p.sort_val[i] = (uint32_t)i;
+    p.sort_key[o] = (alive && ntiles > 0) ? __float_as_uint(depth) : 0xFFFFFFFFu;
+    p.sort_val[o] = (uint32_t)o;
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present)
@@ -314,9 +317,15 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0]; p.tmask = g.tmask;
     // depth-only with a 1-slot buffer depends on list positions (the per-round 'break' of forward.cu:484-488)
     p.cull = !(a.flags & IBGS_FLAG_NO_TILE_CULL) && !(a.render_depth_only && a.buffer_length == 1);
-    const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     const int blocks = (a.P + 255) / 256;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p, cam);
+    const int nv = a.n_views > 1 ? a.n_views : 1;
+    const int gy = (a.H + TILE - 1) / TILE;
+    for (int v = 0; v < nv; v++) {       // batched depth passes: one launch per camera, outputs land in that view's slice
+        p.inst0 = v * a.P; p.tile_row0 = v * gy;
+        const Cam cam = make_cam(a.viewmatrix + 16 * v, a.projmatrix + 16 * v, a.campos + 3 * v, a.bg,
+                                 nv > 1 ? a.view_tanfovx[v] : a.tanfovx, nv > 1 ? a.view_tanfovy[v] : a.tanfovy, a.W, a.H);
+        hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p, cam);
+    }
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -28,6 +28,8 @@ struct FwdParams {
     const uint32_t* ranges; const uint32_t* point_list; const float4* rec;
     Cam cam;
     int ntiles;
+    // batched depth-only views (stacked tile grid): rows per view, per-view focal lengths
+    int n_views, gyv; float fxv[IBGS_MAX_VIEWS], fyv[IBGS_MAX_VIEWS];
     // geo
     int n_src; int L; float thr; int tex_quant;
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
@@ -116,8 +118,11 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const int tile = (PPL == 4) ? item : (item >> 2);
     const int quad0 = (PPL == 4) ? 0 : (item & 3);
     const int W = p.cam.W, H = p.cam.H;
-    const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
+    int trow = tile / p.cam.gx, view = 0;
+    if (DEPTH && p.n_views > 1) { view = trow / p.gyv; trow -= view * p.gyv; }      // which camera's grid this tile belongs to
+    const int tx0 = (tile % p.cam.gx) * TILE, ty0 = trow * TILE;
     const size_t HW = (size_t)W * H;
+    const size_t vbase = (size_t)view * HW;          // offset of this view's planes (0 for a single view)
 
     int px[PPL], py[PPL];
     float pxf[PPL], pyf[PPL];
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         live[q] = __builtin_amdgcn_ballot_w64(inside[q]);
         T[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.f; lastc[q] = 0;
     }
-    const float fx = p.cam.fx, fy = p.cam.fy;
+    const float fx = (DEPTH && p.n_views > 1) ? p.fxv[view] : p.cam.fx, fy = (DEPTH && p.n_views > 1) ? p.fyv[view] : p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
     const float eps = 1.0e-8f;
     const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
         if (!inside[q]) continue;
-        const size_t pix = (size_t)py[q] * W + px[q];
+        const size_t pix = vbase + (size_t)py[q] * W + px[q];
         p.final_T[pix] = T[q];
         p.n_contrib[pix] = lastc[q];
         if (!DEPTH) {
@@ -406,6 +411,12 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;
+    p.n_views = a.n_views > 1 ? a.n_views : 1; p.gyv = p.cam.gy;
+    for (int v = 0; v < IBGS_MAX_VIEWS; v++) {
+        p.fxv[v] = (v < p.n_views && p.n_views > 1) ? a.W / (2.0f * a.view_tanfovx[v]) : p.cam.fx;
+        p.fyv[v] = (v < p.n_views && p.n_views > 1) ? a.H / (2.0f * a.view_tanfovy[v]) : p.cam.fy;
+    }
+    p.ntiles *= p.n_views;
     const int nt = p.ntiles;
     if (a.render_depth_only && !a.render_geo) {
         const int grid = ((nt + 7) / 8) * 8;

@@ -392,6 +392,79 @@ def rasterize_gaussians(means3D, means2D, means2D_abs, sh, colors_precomp, opaci
                                      rotations, cov3Ds_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode)
 
 
+def rasterize_depth_batch(means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, viewmatrices, projmatrices,
+                          camposes, tanfovxs, tanfovys, image_height, image_width, buffer_length, plane_normal=None,
+                          plane_offset=None, plane_mode=2, debug=False):
+    """median ray/plane depth of n cameras of equal size in ONE rasterizer pass (C ABI
+    `ibgs_forward_args.n_views`).  Replaces the reference's loop of `render_depth` calls over the source views
+    (gaussian_renderer/__init__.py:245-253); every view's map is bit-identical to its single pass.
+    viewmatrices / projmatrices: (n, 4, 4) as `world_view_transform` / `full_proj_transform`; camposes (n, 3).
+    Returns (depths (n, 1, H, W), radii (n, P)).  Forward only (the reference runs these passes without gradients)."""
+    lib = _lib.load()
+    device = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must live on a HIP device (libibgs_rast.so has no CPU path)")
+    n = int(viewmatrices.shape[0])
+    if not (1 <= n <= _lib.MAX_VIEWS):
+        raise RuntimeError("rasterize_depth_batch: 1..%d views per call" % _lib.MAX_VIEWS)
+    if not plane_mode:
+        raise RuntimeError("rasterize_depth_batch needs plane_mode 1 (learnt normal) or 2 (smallest axis)")
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    with torch.cuda.device(device), torch.no_grad():
+        depths = (torch.empty if P else torch.zeros)(n, 1, H, W, dtype=torch.float32, device=device)
+        radii = (torch.empty if P else torch.zeros)(n, P, dtype=torch.int32, device=device)
+        if P == 0:
+            return depths, radii
+        m_c = _dev_f32(means3D, device); o_c = _dev_f32(opacities, device)
+        s_c = _dev_f32(scales, device); r_c = _dev_f32(rotations, device); cov_c = _dev_f32(cov3D_precomp, device)
+        vm_c = _dev_f32(viewmatrices.reshape(n, 16), device); pm_c = _dev_f32(projmatrices.reshape(n, 16), device)
+        cp_c = _dev_f32(camposes.reshape(n, 3), device)
+        pn_c = _dev_f32(plane_normal, device); po_c = _dev_f32(plane_offset, device)
+        bg_c = _zeros_view((3,), device).contiguous()
+        gy = (H + 15) // 16
+        geom = torch.empty(lib.ibgs_required_geom(n * P), dtype=torch.uint8, device=device)
+        img = torch.empty(lib.ibgs_required_img(W, n * 16 * gy if n > 1 else H), dtype=torch.uint8, device=device)
+        holder = {}
+
+        def _alloc(nbytes, _user):
+            try:
+                holder["t"] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                return holder["t"].data_ptr()
+            except Exception as ex:
+                holder["err"] = ex
+                return 0
+
+        cb = _lib.ALLOC_FN(_alloc)
+        a = _lib.ForwardArgs()
+        a.stream = torch.cuda.current_stream(device).cuda_stream
+        a.P, a.D, a.M, a.W, a.H = P, 0, 0, W, H
+        a.means3D = _ptr(m_c); a.opacities = _ptr(o_c); a.scales = _ptr(s_c); a.rotations = _ptr(r_c); a.cov3D_precomp = _ptr(cov_c)
+        a.scale_modifier = float(scale_modifier)
+        a.bg = _ptr(bg_c); a.viewmatrix = _ptr(vm_c); a.projmatrix = _ptr(pm_c); a.campos = _ptr(cp_c)
+        a.tanfovx = float(tanfovxs[0]); a.tanfovy = float(tanfovys[0])
+        a.n_src = 1; a.buffer_length = int(buffer_length); a.depth_error_threshold = 0.0
+        a.render_geo = 0; a.render_depth_only = 1
+        a.flags = (_lib.FLAG_DEBUG if debug else 0) | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL)
+        a.geom = geom.data_ptr(); a.geom_bytes = geom.numel(); a.img = img.data_ptr(); a.img_bytes = img.numel()
+        a.binning_alloc = cb; a.binning_user = None
+        a.radii = radii.data_ptr(); a.out_depth = depths.data_ptr()
+        a.plane_normal = _ptr(pn_c); a.plane_offset = _ptr(po_c); a.plane_mode = int(plane_mode)
+        a.n_views = n if n > 1 else 0
+        for v in range(n):
+            a.view_tanfovx[v] = float(tanfovxs[v]); a.view_tanfovy[v] = float(tanfovys[v])
+        hkey = (device.index, P, W, H, "depth_batch", n)
+        hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
+        prev = max(hist) if hist else 0
+        a.rendered_hint = (prev + prev // 4 + 4096) if prev > 0 else 0
+        rc = lib.ibgs_forward(ctypes.byref(a))
+        if rc < 0:
+            if "err" in holder:
+                raise holder["err"]
+            raise RuntimeError("ibgs_forward (depth batch) failed (%d): %s" % (rc, _lib.last_error()))
+        _last_rendered[hkey] = ((hist or []) + [int(rc)])[-RENDERED_WINDOW:]
+    return depths, radii
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,

@@ -181,6 +181,36 @@ def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor
     return outs[3]
 
 
+def render_depth_batch(viewpoint_cameras, pc, scene, pipe, args, bg_color, learnt_normal: bool, nb_src_frames: int,
+                       buffer_length: int, depth_error_threshold: Optional[float] = None, scaling_modifier=1.0,
+                       override_color=None):
+    """Depth maps of several cameras in ONE rasterizer pass: same results as
+    `[render_depth(c, ...) for c in viewpoint_cameras]` stacked to (n, 1, H, W).  Falls back to that loop when the
+    cameras differ in size or the fused plane-map inputs are unavailable."""
+    from .rasterizer import rasterize_depth_batch, _lib as _rl
+    cams = list(viewpoint_cameras)
+    H, W = int(cams[0].image_height), int(cams[0].image_width)
+    same = all(int(c.image_height) == H and int(c.image_width) == W for c in cams)
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    plane = _plane_inputs(pc, cams[0], learnt_normal, pc.get_xyz, scales, rotations) if FUSED_PLANE_MAP else {}
+    if not same or "plane_mode" not in plane or len(cams) > _rl.MAX_VIEWS:
+        return torch.stack([render_depth(c, pc, scene, pipe, args, bg_color, learnt_normal, nb_src_frames, buffer_length,
+                                         depth_error_threshold, scaling_modifier, override_color) for c in cams], dim=0)
+    dev = pc.get_xyz.device
+    vms = torch.stack([c.world_view_transform.to(dev) for c in cams])
+    pms = torch.stack([c.full_proj_transform.to(dev) for c in cams])
+    cps = torch.stack([c.camera_center.to(dev) for c in cams])
+    depths, _ = rasterize_depth_batch(pc.get_xyz, pc.get_opacity, scales, rotations, cov3D_precomp, scaling_modifier, vms, pms, cps,
+                                      [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], H, W,
+                                      buffer_length, plane.get("plane_normal"), plane.get("plane_offset"), plane["plane_mode"],
+                                      debug=pipe.debug)
+    return depths
+
+
 def find_closest_frames(viewpoint_camera, scene, args):
     """Neighbour search of the test-time path (reference :200-227): sort training views by distance
     then angle, keep those inside the angle / distance window, optionally move the most similar pose
@@ -230,9 +260,10 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
                 chosen = list(nearest[:nb_src_frames])
             src_images = scene.original_image_list[chosen]
             if do_render_src_depth:
-                deps = [render_depth(scene.getTrainCameras()[i], pc, scene, pipe, args, bg_color, learnt_normal, nb_src_frames,
-                                     buffer_length, depth_error_threshold, scaling_modifier, override_color) for i in chosen]
-                src_rendered_depths = torch.stack(deps, dim=0)
+                # the reference loops render_depth over the sources (:245-253); here they share ONE rasterizer pass
+                src_rendered_depths = render_depth_batch([scene.getTrainCameras()[i] for i in chosen], pc, scene, pipe, args, bg_color,
+                                                         learnt_normal, nb_src_frames, buffer_length, depth_error_threshold,
+                                                         scaling_modifier, override_color)
             else:
                 src_rendered_depths = scene.rendered_depth_list[chosen]
             world_to_src = scene.world_view_transforms[chosen].to(dev)

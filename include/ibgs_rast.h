@@ -38,6 +38,7 @@ extern "C" {
 
 #define IBGS_MAX_SRC 5           /* DPR/cuda_rasterizer/auxiliary.h:22-23 (MAX_M, M) */
 #define IBGS_MAX_BUFFER_LENGTH 8 /* auxiliary.h:21 */
+#define IBGS_MAX_VIEWS 8          /* batched depth-only passes (ibgs_forward_args.n_views) */
 #define IBGS_TILE 16             /* config.h: BLOCK_X, BLOCK_Y */
 
 #define IBGS_ERR_INVALID 1  /* bad argument combination */
@@ -138,6 +139,17 @@ typedef struct ibgs_forward_args {
     const float* plane_normal;
     const float* plane_offset;
     int32_t plane_mode;
+    /* SURVEY 8(f) row 2 -- batched depth-only passes.  n_views >= 2 (<= IBGS_MAX_VIEWS) renders the median depth of
+     * n_views cameras of equal W x H in ONE pass: the views are laid out as one tall tile grid, so the depth sort, the
+     * binning and the blend each run once over n_views x P instances instead of n_views times (the reference loops
+     * render_depth over the source views, gaussian_renderer/__init__.py:245-253).  Requires render_depth_only and
+     * plane_mode != 0.  viewmatrix / projmatrix / campos hold n_views stacked blocks (n x 16, n x 16, n x 3);
+     * view_tanfovx/y the per-view values (tanfovx / tanfovy are ignored); out_depth is n_views x H x W, radii
+     * n_views x P; geom must hold ibgs_required_geom(n_views * P), img ibgs_required_img(W, n_views * 16 * ceil(H/16)).
+     * Each view's result is bit-identical to its single-view pass.  No backward. */
+    int32_t n_views;
+    float view_tanfovx[8];
+    float view_tanfovy[8];
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {

@@ -38,3 +38,27 @@ for learnt in (True, False):
             for _ in range(10): renderer.render_depth(cams[1], pc, scene, pipe, args, bg, learnt, 4, 4)
             torch.cuda.synchronize(); dd = (time.perf_counter() - t0) / 10
         print("learnt_normal=%s fused=%s: render()+backward %.3f ms, render_depth() %.3f ms" % (learnt, fused, dt * 1e3, dd * 1e3))
+
+# ---- the source-view depth passes of one test-time frame, looped vs batched ----
+renderer.FUSED_PLANE_MAP = True
+src = [cams[j] for j in cams[0].nearest_id[:4]]
+with torch.no_grad():
+    for name, fn in (("4 x render_depth()", lambda: torch.stack([renderer.render_depth(c, pc, scene, pipe, args, bg, True, 4, 4) for c in src])),
+                     ("render_depth_batch(4)", lambda: renderer.render_depth_batch(src, pc, scene, pipe, args, bg, True, 4, 4))):
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): fn()
+        torch.cuda.synchronize()
+        print("%s: %.3f ms" % (name, (time.perf_counter() - t0) / 10 * 1e3))
+    for name, batch in (("render() test-time frame, batched source depths", True), ("render() test-time frame, looped source depths", False)):
+        import ibgs_amd.renderer as R
+        orig = R.render_depth_batch
+        if not batch:
+            R.render_depth_batch = lambda cs, *a, **k: torch.stack([R.render_depth(c, *a, **k) for c in cs])
+        fn = lambda: R.render(cams[0], pc, scene, pipe, args, bg, True, 4, 4, render_geo=True, do_render_src_depth=True, return_depth_normal=False)
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): fn()
+        torch.cuda.synchronize()
+        print("%s: %.3f ms" % (name, (time.perf_counter() - t0) / 10 * 1e3))
+        R.render_depth_batch = orig
