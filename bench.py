@@ -84,13 +84,14 @@ def cpu_baseline(inp, c):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3", choices=list(syn.CONFIGS))
     ap.add_argument("--opacity", default="init", choices=["init", "trained"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="factored", choices=["factored", "dense"],
                     help="N > 1: factored = all-gather 3-float dL/dRGB per view + local SH expansion (default); dense = all-reduce of every gradient")
+    ap.add_argument("--forward-only", action="store_true", help="time the forward render alone (BASELINE configs[1]: --config C2 --forward-only)")
     ap.add_argument("--geo", action="store_true", help="second line of SURVEY 8(d): render_geo=True, n_src=4, L=4")
     a = ap.parse_args()
 
@@ -134,7 +135,15 @@ def main():
     reducer = vdist.ViewParallelReducer(params, sh=leaves["shs"], means3D=leaves["means3D"]) if (world > 1 and a.exchange == "factored") else None
     R_seen = [0]
 
+    def fwd_only():
+        with torch.no_grad():
+            rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
+                 opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
+                 all_map=leaves.get("all_map"))
+
     def step():
+        if a.forward_only:
+            return fwd_only()
         for v in leaves.values():
             v.grad = None
         outs = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
@@ -160,7 +169,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    _lib.timing_enable(["render_bwd"])          # hipEvents around the dominant kernel only, on the op's stream
+    _lib.timing_enable(["render_fwd" if a.forward_only else "render_bwd"])   # hipEvents around the dominant kernel only, on the op's stream
     _lib.timing_collect()
     fence()
     t0 = time.perf_counter()
@@ -175,6 +184,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # forward-only time of the same workload ("report fwd-only and fwd+bwd separately"), untimed for `value`
+    fence()
+    tf = time.perf_counter()
+    for _ in range(10):
+        fwd_only()
+    fence()
+    fwd_ms = (time.perf_counter() - tf) / 10 * 1e3
+
     # per-stage breakdown from a few extra (untimed) steps
     _lib.timing_enable(_lib.STAGES)
     for _ in range(3):
@@ -185,31 +202,42 @@ def main():
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
+        if a.forward_only:
+            with torch.no_grad():
+                o = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"], opacities=leaves["opacities"],
+                         shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"], all_map=leaves.get("all_map"))
+            from ibgs_amd import rasterizer as _r
+            R_seen[0] = _r.LAST_NUM_RENDERED
         R = int(R_seen[0]); HW = H * W; Mc = int(inp["shs"].shape[1]); tiles = ((W + 15) // 16) * ((H + 15) // 16)
         b_fwd, b_bwd, b_rbwd = algorithmic_bytes(P, R, HW, Mc, tiles)
-        k_ms = tm["render_bwd"][0] / max(tm["render_bwd"][1], 1)
+        kstage = "render_fwd" if a.forward_only else "render_bwd"
+        k_ms = tm[kstage][0] / max(tm[kstage][1], 1)
+        if a.forward_only:
+            b_rbwd = HW * 20 + R * 40          # the forward blend's share of B_fwd (records + per-pixel outputs)
         achieved = b_rbwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and a.config == "C3" and not (a.geo or a.forward_only or a.opacity != "init"):   # the profiled workload only
             try:
                 traffic = json.load(open(tpath)).get("render_bwd_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "train-step fps (fwd+bwd raster) @1080p, 1M Gaussians" if a.config == "C3" else "train-step fps (fwd+bwd raster) " + a.config,
+            "metric": ("forward render fps " + a.config) if a.forward_only else
+                      ("train-step fps (fwd+bwd raster) @1080p, 1M Gaussians" if a.config == "C3" else "train-step fps (fwd+bwd raster) " + a.config),
             "value": world * a.steps / dt, "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer fwd+bwd, L1 loss vs fixed random target, "
-                                   "opacity=%s%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], a.opacity, ", render_geo n_src=4 L=4" if a.geo else "",
+            "config": {"workload": "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, "
+                                   "opacity=%s%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], "forward only" if a.forward_only else "fwd+bwd, L1 loss vs fixed random target", a.opacity, ", render_geo n_src=4 L=4" if a.geo else "",
                                                                         (", RCCL gradient exchange (%s)" % a.exchange) if world > 1 else ""),
                        "num_rendered": R, "parallelism": "view-parallel x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "render_bwd_geo_kernel" if a.geo else "render_bwd_color_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "forward_only_ms": fwd_ms,
+            "roofline": {"bound": "hbm", "kernel": ("render_fwd_kernel" if a.forward_only else ("render_bwd_geo_kernel" if a.geo else "render_bwd_color_kernel")), "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
-                         "step_algorithmic_bytes": b_fwd + b_bwd,
-                         "step_frac": (b_fwd + b_bwd) / (ms_step * 1e-3) / HBM_PEAK},
+                         "step_algorithmic_bytes": b_fwd if a.forward_only else b_fwd + b_bwd,
+                         "step_frac": (b_fwd if a.forward_only else b_fwd + b_bwd) / (ms_step * 1e-3) / HBM_PEAK},
             "stages_ms": stages,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -16,6 +16,8 @@ FLAG_TEX_QUANT = 2
 FLAG_NO_TILE_CULL = 4
 FLAG_CLEAR_GRAD_ACC = 8
 FLAG_SH_FACTORED = 16
+FLAG_TILE_WAVES = 32
+FLAG_QUADRANT_WAVES = 64
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 MAX_VIEWS = 8
 

@@ -322,6 +322,8 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 // SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
 __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
 __global__ void __launch_bounds__(64) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
+// small frames (fewer tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up
+__global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_body<false, 1>(p); }
 
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
                            const ImgState& im, const float4* src_rgba)
@@ -342,6 +344,11 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         const int grid = ((nt * 4 + 7) / 8) * 8;
         hipLaunchKernelGGL(render_bwd_geo_kernel, dim3(grid), dim3(64), 0, s, p);
     } else {
+        if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {
+            hipLaunchKernelGGL(render_bwd_color_small_kernel, dim3(((nt * 4 + 7) / 8) * 8), dim3(64), 0, s, p);
+            IBGS_HIP(hipGetLastError());
+            return 0;
+        }
         const int grid = ((nt + 7) / 8) * 8;
         static const int pad = getenv("IBGS_BWD_LDS_PAD") ? atoi(getenv("IBGS_BWD_LDS_PAD")) : 0;   // occupancy experiments only
         hipLaunchKernelGGL(render_bwd_color_kernel, dim3(grid), dim3(64), pad, s, p);

@@ -20,6 +20,7 @@
 //   * CUDA layered textures do not exist on gfx950; source images are packed to RGBA float4 once per
 //     call and sampled with explicit bilinear gathers that follow the texture unit's addressing rules
 //     (unnormalised, clamp, linear).
+#include <cstdlib>
 #include "common.h"
 
 namespace ibgs {
@@ -428,8 +429,16 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
         if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), dim3(grid), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), dim3(grid), dim3(64), 0, s, p);
     } else {
-        const int grid = ((nt + 7) / 8) * 8;
-        hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), dim3(grid), dim3(64), 0, s, p);
+        // Small frames: one wave per 8x8 quadrant instead of per tile, otherwise the chip (1024 SIMDs x 8 waves) stays
+        // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).
+        const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096);
+        if (small) {
+            const int grid = ((nt * 4 + 7) / 8) * 8;
+            hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 1, 4>), dim3(grid), dim3(64), 0, s, p);
+        } else {
+            const int grid = ((nt + 7) / 8) * 8;
+            hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), dim3(grid), dim3(64), 0, s, p);
+        }
     }
     IBGS_HIP(hipGetLastError());
     return 0;

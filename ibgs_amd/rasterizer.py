@@ -32,6 +32,15 @@ TEX_QUANT = False
 # Exact tile culling (shorter per-tile lists, identical outputs).  False reproduces the reference's AABB lists.
 TILE_CULL = True
 
+# Work decomposition of the colour blend kernels: None = by frame size (one wave per 16x16 tile from 4096 tiles on,
+# one wave per 8x8 quadrant below), "tile" / "quadrant" force one of them (tests run both against the oracle).
+WAVE_SHAPE = None
+
+
+def _shape_flag():
+    return {None: 0, "tile": _lib.FLAG_TILE_WAVES, "quadrant": _lib.FLAG_QUADRANT_WAVES}[WAVE_SHAPE]
+
+
 # View-parallel training (ibgs_amd/dist.py): while a `capture_sh_factors()` block is active the backward leaves
 # dL/dsh unwritten (returns None for it) and records the per-view factors -- clamp-masked dL/dRGB (P, 3), camera
 # centre, active degree -- so that ranks exchange 3 floats per Gaussian instead of 3 M (include/ibgs_rast.h,
@@ -60,6 +69,7 @@ class capture_sh_factors:
 RENDERED_HINT = True
 RENDERED_WINDOW = 16
 _last_rendered = {}           # key -> R of the last call, or a list of recent R values
+LAST_NUM_RENDERED = 0         # diagnostic: R of the most recent forward
 LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent forward carved its binning arena for
 
 _tex_scratch = {}
@@ -226,7 +236,7 @@ class _CModule:
                 a.buffer_length = int(buffer_length); a.depth_error_threshold = float(depth_error_threshold)
                 a.prefiltered = int(bool(prefiltered)); a.render_geo = int(render_geo); a.render_depth_only = int(render_depth_only)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL))
+                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL) | _shape_flag())
                 a.geom = geomBuffer.data_ptr(); a.geom_bytes = geomBuffer.numel()
                 a.img = imgBuffer.data_ptr(); a.img_bytes = imgBuffer.numel()
                 a.binning_alloc = cb; a.binning_user = None
@@ -261,7 +271,8 @@ class _CModule:
                 hist = _last_rendered.get(hkey)
                 hist = (hist if isinstance(hist, list) else ([int(hist)] if hist else [])) + [rendered]
                 _last_rendered[hkey] = hist[-RENDERED_WINDOW:]
-                global LAST_BINNING_CAPACITY
+                global LAST_BINNING_CAPACITY, LAST_NUM_RENDERED
+                LAST_NUM_RENDERED = rendered
                 LAST_BINNING_CAPACITY = max(rendered, int(a.rendered_hint)) if a.rendered_hint else rendered
                 binningBuffer = holder.get("t", binningBuffer)
         return (rendered, out_color, radii, out_normal, out_depth, out_cam_feat, out_warped, out_min_depth_diff,
@@ -356,7 +367,7 @@ class _CModule:
                     a.dL_dplane_normal = _ptr(dL_dplane_normal); a.dL_dplane_offset = _ptr(dL_dplane_offset)
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0))
+                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag())
                 rc = lib.ibgs_backward(ctypes.byref(a))
                 if rc < 0:
                     raise RuntimeError("ibgs_backward failed (%d): %s" % (rc, _lib.last_error()))

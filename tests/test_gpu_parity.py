@@ -15,6 +15,17 @@ from tests.metrics import l1, psnr, rel_l2
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["tile", "quadrant"])
+def wave_shape(request):
+    """Every parity test runs with both work decompositions of the colour kernels (one wave per 16x16 tile / per 8x8
+    quadrant); left alone the library would pick 'quadrant' for all of these small frames."""
+    from ibgs_amd import rasterizer
+    old = rasterizer.WAVE_SHAPE
+    rasterizer.WAVE_SHAPE = request.param
+    yield request.param
+    rasterizer.WAVE_SHAPE = old
+
 L1_TOL = 1e-4          # north_star: forward renders within 1e-4 L1 per pixel
 GRAD_TOL = 1e-3        # BASELINE.md: gradient relative L2 <= 1e-3
 
