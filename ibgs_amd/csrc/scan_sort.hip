@@ -391,9 +391,12 @@ __global__ void __launch_bounds__(RS_THREADS) onesweep_pass_kernel(const uint32_
 
 // Measured on MI355X (C3): depth sort (P = 1M, 245 chunks) 0.154 -> 0.135 ms, tile sort (R = 12.5M, 3052 chunks)
 // 0.189 -> 0.254 ms: when ~1000 workgroups start together their look-back walks hundreds of AGGREGATE rows before
-// the first INCLUSIVE prefix appears.  Net loss, so it stays an opt-in experiment (IBGS_RADIX_ONESWEEP=1).
-static bool g_use_onesweep = (getenv("IBGS_RADIX_ONESWEEP") != nullptr);
-void radix_set_onesweep(bool on) { g_use_onesweep = on; }
+// the first INCLUSIVE prefix appears.  So it is used where it wins -- sorts of at most OS_AUTO_MAX_CHUNKS chunks (the
+// launch-bound depth sort: 6 launches instead of 20) -- and the hist + scan + scatter passes everywhere else.
+// IBGS_RADIX_ONESWEEP=1 / =0 forces it on / off for experiments.
+static int g_use_onesweep = getenv("IBGS_RADIX_ONESWEEP") ? atoi(getenv("IBGS_RADIX_ONESWEEP")) : -1;   // -1 = by size
+void radix_set_onesweep(bool on) { g_use_onesweep = on ? 1 : 0; }
+constexpr size_t OS_AUTO_MAX_CHUNKS = 512;
 
 static size_t onesweep_elems(size_t n)
 {
@@ -447,7 +450,8 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int npass = (nbits_total + 7) / 8;
     const int dbits = (nbits_total + npass - 1) / npass;
     const int nbins = 1 << dbits;
-    if (g_use_onesweep && !n_dev && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
+    const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
+    if (want_os && !n_dev && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
         return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
