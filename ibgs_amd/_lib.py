@@ -54,6 +54,12 @@ class ForwardArgs(ctypes.Structure):
     ]
 
 
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("numel", ctypes.c_int64), ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("eps", ctypes.c_double), ("bias_correction1", ctypes.c_double), ("bias_correction2", ctypes.c_double)]
+
+
 class BackwardArgs(ctypes.Structure):
     _fields_ = [
         ("stream", ctypes.c_void_p),
@@ -87,7 +93,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_forward", "ibgs_backward", "ibgs_mark_visible",
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
-           "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views",
+           "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -143,6 +149,8 @@ def load():
     lib.ibgs_required_knn.argtypes = [ctypes.c_int32]
     lib.ibgs_sh_grad_from_views.restype = ctypes.c_int32
     lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 4
+    lib.ibgs_adam_step.restype = ctypes.c_int32
+    lib.ibgs_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     lib.ibgs_knn_mean_dist2.restype = ctypes.c_int32
     lib.ibgs_knn_mean_dist2.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ibgs_sizeof_forward_args.restype = ctypes.c_size_t

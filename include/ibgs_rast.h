@@ -233,6 +233,19 @@ int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const f
 int32_t ibgs_sh_grad_from_views(void* stream, int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,
                                 const float* camposes, const float* dcolor, float* dL_dsh);
 
+/* Section 8(f) "next" row 4 -- the trainer's optimiser step (train.py:421-430: torch.optim.Adam over the eight Gaussian
+ * parameter groups of scene/gaussian_model.py:227-241) as ONE launch.  Update rule and operation order of
+ * torch.optim.Adam without weight decay / amsgrad; bias_correction{1,2} = 1 - beta{1,2}^step are computed by the caller.
+ * All pointers are device fp32 arrays of `numel` elements, updated in place (param, exp_avg, exp_avg_sq). */
+#define IBGS_ADAM_MAX_TENSORS 16
+typedef struct ibgs_adam_tensor {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    int64_t numel;
+    double lr, beta1, beta2, eps;                  /* as the optimiser holds them (Python floats); 1 - beta is formed in double */
+    double bias_correction1, bias_correction2;      /* 1 - beta1^step, 1 - beta2^step */
+} ibgs_adam_tensor;
+int32_t ibgs_adam_step(void* stream, int32_t n_tensors, const ibgs_adam_tensor* tensors);
+
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other
  * points (exact).  `scratch` >= ibgs_required_knn(P) bytes, caller-owned, transient. */
