@@ -321,7 +321,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 // Two entry points so that each variant gets its own register budget: the colour kernel fits 5 waves per
 // SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
 __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
-__global__ void __launch_bounds__(64) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
+__global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
 // small frames (fewer tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_body<false, 1>(p); }
 
