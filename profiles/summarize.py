@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def find(d, suffix):
     fs = glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*" + suffix))
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None      # gpurun merges runs into the same directory: take the latest
 
 
 def short(name):
@@ -38,7 +38,7 @@ def main():
     if st:
         rows = list(csv.DictReader(open(st)))
         with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"), "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (23 steps + 3 stage-timing steps)\n")
+            f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (23 steps + 3 stage-timing steps + 10 forward-only passes)\n")
             f.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
             for r in rows[:24]:
                 f.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
