@@ -53,3 +53,22 @@ def test_render_uses_the_batch_for_its_sources_and_matches_the_loop():
     assert torch.allclose(a["render"], b["render"], atol=1e-6)
     d = (a["median_intersected_depth"] - b["median_intersected_depth"]).abs().mean() / b["median_intersected_depth"].abs().mean()
     assert float(d) < 1e-3
+
+
+def test_batch_edge_cases_empty_and_everything_culled():
+    dev, pc, cams, scene, pipe, args, bg = _setup(500, 80, 48, 3, seed=1)
+    from ibgs_amd.rasterizer import rasterize_depth_batch
+    vms = torch.stack([c.world_view_transform for c in cams]); pms = torch.stack([c.full_proj_transform for c in cams])
+    cps = torch.stack([c.camera_center for c in cams])
+    tx = [math.tan(c.FoVx * 0.5) for c in cams]; ty = [math.tan(c.FoVy * 0.5) for c in cams]
+    # no Gaussians at all
+    e = torch.zeros(0, 3, device=dev)
+    d, r = rasterize_depth_batch(e, torch.zeros(0, 1, device=dev), e, torch.zeros(0, 4, device=dev), None, 1.0, vms, pms, cps, tx, ty, 48, 80, 4,
+                                 plane_mode=2)
+    assert d.shape == (3, 1, 48, 80) and not d.any() and r.shape == (3, 0)
+    # every Gaussian behind every camera: R = 0, twice (the second call runs with a rendered_hint from ... nothing)
+    far = (pc.get_xyz.detach() * 0.01 + torch.tensor([0.0, 0.0, 500.0], device=dev))
+    for _ in range(2):
+        d, r = rasterize_depth_batch(far, pc.get_opacity.detach(), pc.get_scaling.detach(), pc.get_rotation.detach(), None, 1.0, vms, pms, cps,
+                                     tx, ty, 48, 80, 4, plane_mode=2)
+        assert not r.any() and not d.any()

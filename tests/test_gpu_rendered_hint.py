@@ -65,3 +65,15 @@ def test_hint_follows_the_previous_call():
     # debug mode keeps the reference's stage-by-stage synchronous behaviour
     o3, _, _ = hipref.run_forward(inp, debug=True, requires_grad=False)
     assert rasterizer.LAST_BINNING_CAPACITY == R and torch.equal(o1["color"], o3["color"])
+
+
+def test_hint_larger_than_an_empty_result():
+    """A generous hint while nothing is visible (R = 0): kernels sized for the hint find a zero count on the device."""
+    inp = syn.make_scene(800, 96, 64, sh_degree=0, seed=3)
+    inp["means3D"] = (inp["means3D"] + np.array([0, 0, 300.0], np.float32)).astype(np.float32)
+    inp["bg"] = np.array([0.2, 0.4, 0.6], np.float32)
+    o, l, st = _run(inp, 50000)
+    assert st["R"] == 0 and int(o["color"].grad_fn.num_rendered) == 0
+    assert torch.allclose(o["color"], torch.tensor([0.2, 0.4, 0.6], device="cuda")[:, None, None].expand_as(o["color"]))
+    o["color"].sum().backward()
+    assert all(v.grad is None or not v.grad.any() for v in l.values() if v is not None)
