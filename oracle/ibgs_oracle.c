@@ -198,16 +198,17 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
     const int w = tx1 - tx0, h = ty1 - ty0;
     if (w * h > 64 || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
     uint64_t m = 0; uint32_t cnt = 0;
+    const float nbc = -B / C, nba = -B / A;      /* minimiser of q along an edge x = const / y = const, per unit of x / y */
     for (int ty = ty0; ty < ty1; ty++) for (int tx = tx0; tx < tx1; tx++) {
         const float X0 = (float)(tx * 16) - px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
         int keep;
         if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) keep = 1;
         else {
             float qmin, t, q;
-            t = clampf_(-B * X0 / C, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
-            t = clampf_(-B * X1 / C, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = q < qmin ? q : qmin;
-            t = clampf_(-B * Y0 / A, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = q < qmin ? q : qmin;
-            t = clampf_(-B * Y1 / A, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
+            t = clampf_(nbc * X0, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
+            t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = q < qmin ? q : qmin;
+            t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = q < qmin ? q : qmin;
+            t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
             keep = !(qmin > qmax);
         }
         if (keep) { m |= 1ull << ((ty - ty0) * w + (tx - tx0)); cnt++; }
