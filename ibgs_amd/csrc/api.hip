@@ -272,17 +272,18 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     else { IBGS_HIP(hipEventSynchronize(rs->ev)); R = (int64_t)*rs->host; cap = R; }
 
     const int bit = (int)higher_msb((uint32_t)(gx * gy));
+    const bool key16 = gx * gy <= 65536;          // tile ids fit 16 bits: the binning keys travel as uint16_t
     auto tail = [&](int64_t n, const uint32_t* n_dev) -> int {
         int rc;
         char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, a.H), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, a.H, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, Pn, n, gx, g, b, n_dev))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, Pn, n, gx, g, b, n_dev, key16))) return rc; }
         if ((rc = stage_check(s, debug, "emit"))) return rc;
         { StageTimer t(s, IBGS_STAGE_TILE_SORT);
-          if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)n, bit, b.hist, b.hist_elems, n_dev))) return rc; }
+          if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)n, bit, b.hist, b.hist_elems, n_dev, key16))) return rc; }
         if ((rc = stage_check(s, debug, "tile sort"))) return rc;
-        { StageTimer t(s, IBGS_STAGE_RANGES); if ((rc = launch_ranges(s, n, gx * gy, b.keys[0], im.ranges, n_dev))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_RANGES); if ((rc = launch_ranges(s, n, gx * gy, b.keys[0], im.ranges, n_dev, key16))) return rc; }
         if ((rc = stage_check(s, debug, "ranges"))) return rc;
         const float4* rgba = nullptr;
         if (a.render_geo) {

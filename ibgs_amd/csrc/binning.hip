@@ -51,12 +51,13 @@ __device__ __forceinline__ uint32_t wave_search_le(const uint32_t* __restrict__ 
     return lo;
 }
 
+template <typename K>
 __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R, const uint32_t* __restrict__ R_dev, int gx,
                                                           const uint32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ offs /* P+1 */,
                                                           const uint32_t* __restrict__ rect,
                                                           const uint64_t* __restrict__ tmask,
-                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                          K* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     __shared__ uint32_t win[EM_CHUNK + 2];
     __shared__ uint32_t jrange[2];
@@ -108,24 +109,27 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
                 k = pos;
             }
             const uint32_t ty = y0 + k / w, tx = x0 + k % w;
-            keys[s] = ty * (uint32_t)gx + tx;
+            keys[s] = (K)(ty * (uint32_t)gx + tx);
             vals[s] = id;
         }
     }
 }
 
-int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b, const uint32_t* R_dev)
+int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b, const uint32_t* R_dev, bool key16)
 {
     if (R <= 0) return 0;
     const unsigned nblocks = (unsigned)((R + EM_CHUNK - 1) / EM_CHUNK);
-    hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(EM_THREADS), 0, s, (uint32_t)P, (uint32_t)R, R_dev, gx,
-                       g.sort_val[0], g.offsets, g.rect, g.tmask, b.keys[0], b.vals[0]);
+    if (key16) hipLaunchKernelGGL(emit_kernel<uint16_t>, dim3(nblocks), dim3(EM_THREADS), 0, s, (uint32_t)P, (uint32_t)R, R_dev, gx,
+                                  g.sort_val[0], g.offsets, g.rect, g.tmask, reinterpret_cast<uint16_t*>(b.keys[0]), b.vals[0]);
+    else hipLaunchKernelGGL(emit_kernel<uint32_t>, dim3(nblocks), dim3(EM_THREADS), 0, s, (uint32_t)P, (uint32_t)R, R_dev, gx,
+                            g.sort_val[0], g.offsets, g.rect, g.tmask, b.keys[0], b.vals[0]);
     IBGS_HIP(hipGetLastError());
     return 0;
 }
 
 // identifyTileRanges, rasterizer_impl.cu:233-255 (ranges pre-zeroed by the caller)
-__global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t* __restrict__ R_dev, const uint32_t* __restrict__ keys, uint32_t* __restrict__ ranges)
+template <typename K>
+__global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t* __restrict__ R_dev, const K* __restrict__ keys, uint32_t* __restrict__ ranges)
 {
     if (R_dev) R = min(R, *R_dev);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,11 +143,12 @@ __global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t*
     if (i == R - 1) ranges[2 * cur + 1] = R;
 }
 
-int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev)
+int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev, bool key16)
 {
     IBGS_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles, s));
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, R_dev, sorted_keys, ranges);
+    if (key16) hipLaunchKernelGGL(ranges_kernel<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, R_dev, reinterpret_cast<const uint16_t*>(sorted_keys), ranges);
+    else hipLaunchKernelGGL(ranges_kernel<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, R_dev, sorted_keys, ranges);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -164,7 +164,8 @@ int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float*
 size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by radix_sort_pairs on n items
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev = nullptr);
+                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev = nullptr, bool key16 = false);
+// key16: keys[] hold uint16_t values (tile ids of frames with <= 65536 tiles)
 // Exclusive scan of `n` uint32 (in place allowed); out[n] receives the total when with_total.
 int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch,
                        size_t scratch_elems, bool with_total);
@@ -172,8 +173,8 @@ size_t scan_scratch_elems(size_t n);
 void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatter launches per pass
 
 int launch_gather_tiles(hipStream_t s, int P, const GeomState& g);   // tiles in depth order -> offsets input
-int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b, const uint32_t* R_dev = nullptr);
-int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev = nullptr);
+int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b, const uint32_t* R_dev = nullptr, bool key16 = false);
+int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev = nullptr, bool key16 = false);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,

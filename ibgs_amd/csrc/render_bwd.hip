@@ -25,7 +25,6 @@
 // (the reference uses __expf forward / exp backward) so that T/(1-alpha) retraces the
 // forward transmittance; 1/(1-alpha) is a hardware reciprocal refined by one Newton step instead of an
 // IEEE division.
-#include <cstdlib>
 #include "common.h"
 #include "wave_reduce.h"
 
@@ -350,8 +349,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             return 0;
         }
         const int grid = ((nt + 7) / 8) * 8;
-        static const int pad = getenv("IBGS_BWD_LDS_PAD") ? atoi(getenv("IBGS_BWD_LDS_PAD")) : 0;   // occupancy experiments only
-        hipLaunchKernelGGL(render_bwd_color_kernel, dim3(grid), dim3(64), pad, s, p);
+        hipLaunchKernelGGL(render_bwd_color_kernel, dim3(grid), dim3(64), 0, s, p);
     }
     IBGS_HIP(hipGetLastError());
     return 0;

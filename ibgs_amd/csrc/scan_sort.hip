@@ -129,7 +129,9 @@ int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t 
 // ------------------------------------------------------------------------------------------------
 // `n_dev` (may be NULL): the element count lives in device memory (written by an earlier kernel of the same stream);
 // the launch is then sized for the upper bound `n` and workgroups past the real count find nothing to do.
-__global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev,
+// K = uint32_t, or uint16_t for the tile sort of frames with <= 65536 tiles (a third less traffic per pass).
+template <typename K>
+__global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const K* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev,
                                                                 int shift, int nbins, uint32_t* __restrict__ hist, unsigned nblocks)
 {
     __shared__ uint32_t h[RS_MAX_BINS];
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* 
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
         const size_t idx = base + (size_t)k * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) atomicAdd(&h[((uint32_t)keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nbins; k += RS_THREADS) hist[(size_t)k * nblocks + blockIdx.x] = h[k];
@@ -150,8 +152,9 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const uint32_t* 
 // Stable scatter of one 4096-element chunk. Element order inside the chunk is
 // wave * 1024 + step * 64 + lane, i.e. each wave owns a contiguous quarter and walks it in
 // 64-element steps, so (earlier wave, earlier step, lower lane) == earlier input position.
-__global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+template <typename K>
+__global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                   K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                    size_t n, const uint32_t* __restrict__ n_dev, int shift, int nbits, int nbins,
                                                                    const uint32_t* __restrict__ hist_scanned, unsigned nblocks)
 {
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
     for (int k = 0; k < RS_ITEMS; k++) {
         const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
         const bool valid = idx < n;
-        key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        key[k] = valid ? (uint32_t)keys_in[idx] : 0xFFFFFFFFu;
         val[k] = valid ? vals_in[idx] : 0u;
         const uint32_t d = (key[k] >> shift) & mask;
         // match-any over the digit bits
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
             const uint32_t kk = skey[l];
             const uint32_t d = (kk >> shift) & mask;
             const uint32_t dst = l + delta[d];     // wraps correctly in uint32 arithmetic
-            keys_out[dst] = kk;
+            keys_out[dst] = (K)kk;
             vals_out[dst] = sval[l];
         }
     }
@@ -443,7 +446,7 @@ size_t radix_hist_elems(size_t n)
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev)
+                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev, bool key16)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -451,7 +454,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int dbits = (nbits_total + npass - 1) / npass;
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
-    if (want_os && !n_dev && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
+    if (want_os && !n_dev && !key16 && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
         return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
@@ -460,17 +463,20 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
         const int shift = pass * dbits;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, n_dev, shift, nbins, hist, nblocks);
+        if (key16) hipLaunchKernelGGL(radix_hist_kernel<uint16_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, reinterpret_cast<const uint16_t*>(keys[cur]), n, n_dev, shift, nbins, hist, nblocks);
+        else hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, n_dev, shift, nbins, hist, nblocks);
         IBGS_HIP(hipGetLastError());
         int rc = exclusive_scan_u32(s, hist, hist, hist_n, scan_scratch, scan_elems, false);
         if (rc) return rc;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
-                           n, n_dev, shift, dbits, nbins, hist, nblocks);
+        if (key16) hipLaunchKernelGGL(radix_scatter_kernel<uint16_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, reinterpret_cast<const uint16_t*>(keys[cur]), vals[cur],
+                                      reinterpret_cast<uint16_t*>(keys[cur ^ 1]), vals[cur ^ 1], n, n_dev, shift, dbits, nbins, hist, nblocks);
+        else hipLaunchKernelGGL(radix_scatter_kernel<uint32_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                                n, n_dev, shift, dbits, nbins, hist, nblocks);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
     if (cur != 0) {   // odd number of passes: bring the result back to buffer 0
-        IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * (key16 ? sizeof(uint16_t) : sizeof(uint32_t)), hipMemcpyDeviceToDevice, s));
         IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     return 0;
