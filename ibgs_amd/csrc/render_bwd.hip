@@ -174,6 +174,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];
             const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
+            const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
             // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist (= grad_acc columns)
             float v[NV];
 #pragma unroll
@@ -193,13 +194,12 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
-                // power > 0 <=> p2 < 0;  min(0.99, oG) < 1/255 <=> oG < 1/255: same decisions as the forward, fewer instructions
-                const float G = __builtin_amdgcn_exp2f(p2q[q] * NHL2E);
-                const float oG = op * G;
-                const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(!(p2q[q] < 0.0f)) &
-                                     __builtin_amdgcn_ballot_w64(!(oG < 1.0f / 255.0f));
+                // the forward's test: 0 <= p2 <= 2 ln(255 o) as one unsigned compare of the float bits (render_fwd.hip)
+                const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(__float_as_uint(p2q[q]) < qbound);
                 if (okm != 0ull) {
                     any = true;
+                    const float G = __builtin_amdgcn_exp2f(p2q[q] * NHL2E);
+                    const float oG = op * G;
                     const float alpha = min_099(oG);
                     // Colour variant: no per-lane branch.  Lanes that fail the test run the same instructions with
                     // alpha = o G = 0, which leaves T and S unchanged (1/(1-0) = 1 exactly) and adds zeros.

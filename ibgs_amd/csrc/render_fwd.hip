@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];          // normal
             const int e = base + j;
+            const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
             // p2 = d^T conic d = -2 * power.  With 4 pixels per lane the quadratic form is evaluated once for the
             // lane's pixel in quadrant 0 and shifted to the other three (pixel offsets (8,0), (0,8), (8,8)):
             // p2(d - s) = p2(d) - 2 s^T conic d + s^T conic s -- 14 VALU ops for four pixels instead of 32.
@@ -209,16 +210,18 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             for (int q = 0; q < PPL; q++) {
                 if (live[q] == 0ull) continue;                        // wave-uniform: quadrant finished
                 const float p2 = p2q[q];                              // = -2 * power
-                const float G = __builtin_amdgcn_exp2f(p2 * NHL2E);
-                const float alpha = fminf(0.99f, q0.z * G);
-                // one ballot per compare: a ballot of an AND of compares is lowered through a VGPR 0/1 round trip
-                uint64_t m = __builtin_amdgcn_ballot_w64(!(p2 < 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & live[q];
+                // "power > 0" (p2 < 0) and "alpha < 1/255" (p2 > 2 ln(255 o)) in ONE unsigned compare of the float bits against
+                // the per-Gaussian bound from preprocess: a negative p2 has the sign bit set and compares as huge.  No exp, no
+                // multiply for quadrants that nobody passes.
+                uint64_t m = __builtin_amdgcn_ballot_w64(__float_as_uint(p2) < qbound) & live[q];
                 if (DEPTH) {
                     const uint64_t running = __builtin_amdgcn_ballot_w64(e >= resume[q]) & live[q];
                     if (__builtin_amdgcn_inverse_ballot_w64(running)) cnt[q]++;
                     m &= running;
                 }
                 if (m == 0ull) continue;                              // wave-uniform: nobody sees this Gaussian
+                const float G = __builtin_amdgcn_exp2f(p2 * NHL2E);
+                const float alpha = fminf(0.99f, q0.z * G);
                 const float aeff = __builtin_amdgcn_inverse_ballot_w64(m) ? alpha : 0.f;
                 float aT = aeff * T[q];
                 float test_T = T[q] * (1.0f - aeff);

@@ -50,8 +50,8 @@ def test_results_do_not_depend_on_the_hint(cfg):
             assert torch.equal(o[k], base_o[k]), (k, prev)
         (o["color"] * g).sum().backward()
         for k in ("means3D", "opacities", "scales"):
-            a, b = l[k].grad, base_l[k].grad
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max()) + 1e-12), (k, prev)
+            a, b = l[k].grad, base_l[k].grad          # same lists, same images; only the float-atomic summation order differs
+            assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-5, (k, prev)
 
 
 def test_hint_follows_the_previous_call():
