@@ -148,7 +148,7 @@ def load():
     lib.ibgs_required_knn.restype = ctypes.c_size_t
     lib.ibgs_required_knn.argtypes = [ctypes.c_int32]
     lib.ibgs_sh_grad_from_views.restype = ctypes.c_int32
-    lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 4
+    lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     lib.ibgs_adam_step.restype = ctypes.c_int32
     lib.ibgs_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     lib.ibgs_knn_mean_dist2.restype = ctypes.c_int32

@@ -352,12 +352,14 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
 }
 
 int32_t ibgs_sh_grad_from_views(void* stream, int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,
-                                const float* camposes, const float* dcolor, float* dL_dsh)
+                                const float* camposes, const float* dcolor, int64_t view_stride, float* dL_dsh)
 {
+    if (view_stride == 0) view_stride = (int64_t)P * 3;
+    if (view_stride < (int64_t)P * 3) { set_error("view_stride smaller than P x 3"); return -IBGS_ERR_INVALID; }
     if (P <= 0 || M <= 0) return 0;
     if (D < 0 || D > 3 || (D + 1) * (D + 1) > M || n_views < 0) { set_error("bad SH degree / view count"); return -IBGS_ERR_INVALID; }
     if (!means3D || !dL_dsh || (n_views > 0 && (!camposes || !dcolor))) { set_error("null pointer"); return -IBGS_ERR_INVALID; }
-    return launch_sh_grad_from_views(reinterpret_cast<hipStream_t>(stream), P, D, M, n_views, means3D, camposes, dcolor, dL_dsh);
+    return launch_sh_grad_from_views(reinterpret_cast<hipStream_t>(stream), P, D, M, n_views, means3D, camposes, dcolor, (size_t)view_stride, dL_dsh);
 }
 
 int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

@@ -183,7 +183,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
                            const ImgState& im, const float4* src_rgba);
 int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g);
 int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, const float* means3D, const float* camposes,
-                              const float* dcolor, float* dL_dsh);
+                              const float* dcolor, size_t view_stride, float* dL_dsh);
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pack_rect(int lo, int hi) { return (uint32_t)lo | ((uint32_t)hi << 16); }

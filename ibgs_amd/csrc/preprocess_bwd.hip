@@ -389,7 +389,7 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
 // One thread per Gaussian; views in index order on every rank, so all ranks hold bit-identical sums.
 // M == 16: the 192-B rows leave through the same LDS transpose as preprocess_bwd_kernel<true, true>.
 template <bool FAST16>
-__global__ void __launch_bounds__(FAST16 ? 64 : 256) sh_grad_from_views_kernel(int P, int D, int M, int n_views, const float* __restrict__ means3D,
+__global__ void __launch_bounds__(FAST16 ? 64 : 256) sh_grad_from_views_kernel(int P, int D, int M, int n_views, size_t view_stride, const float* __restrict__ means3D,
                                                                                 const float* __restrict__ camposes, const float* __restrict__ dcolor,
                                                                                 float* __restrict__ dL_dsh)
 {
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) sh_grad_from_views_kernel(i
     if (i < P) {
         const float mx = means3D[3 * i], my = means3D[3 * i + 1], mz = means3D[3 * i + 2];
         for (int v = 0; v < n_views; v++) {
-            const float* g = dcolor + ((size_t)v * P + i) * 3;
+            const float* g = dcolor + (size_t)v * view_stride + (size_t)i * 3;
             const float g0 = g[0], g1 = g[1], g2 = g[2];
             const float dx = mx - camposes[3 * v], dy = my - camposes[3 * v + 1], dz = mz - camposes[3 * v + 2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -436,10 +436,10 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) sh_grad_from_views_kernel(i
 }
 
 int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, const float* means3D, const float* camposes,
-                              const float* dcolor, float* dL_dsh)
+                              const float* dcolor, size_t view_stride, float* dL_dsh)
 {
-    if (M == 16) hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3((P + 63) / 64), dim3(64), 0, s, P, D, M, n_views, means3D, camposes, dcolor, dL_dsh);
-    else hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, n_views, means3D, camposes, dcolor, dL_dsh);
+    if (M == 16) hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3((P + 63) / 64), dim3(64), 0, s, P, D, M, n_views, view_stride, means3D, camposes, dcolor, dL_dsh);
+    else hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, s, P, D, M, n_views, view_stride, means3D, camposes, dcolor, dL_dsh);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -135,14 +135,17 @@ class ViewParallelReducer:
         if expand is None:
             from .shgrad import sh_grad_from_views as expand
         degree, M = items[0]["degree"], items[0]["M"]
-        dcolor = torch.stack([it["dcolor"] for it in items])                   # (n_local, P, 3)
-        campos = torch.stack([it["campos"].to(dcolor.device) for it in items])  # (n_local, 3)
+        n_local, P = len(items), int(items[0]["dcolor"].shape[0])
+        # one buffer per exchange: each view's (P, 3) factor followed by its camera centre -> ONE all-gather
+        buf = torch.empty(n_local, P + 1, 3, dtype=torch.float32, device=items[0]["dcolor"].device)
+        for i, it in enumerate(items):
+            buf[i, :P] = it["dcolor"]
+            buf[i, P] = it["campos"].to(buf.device)
         if world > 1:
-            all_d = torch.empty((world * dcolor.shape[0],) + tuple(dcolor.shape[1:]), dtype=dcolor.dtype, device=dcolor.device)
-            all_c = torch.empty((world * campos.shape[0], 3), dtype=campos.dtype, device=campos.device)
-            dist.all_gather_into_tensor(all_d, dcolor.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(all_c, campos.contiguous(), group=self.group)
-            dcolor, campos = all_d, all_c
+            allb = torch.empty(world * n_local, P + 1, 3, dtype=buf.dtype, device=buf.device)
+            dist.all_gather_into_tensor(allb, buf, group=self.group)
+            buf = allb
+        dcolor, campos = buf[:, :P], buf[:, P].contiguous()      # dcolor keeps the (P + 1) * 3 view stride
         g = expand(self.means3D.detach(), campos, dcolor, degree, M)
         if average:
             g = g / world

@@ -229,9 +229,11 @@ int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const f
 /* View-parallel step, SURVEY 8(e): dL_dsh[i][k][c] = sum over views v of basis_k(normalise(means3D[i] - camposes[v]))
  * * dcolor[v][i][c] for k < (D+1)^2, zero for the other coefficients; dL_dsh (P x M x 3) is fully overwritten.
  * `dcolor` = the dL_dcolors outputs of n_views ibgs_backward calls made with IBGS_FLAG_SH_FACTORED, stacked
- * (n_views x P x 3); `camposes` = their camera centres (n_views x 3).  No reference counterpart (single GPU). */
+ * (n_views x P x 3, view v starting at dcolor + v * view_stride floats; view_stride = 0 means P * 3); `camposes` = their
+ * camera centres (n_views x 3).  A stride > P * 3 lets an exchange carry per-view extras (e.g. the camera centre) behind
+ * each view's block in ONE all-gather.  No reference counterpart (single GPU). */
 int32_t ibgs_sh_grad_from_views(void* stream, int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,
-                                const float* camposes, const float* dcolor, float* dL_dsh);
+                                const float* camposes, const float* dcolor, int64_t view_stride, float* dL_dsh);
 
 /* Section 8(f) "next" row 4 -- the trainer's optimiser step (train.py:421-430: torch.optim.Adam over the eight Gaussian
  * parameter groups of scene/gaussian_model.py:227-241) as ONE launch.  Update rule and operation order of
