@@ -113,7 +113,8 @@ def _check_lists(ist, depths):
     order = np.argsort(nz[:, 0])
     assert nz[order][0, 0] == 0 and nz[order][-1, 1] == ist["R"] and np.array_equal(nz[order][1:, 0], nz[order][:-1, 1])
     pl = ist["point_list"].astype(np.int64)
-    key = depths.view(np.uint32)[pl].astype(np.int64) * (1 << 21) + pl          # (depth bits, id) composite
+    assert pl.size == 0 or int(pl.max()) < (1 << 26)
+    key = depths.view(np.uint32)[pl].astype(np.int64) * (1 << 26) + pl          # (depth bits, id) composite: 31 + 26 bits
     inc = key[1:] > key[:-1]
     starts = np.zeros(ist["R"], bool); starts[nz[:, 0]] = True
     assert np.all(inc | starts[1:]), "a tile list is not sorted by (depth, index)"
