@@ -6,7 +6,8 @@
 // into five separate arrays.  On MI355X global float atomics run at ~1.3 TB/s chip-wide only when
 // they arrive as contiguous 64-byte requests (MI355X_MICROARCH.md "Global float atomics"), so here:
 //
-//   * one wave owns a 16x16 tile (PPL = 4) or an 8x8 quadrant (PPL = 1, geo variant); a lane first
+//   * one wave owns a 16x16 tile (PPL = 4) or an 8x8 quadrant (PPL = 1: geo variant, and the colour variant on
+//     frames with fewer than 4096 tiles, where tiles alone would leave the chip mostly empty); a lane first
 //     sums its own pixels' contributions in registers;
 //   * what is summed per pixel are MOMENTS of q = o*G*dL/dalpha -- sum q, q dx, q dy, q dx^2, q dx dy,
 //     q dy^2, |q lx|, |q ly| -- instead of the reference's eight final quantities; the per-Gaussian
@@ -15,13 +16,14 @@
 //   * the 16 per-lane partial sums are reduced over the 64 lanes with a butterfly TRANSPOSE-reduce
 //     (v_permlane32_swap, v_permlane16_swap, DPP row rotates / mirrors, quad_perm): 31 VALU ops for the 12 values of
 //     the colour variant (40 for 16), after which one lane per value holds its wave total -- no LDS traffic;
-//   * the wave then issues ONE atomic instruction per Gaussian: 16 lanes add the 16 floats of that
+//   * the wave then issues ONE atomic instruction per Gaussian: 11 (colour) / 15 (geo) lanes add their totals to that
 //     Gaussian's 64-byte accumulation row (grad_acc[P][16]) -- one 64-byte memory-side request per
 //     (Gaussian, tile) instead of 11-16 scattered dword atomics per (Gaussian, pixel);
 //   * Gaussians that no pixel of the wave uses (ballot == 0, or behind every pixel's last contributor)
 //     cost a few VALU instructions and no memory traffic.
 //
-// Deviations (documented in DESIGN.md): alpha is recomputed with the same fast exp2 as the forward
+// Deviations (documented in DESIGN.md): the skip tests are the forward's single compare of p2 against the per-Gaussian
+// bound 2 ln(255 o) (render_fwd.hip), so both passes visit exactly the same (pixel, Gaussian) pairs; alpha is recomputed with the same fast exp2 as the forward
 // (the reference uses __expf forward / exp backward) so that T/(1-alpha) retraces the
 // forward transmittance; 1/(1-alpha) is a hardware reciprocal refined by one Newton step instead of an
 // IEEE division.

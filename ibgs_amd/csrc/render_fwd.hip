@@ -11,8 +11,9 @@
 //   * Gaussian records (64 B, written by preprocess) are staged 64 at a time into LDS with 16-byte
 //     per-lane loads and read back as wave-uniform broadcasts (ds_read_b128), i.e. 3 LDS reads per
 //     Gaussian per 256 pixels.
-//   * Each quadrant is skipped with a wave-uniform branch when no lane has alpha >= 1/255 (ballot),
-//     which recovers 8x8 sub-tile culling without changing any result.  "Pixel still blending" is a
+//   * Each quadrant is skipped with a wave-uniform branch when no lane passes the alpha test (ballot), which
+//     recovers 8x8 sub-tile culling.  The test itself is one unsigned compare of the quadratic form's float bits
+//     against a per-Gaussian bound (0 <= p2 <= 2 ln(255 o), from preprocess): no exp for pairs that fail.  "Pixel still blending" is a
 //     64-bit lane mask kept in SGPRs (one per quadrant): masks are combined on the scalar unit and
 //     turned back into predicates with inverse_ballot, so the blend itself is branch-free VALU code and
 //     a finished quadrant costs one scalar compare per Gaussian.
@@ -20,7 +21,6 @@
 //   * CUDA layered textures do not exist on gfx950; source images are packed to RGBA float4 once per
 //     call and sampled with explicit bilinear gathers that follow the texture unit's addressing rules
 //     (unnormalised, clamp, linear).
-#include <cstdlib>
 #include "common.h"
 
 namespace ibgs {
