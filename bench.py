@@ -233,7 +233,7 @@ def main():
                                                                         (", RCCL gradient exchange (%s)" % a.exchange) if world > 1 else ""),
                        "num_rendered": R, "parallelism": "view-parallel x%d" % world},
             "forward_only_ms": fwd_ms,
-            "roofline": {"bound": "hbm", "kernel": ("render_fwd_kernel" if a.forward_only else ("render_bwd_geo_kernel" if a.geo else "render_bwd_color_kernel")), "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("render_fwd_kernel" if a.forward_only else (("render_bwd_geo2_kernel" if tiles >= 4096 else "render_bwd_geo_kernel") if a.geo else ("render_bwd_color_kernel" if tiles >= 4096 else "render_bwd_color_small_kernel"))), "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
                          "step_algorithmic_bytes": b_fwd if a.forward_only else b_fwd + b_bwd,

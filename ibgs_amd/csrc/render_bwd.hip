@@ -102,11 +102,12 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
     // the lane that ends up with the wave total of grad_acc column `col` after the reduce (-1: none)
     int col = GEO ? reduce16_column(lane) : reduce12_column(lane);
     if (col >= (GEO ? 15 : 11)) col = -1;
-    const int nitems = p.ntiles * (PPL == 4 ? 1 : 4);
+    constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
+    const int nitems = p.ntiles * IPT;
     const int item = xcd_band_map_b(blockIdx.x, nitems);
     if (item >= nitems) return;
-    const int tile = (PPL == 4) ? item : (item >> 2);
-    const int quad0 = (PPL == 4) ? 0 : (item & 3);
+    const int tile = item / IPT;
+    const int quad0 = (item % IPT) * PPL;
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
     const size_t HW = (size_t)W * H;
@@ -189,8 +190,8 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
             const float P0 = dx0 * lx0 + dy0 * ly0;
             float p2q[PPL];
             p2q[0] = P0;
+            if (PPL >= 2) p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
             if (PPL == 4) {
-                p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
                 p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
                 p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
             }
@@ -210,8 +211,8 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                     const float alpha_s = SEL ? select_or_zero(okm, alpha) : alpha;
                     if (SEL || ok) {
                         // only the moments need d and conic*d per quadrant; the lane's other pixels sit 8 px right / down
-                        const float dx = (PPL == 4) ? dx0 - ((q & 1) ? 8.0f : 0.0f) : q0.x - pxf[q];
-                        const float dy = (PPL == 4) ? dy0 - ((q >> 1) ? 8.0f : 0.0f) : q0.y - pyf[q];
+                        const float dx = (PPL >= 2) ? dx0 - ((q & 1) ? 8.0f : 0.0f) : q0.x - pxf[q];
+                        const float dy = (PPL >= 2) ? dy0 - ((q >> 1) ? 8.0f : 0.0f) : q0.y - pyf[q];
                         const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
                         const float rinv = fast_rcp(1.f - alpha_s);
                         T[q] = T[q] * rinv;
@@ -323,6 +324,8 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 // SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
 __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
 __global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
+// geo on large frames: one wave per half tile (quadrant pairs 0-1 / 2-3), 128 VGPRs, 4 waves per SIMD
+__global__ void __launch_bounds__(64, 4) render_bwd_geo2_kernel(BwdParams p) { render_bwd_body<true, 2>(p); }
 // small frames (fewer tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_body<false, 1>(p); }
 
@@ -342,8 +345,10 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.gacc = a.grad_acc;
     const int nt = p.ntiles;
     if (a.render_geo) {
-        const int grid = ((nt * 4 + 7) / 8) * 8;
-        hipLaunchKernelGGL(render_bwd_geo_kernel, dim3(grid), dim3(64), 0, s, p);
+        // geo: half tiles (two quadrants per lane: half the per-Gaussian overhead and reductions) on large frames
+        const bool half = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
+        if (half) hipLaunchKernelGGL(render_bwd_geo2_kernel, dim3(((nt * 2 + 7) / 8) * 8), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL(render_bwd_geo_kernel, dim3(((nt * 4 + 7) / 8) * 8), dim3(64), 0, s, p);
     } else {
         if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {
             hipLaunchKernelGGL(render_bwd_color_small_kernel, dim3(((nt * 4 + 7) / 8) * 8), dim3(64), 0, s, p);

@@ -113,11 +113,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     __shared__ float4 s_rec[NQ][WAVE];
 
     const int lane = threadIdx.x;
-    const int nitems = p.ntiles * (PPL == 4 ? 1 : 4);
+    constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
+    const int nitems = p.ntiles * IPT;
     const int item = xcd_band_map(blockIdx.x, nitems);
     if (item >= nitems) return;
-    const int tile = (PPL == 4) ? item : (item >> 2);
-    const int quad0 = (PPL == 4) ? 0 : (item & 3);
+    const int tile = item / IPT;
+    const int quad0 = (item % IPT) * PPL;
     const int W = p.cam.W, H = p.cam.H;
     int trow = tile / p.cam.gx, view = 0;
     if (DEPTH && p.n_views > 1) { view = trow / p.gyv; trow -= view * p.gyv; }      // which camera's grid this tile belongs to
@@ -148,7 +149,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 
     // geo / depth-only state (PPL == 1 for GEO; DEPTH keeps running sums only plus the ring)
     float Nacc[PPL][3];
-    float bd[PPL][MAXL], bw[PPL][MAXL]; uint32_t bc[PPL][MAXL];
+    // Median ring buffer (weight, contributor position [, depth]).  The geo pass (one pixel per lane) keeps it in a per-lane
+    // LDS column: a slot is then written / read with ONE indexed LDS access instead of MAXL compare-and-select rounds over
+    // registers.  The depth-only pass (four pixels per lane, 8 waves per SIMD) cannot afford 12 KB of LDS and keeps registers.
+    constexpr bool RING_LDS = GEO && PPL <= 2;
+    __shared__ float s_bw[RING_LDS ? PPL : 1][RING_LDS ? MAXL : 1][RING_LDS ? WAVE : 1];
+    __shared__ uint32_t s_bc[RING_LDS ? PPL : 1][RING_LDS ? MAXL : 1][RING_LDS ? WAVE : 1];
+    float bd[PPL][RING_LDS ? 1 : MAXL], bw[PPL][RING_LDS ? 1 : MAXL]; uint32_t bc[PPL][RING_LDS ? 1 : MAXL];
     int before_ptr[PPL], below_count[PPL];
     float tot_w[PPL], wd_sum[PPL];
     int resume[PPL]; uint32_t cnt[PPL];
@@ -161,7 +168,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         for (int q = 0; q < PPL; q++) {
             Nacc[q][0] = Nacc[q][1] = Nacc[q][2] = 0.f;
 #pragma unroll
-            for (int s = 0; s < MAXL; s++) { bd[q][s] = 0.f; bw[q][s] = 0.f; bc[q][s] = 0u; }
+            for (int s = 0; s < MAXL; s++) {
+                if (RING_LDS) { s_bw[q][s][lane] = 0.f; s_bc[q][s][lane] = 0u; }
+                else if (s < (RING_LDS ? 1 : MAXL)) { bd[q][s] = 0.f; bw[q][s] = 0.f; bc[q][s] = 0u; }
+            }
             before_ptr[q] = 0; below_count[q] = 0; tot_w[q] = 0.f; wd_sum[q] = 0.f; resume[q] = 0; cnt[q] = 0;
             rayx[q] = (pxf[q] - cx) / fx; rayy[q] = (pyf[q] - cy) / fy;
         }
@@ -201,8 +211,8 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             const float P0 = dx0 * lx0 + dy0 * ly0;
             float p2q[PPL];
             p2q[0] = P0;
+            if (PPL >= 2) p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * q1.x);
             if (PPL == 4) {
-                p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * q1.x);
                 p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
                 p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * q1.y + 64.0f * q1.z));
             }
@@ -244,7 +254,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     float dep = 0.f;
                     if (DEPTH) dep = -q1.w / denom;
                     if (GEO) { Nacc[q][0] += q3.x * aT; Nacc[q][1] += q3.y * aT; Nacc[q][2] += q3.z * aT; }
-                    const bool pos = DEPTH ? (dep > 0.0f) : ((q1.w > 0.f && denom < 0.f) || (q1.w < 0.f && denom > 0.f));
+                    const bool pos = DEPTH ? (dep > 0.0f) : (q1.w * denom < 0.0f);       // sign of -dist / denom (|dist * denom| cannot underflow: |denom| >= 1e-8)
                     const bool hit = acc && pos;
                     const bool front = T[q] > 0.5f;
                     int slot = -1;
@@ -253,13 +263,16 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     if (DEPTH && slot >= 0 && front) {
                         float oldw = 0.f, oldd = 0.f;
 #pragma unroll
-                        for (int s = 0; s < MAXL; s++) if (s == slot) { oldw = bw[q][s]; oldd = bd[q][s]; }
+                        for (int s = 0; s < (RING_LDS ? 1 : MAXL); s++) if (s == slot) { oldw = bw[q][s]; oldd = bd[q][s]; }
                         tot_w[q] -= oldw; wd_sum[q] -= oldw * oldd;
                     }
                     if (slot >= 0) {
+                        if (RING_LDS) { s_bw[q][slot][lane] = aT; s_bc[q][slot][lane] = contributor; }
+                        else {
 #pragma unroll
-                        for (int s = 0; s < MAXL; s++) if (s == slot) { if (DEPTH) bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
-                        if (front) before_ptr[q] = (before_ptr[q] + 1) % before_cap;
+                            for (int s = 0; s < (RING_LDS ? 1 : MAXL); s++) if (s == slot) { if (DEPTH) bd[q][s] = dep; bw[q][s] = aT; bc[q][s] = contributor; }
+                        }
+                        if (front) { const int nb = before_ptr[q] + 1; before_ptr[q] = (nb == before_cap) ? 0 : nb; }   // (ptr + 1) % cap without a division
                         else below_count[q]++;
                         if (DEPTH) { tot_w[q] += aT; wd_sum[q] += aT * dep; }
                     }
@@ -305,11 +318,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             float tw_src[IBGS_MAX_SRC], wc[IBGS_MAX_SRC][3];
 #pragma unroll
             for (int si = 0; si < IBGS_MAX_SRC; si++) { tw_src[si] = 0.f; wc[si][0] = wc[si][1] = wc[si][2] = 0.f; }
-            uint32_t lo = bc[q][0], hi = bc[q][0];     // Q4: slot 0 even when empty
+            uint32_t lo = RING_LDS ? s_bc[q][0][lane] : bc[q][0], hi = lo;     // Q4: slot 0 even when empty
             for (int s = 0; s < L; s++) {
                 float w = 0.f, d = 0.f; uint32_t c = 0;
 #pragma unroll
-                for (int k = 0; k < MAXL; k++) if (k == s) { w = bw[q][k]; c = bc[q][k]; }
+                for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (!RING_LDS && k == s) { w = bw[q][k]; c = bc[q][k]; }
+                if (RING_LDS) { w = s_bw[q][s][lane]; c = s_bc[q][s][lane]; }
                 if (w == 0.0f) continue;
                 {   // depth of buffered contributor c (1-based list position): same expression as the blend loop would use
                     const uint32_t gid = p.point_list[r0 + c - 1u];
@@ -429,7 +443,10 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     } else if (a.render_geo) {
         const int items = nt * 4;
         const int grid = ((items + 7) / 8) * 8;
-        if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), dim3(grid), dim3(64), 0, s, p);
+        // geo: half tiles (two quadrants per lane) on large frames, single quadrants on small ones; IBGS_FLAG_*_WAVES force either
+        const bool half = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
+        if (half && a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), dim3(((nt * 2 + 7) / 8) * 8), dim3(64), 0, s, p);
+        else if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), dim3(grid), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), dim3(grid), dim3(64), 0, s, p);
     } else {
         // Small frames: one wave per 8x8 quadrant instead of per tile, otherwise the chip (1024 SIMDs x 8 waves) stays

@@ -58,8 +58,9 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
 #define IBGS_FLAG_NO_TILE_CULL 4u /* emit the reference's full AABB tile lists (rasterizer_impl.cu:205-225) instead of
                                      dropping tiles that provably fail the alpha >= 1/255 test; outputs are identical */
 
-#define IBGS_FLAG_TILE_WAVES 32u     /* colour kernels: always one wave per 16x16 tile (default: only when the frame has >= 4096 tiles) */
-#define IBGS_FLAG_QUADRANT_WAVES 64u /* colour kernels: always one wave per 8x8 quadrant (default for small frames, fills the chip) */
+#define IBGS_FLAG_TILE_WAVES 32u     /* blend kernels: always the coarse decomposition -- one wave per 16x16 tile (colour) or per half
+                                        tile (geo); default: only when the frame has >= 4096 tiles */
+#define IBGS_FLAG_QUADRANT_WAVES 64u /* blend kernels: always one wave per 8x8 quadrant (default for small frames, fills the chip) */
 
 #define IBGS_PLANE_NONE 0
 #define IBGS_PLANE_LEARNT 1
