@@ -108,7 +108,10 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
                 }
                 k = pos;
             }
-            const uint32_t ty = y0 + k / w, tx = x0 + k % w;
+            // k / w and k % w without an integer division: (k + 0.5) / w is at least 0.5 / w away from an integer, far more
+            // than the error of the hardware reciprocal (k < 2^17, w <= 512)
+            const uint32_t row = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+            const uint32_t ty = y0 + row, tx = x0 + (k - row * w);
             keys[s] = (K)(ty * (uint32_t)gx + tx);
             vals[s] = id;
         }
