@@ -149,7 +149,7 @@ def main():
         outs = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
                     opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
                     all_map=leaves.get("all_map"))
-        loss = (outs[0] - target).abs().mean()
+        loss = torch.nn.functional.l1_loss(outs[0], target)
         if a.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
             loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
         R_seen[0] = outs[0].grad_fn.num_rendered
