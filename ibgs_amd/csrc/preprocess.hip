@@ -62,7 +62,9 @@ __device__ __forceinline__ float ln_portable(float x)
     return (float)e * 0.6931472f + 2.0f * s * poly;
 }
 
-__device__ __forceinline__ float clampf_(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// median of (v, lo, hi) == the oracle's v < lo ? lo : (v > hi ? hi : v) for lo <= hi and finite v: a pure selection, so the
+// values (and the masks) stay bit-identical; one v_med3_f32 instead of two compare + select pairs
+__device__ __forceinline__ float clampf_(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
 __device__ uint32_t tile_cull(float px, float py, float sxx, float syy, float A, float B, float C, float o,
                               int& x0, int& y0, int& x1, int& y1, uint64_t& mask)
@@ -89,9 +91,9 @@ __device__ uint32_t tile_cull(float px, float py, float sxx, float syy, float A,
             else {
                 float qmin, t, q;
                 t = clampf_(nbc * X0, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
-                t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = q < qmin ? q : qmin;
-                t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = q < qmin ? q : qmin;
-                t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
+                t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = __builtin_fminf(q, qmin);
+                t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = __builtin_fminf(q, qmin);
+                t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = __builtin_fminf(q, qmin);
                 keep = !(qmin > qmax);
             }
             if (keep) { m |= 1ull << ((ty - ty0) * w + (tx - tx0)); cnt++; }
