@@ -65,3 +65,25 @@ K = torch.tensor([[300.0, 0, 14.0], [0, 310.0, 10.0], [0, 0, 1]])
 n = normal_from_depth_image(depth, K, torch.eye(4))
 np.savez_compressed(os.path.join(HERE, "depth_normal.npz"), depth=depth.numpy(), K=K.numpy(), normal=n.numpy())
 print("golden fixtures written to", HERE)
+
+# ---- 3D covariance (gaussian_model.py:38-42 + utils/general_utils.py:67-120) -------------------------------------
+# build_rotation / build_scaling_rotation / strip_symmetric allocate with device="cuda"; there is no GPU in the build
+# container, so the allocation calls are pointed at the CPU for the duration of this section -- the arithmetic is the
+# reference's own.  Pins the oracle's computeCov3D restatement (forward.cu:118-153 does the same product on the GPU) and the
+# renderer's `get_covariance` convention (row-major upper triangle xx, xy, xz, yy, yz, zz).
+import utils.general_utils as gu  # noqa: E402
+
+_zeros = torch.zeros
+torch.zeros = lambda *a, **k: _zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+try:
+    scal = torch.tensor(np.exp(rng.normal(-2.0, 1.0, size=(96, 3))).astype(np.float32))
+    quat = torch.tensor(rng.normal(size=(96, 4)).astype(np.float32))          # NOT normalised: build_rotation normalises
+    cov = {}
+    for mod in (1.0, 0.5):
+        L = gu.build_scaling_rotation(mod * scal, quat)
+        cov["cov6_mod%g" % mod] = gu.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+    cov["rotmat"] = gu.build_rotation(quat).numpy()
+finally:
+    torch.zeros = _zeros
+np.savez_compressed(os.path.join(HERE, "cov3d.npz"), scales=scal.numpy(), quats=quat.numpy(), **cov)
+print("cov3d.npz written")

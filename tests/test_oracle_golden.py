@@ -56,3 +56,31 @@ def test_metric_definitions():
     d = np.load(os.path.join(G, "metrics.npz"))
     np.testing.assert_allclose(metrics.psnr(d["a"], d["b"]), d["psnr"].reshape(-1), rtol=1e-5)
     assert abs(metrics.l1(d["a"], d["b"]) - float(d["l1"])) < 1e-7
+
+
+def test_cov3d_matches_reference_covariance_activation():
+    """tests/golden/cov3d.npz = build_scaling_rotation / strip_symmetric of the reference (gaussian_model.py:38-42,
+    utils/general_utils.py:67-120).  The oracle's computeCov3D (forward.cu:118-153 restated) must give the same six
+    numbers for the normalised quaternion, for both scale modifiers; so must the renderer's get_covariance glue."""
+    import torch
+    import oracle
+    from ibgs_amd import simple_scene, synthetic as syn
+    g = np.load(os.path.join(G, "cov3d.npz"))
+    P = g["scales"].shape[0]
+    q = g["quats"] / np.linalg.norm(g["quats"], axis=1, keepdims=True)
+    cam = syn.make_camera(64, 48)
+    rng = np.random.default_rng(0)
+    base = {"means3D": (0.2 * rng.normal(size=(P, 3))).astype(np.float32), "shs": np.zeros((P, 1, 3), np.float32),
+            "opacities": np.full(P, 0.5, np.float32), "scales": g["scales"], "rotations": q.astype(np.float32),
+            "W": 64, "H": 48, "tanfovx": cam["tanfovx"], "tanfovy": cam["tanfovy"], "viewmatrix": cam["viewmatrix"],
+            "projmatrix": cam["projmatrix"], "campos": cam["campos"], "bg": np.zeros(3, np.float32), "sh_degree": 0}
+    for mod in (1.0, 0.5):
+        inp = dict(base); inp["scale_modifier"] = mod
+        out = oracle.forward(inp)
+        want = g["cov6_mod%g" % mod]
+        assert np.abs(out["cov3D"] - want).max() <= 2e-6 * np.abs(want).max()
+    pc = simple_scene.SimpleGaussians({"means3D": base["means3D"], "shs": base["shs"], "opacities": base["opacities"],
+                                       "scales": g["scales"], "rotations": g["quats"]}, sh_degree=0)
+    got = pc.get_covariance(0.5).detach().numpy()
+    assert np.abs(got - g["cov6_mod0.5"]).max() <= 2e-6 * np.abs(g["cov6_mod0.5"]).max()
+    assert np.abs(pc.rotation_matrices().detach().numpy() - g["rotmat"]).max() < 2e-6
