@@ -135,23 +135,44 @@ template <typename K>
 __global__ void __launch_bounds__(256) ranges_kernel(uint32_t R, const uint32_t* __restrict__ R_dev, const K* __restrict__ keys, uint32_t* __restrict__ ranges)
 {
     if (R_dev) R = min(R, *R_dev);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t cur = keys[i];
-    if (i == 0) ranges[2 * cur] = 0;
-    else {
-        const uint32_t prev = keys[i - 1];
-        if (cur != prev) { ranges[2 * prev + 1] = i; ranges[2 * cur] = i; }
+    constexpr int N = 8;                                        // consecutive keys per thread (16-byte loads)
+    const uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * (uint32_t)N;
+    if (i0 >= R) return;
+    uint32_t kv[N];
+    if (i0 + N <= R) {
+        constexpr int PER = 16 / (int)sizeof(K);
+        const uint4* src = reinterpret_cast<const uint4*>(keys + i0);
+#pragma unroll
+        for (int v = 0; v < N / PER; v++) {
+            const uint4 q = src[v];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < PER; e++) kv[v * PER + e] = (sizeof(K) == 4) ? w[e] : ((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) kv[k] = (i0 + k < R) ? (uint32_t)keys[i0 + k] : 0u;
     }
-    if (i == R - 1) ranges[2 * cur + 1] = R;
+    uint32_t prev = (i0 == 0) ? 0xFFFFFFFFu : (uint32_t)keys[i0 - 1];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t i = i0 + k;
+        if (i < R) {
+            const uint32_t cur = kv[k];
+            if (i == 0) ranges[2 * cur] = 0;
+            else if (cur != prev) { ranges[2 * prev + 1] = i; ranges[2 * cur] = i; }
+            if (i == R - 1) ranges[2 * cur + 1] = R;
+            prev = cur;
+        }
+    }
 }
 
 int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev, bool key16)
 {
     IBGS_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles, s));
     if (R <= 0) return 0;
-    if (key16) hipLaunchKernelGGL(ranges_kernel<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, R_dev, reinterpret_cast<const uint16_t*>(sorted_keys), ranges);
-    else hipLaunchKernelGGL(ranges_kernel<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (uint32_t)R, R_dev, sorted_keys, ranges);
+    if (key16) hipLaunchKernelGGL(ranges_kernel<uint16_t>, dim3((unsigned)((R + 2047) / 2048)), dim3(256), 0, s, (uint32_t)R, R_dev, reinterpret_cast<const uint16_t*>(sorted_keys), ranges);
+    else hipLaunchKernelGGL(ranges_kernel<uint32_t>, dim3((unsigned)((R + 2047) / 2048)), dim3(256), 0, s, (uint32_t)R, R_dev, sorted_keys, ranges);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -162,11 +162,36 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const K* __restr
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * RS_CHUNK;
     const uint32_t mask = (uint32_t)nbins - 1;
+    // Each thread counts RS_ITEMS CONSECUTIVE keys (16-byte loads) and merges runs of equal digits before touching the LDS:
+    // after the first pass neighbours mostly share the next digit, and 64 lanes adding 1 to the same LDS word serialise.
+    const size_t i0 = base + (size_t)threadIdx.x * RS_ITEMS;
+    uint32_t kv[RS_ITEMS];
+    if (i0 + RS_ITEMS <= n) {
+        constexpr int PER = 16 / (int)sizeof(K);                 // keys per 16-byte load
+        const uint4* src = reinterpret_cast<const uint4*>(keys + i0);
+#pragma unroll
+        for (int v = 0; v < RS_ITEMS / PER; v++) {
+            const uint4 q = src[v];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < PER; e++)
+                kv[v * PER + e] = (sizeof(K) == 4) ? w[e] : ((w[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; k++) kv[k] = (i0 + k < n) ? (uint32_t)keys[i0 + k] : 0xFFFFFFFFu;
+    }
+    const int nvalid = (i0 >= n) ? 0 : (int)((n - i0 < (size_t)RS_ITEMS) ? (n - i0) : (size_t)RS_ITEMS);
+    uint32_t run_d = 0, run_n = 0;
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
-        const size_t idx = base + (size_t)k * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[((uint32_t)keys[idx] >> shift) & mask], 1u);
+        if (k < nvalid) {
+            const uint32_t d = (kv[k] >> shift) & mask;
+            if (run_n != 0 && d != run_d) { atomicAdd(&h[run_d], run_n); run_n = 0; }
+            run_d = d; run_n++;
+        }
     }
+    if (run_n != 0) atomicAdd(&h[run_d], run_n);
     __syncthreads();
     for (int k = threadIdx.x; k < nbins; k += RS_THREADS) hist[(size_t)k * nblocks + blockIdx.x] = h[k];
 }
