@@ -222,6 +222,18 @@ def main():
                 traffic = json.load(open(tpath)).get("render_bwd_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what the dominant kernel is actually bound by: wave-VALU instructions per launch from the committed PMC pass,
+        # divided by this run's kernel time -> instructions per cycle per SIMD (the chip issues at most one per ~2.6 cycles)
+        valu = None
+        cpath = os.path.join(ROOT, "profiles", "r01_counters.json")
+        if traffic is not None and os.path.exists(cpath) and k_ms > 0:
+            try:
+                ctr = json.load(open(cpath))["per_launch_counters"]["render_bwd_color_kernel"]
+                ipc = ctr["SQ_INSTS_VALU"] / (1024.0 * k_ms * 1e-3 * 2.4e9)
+                valu = {"wave_valu_insts_per_launch": ctr["SQ_INSTS_VALU"], "insts_per_cycle_per_simd": ipc, "cycles_per_inst": 1.0 / ipc,
+                        "clock_ghz": 2.4, "simds": 1024}
+            except Exception:
+                valu = None
         out = {
             "metric": ("forward render fps " + a.config) if a.forward_only else
                       ("train-step fps (fwd+bwd raster) @1080p, 1M Gaussians" if a.config == "C3" else "train-step fps (fwd+bwd raster) " + a.config),
@@ -236,6 +248,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("render_fwd_kernel" if a.forward_only else (("render_bwd_geo2_kernel" if tiles >= 4096 else "render_bwd_geo_kernel") if a.geo else ("render_bwd_color_kernel" if tiles >= 4096 else "render_bwd_color_small_kernel"))), "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
+                         "valu_issue": valu,
                          "step_algorithmic_bytes": b_fwd if a.forward_only else b_fwd + b_bwd,
                          "step_frac": (b_fwd if a.forward_only else b_fwd + b_bwd) / (ms_step * 1e-3) / HBM_PEAK},
             "stages_ms": stages,
