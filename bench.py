@@ -249,6 +249,7 @@ def main():
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
                          "valu_issue": valu,
+                         "mfma_utilisation": 0.0,        # by design: no kernel of this path is a dense contraction (DESIGN.md "MFMA")
                          "step_algorithmic_bytes": b_fwd if a.forward_only else b_fwd + b_bwd,
                          "step_frac": (b_fwd if a.forward_only else b_fwd + b_bwd) / (ms_step * 1e-3) / HBM_PEAK},
             "stages_ms": stages,
