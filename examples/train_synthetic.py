@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--geo-from", type=int, default=30, help="iteration from which render_geo is on (train.py: 7000 - 2 * #cameras)")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
-    rank, world, local = vdist.init_from_env()
+    rank, world, local = vdist.init_from_env(backend=os.environ.get("IBGS_DIST_BACKEND"))      # default nccl (= RCCL); gloo lets two ranks share one GPU
     dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
@@ -96,6 +96,12 @@ def main():
         k = max(1, min(10, a.iters // 4))
         print("train_synthetic: %d iterations, %.2f ms / iteration, loss %.5f -> %.5f" % (a.iters, dt / a.iters * 1e3, float(np.mean(hist[:k])), float(np.mean(hist[-k:]))))
     if world > 1:
+        # replicas must stay bit-identical: same summed gradients on every rank, same optimiser step
+        cs = torch.stack([p.detach().double().sum() for p in params])
+        lo, hi = cs.clone(), cs.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN); torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            print("replicas in sync: %s" % bool(torch.equal(lo, hi)))
         torch.distributed.barrier(); torch.distributed.destroy_process_group()
     return hist
 

@@ -19,3 +19,17 @@ def test_example_training_reduces_the_loss():
     assert m, r.stdout
     first, last = float(m.group(1)), float(m.group(2))
     assert last < 0.75 * first, r.stdout
+
+
+@pytest.mark.gpu
+def test_example_training_view_parallel_two_ranks_on_one_gpu():
+    """Two ranks (gloo, both on cuda:0) run the view-parallel step with the real kernels: factored SH exchange, dense all-reduce,
+    FusedAdam.  The loss falls and the two replicas end with identical parameters."""
+    env = dict(os.environ, IBGS_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29677", os.path.join(ROOT, "examples", "train_synthetic.py"), "--iters", "40", "--points", "4000",
+                        "--width", "160", "--height", "112", "--geo-from", "20", "--quiet"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "replicas in sync: True" in r.stdout, r.stdout
+    m = re.search(r"loss ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert m and float(m.group(2)) < 0.85 * float(m.group(1)), r.stdout
