@@ -103,7 +103,8 @@ typedef struct ibgs_forward_args {
     int32_t buffer_length;      /* 1..IBGS_MAX_BUFFER_LENGTH */
     float depth_error_threshold;
     /* modes */
-    int32_t prefiltered;
+    int32_t prefiltered;        /* signature compatibility only.  The reference traps the kernel when a Gaussian is near-culled although the
+                                   caller set this (auxiliary.h:158-166; its callers always pass false); here such a Gaussian is just culled */
     int32_t render_geo;
     int32_t render_depth_only;
     uint32_t flags;
