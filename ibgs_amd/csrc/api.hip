@@ -43,7 +43,7 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.cov3D = c.take<float>(P * 6);
     g.tiles = c.take<uint32_t>(P);
     g.rect = c.take<uint32_t>(P * 2);
-    g.tmask = c.take<uint64_t>(P);
+    g.tmask = c.take<uint64_t>(P * IBGS_CULL_WORDS);
     g.clamped = c.take<uint8_t>(P);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);

@@ -96,10 +96,19 @@ __global__ void __launch_bounds__(EM_THREADS) emit_kernel(uint32_t P, uint32_t R
             const uint32_t rx = rect[2 * id], ry = rect[2 * id + 1];
             const uint32_t x0 = rx & 0xFFFFu, x1 = rx >> 16, y0 = ry & 0xFFFFu, y1 = ry >> 16;
             const uint32_t w = x1 - x0;
-            if (w * (y1 - y0) <= 64u) {
-                // k-th surviving tile = position of the k-th set bit of the cull mask
-                uint64_t m = tmask[id];
+            if (w * (y1 - y0) <= (uint32_t)IBGS_CULL_MAX_TILES) {
+                // k-th surviving tile = position of the k-th set bit of the cull mask (up to four 64-bit words)
+                const uint64_t* mw = tmask + (size_t)id * IBGS_CULL_WORDS;
+                uint64_t m = mw[0];
                 uint32_t pos = 0;
+                if (w * (y1 - y0) > 64u) {
+#pragma unroll
+                    for (int r = 0; r < IBGS_CULL_WORDS - 1; r++) {
+                        const uint32_t c = (uint32_t)__popcll(m);
+                        if (k >= c) { k -= c; pos += 64u; m = mw[r + 1]; }
+                        else break;
+                    }
+                }
 #pragma unroll
                 for (int sft = 32; sft >= 1; sft >>= 1) {
                     const uint64_t low = m & ((1ull << sft) - 1ull);

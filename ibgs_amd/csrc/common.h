@@ -15,6 +15,9 @@ constexpr int GACC_FLOATS = 16;  // one 64-byte gradient accumulation row per Ga
 // Field indices of the per-Gaussian render record written by preprocess and staged (as 16-byte
 // quads) by the render kernels.  Quad 0 = {x, y, opacity, pad}, quad 1 = {conic a,b,c, dist},
 // quad 2 = {r,g,b, pad}, quad 3 = {nx,ny,nz, pad}.
+constexpr int IBGS_CULL_WORDS = 4;                         // 64-bit mask words per Gaussian
+constexpr int IBGS_CULL_MAX_TILES = 64 * IBGS_CULL_WORDS;  // rectangles up to 256 tiles are culled per tile
+
 enum RecField { R_X = 0, R_Y = 1, R_OP = 2, R_PAD0 = 3, R_CA = 4, R_CB = 5, R_CC = 6, R_DIST = 7,
                 R_R = 8, R_G = 9, R_B = 10, R_PAD1 = 11, R_NX = 12, R_NY = 13, R_NZ = 14, R_PAD2 = 15 };
 
@@ -40,7 +43,7 @@ struct GeomState {
     float* cov3D;          // P x 6
     uint32_t* tiles;       // P   tiles touched
     uint32_t* rect;        // P x 2  (x0 | x1<<16, y0 | y1<<16), tightened by the tile cull
-    uint64_t* tmask;       // P   surviving tiles inside rect (row-major bit mask, rects of <= 64 tiles)
+    uint64_t* tmask;       // P x IBGS_CULL_WORDS  surviving tiles inside rect (row-major bit mask, rects of <= IBGS_CULL_MAX_TILES tiles)
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered

@@ -66,55 +66,62 @@ __device__ __forceinline__ float ln_portable(float x)
 // values (and the masks) stay bit-identical; one v_med3_f32 instead of two compare + select pairs
 __device__ __forceinline__ float clampf_(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
-__device__ uint32_t tile_cull(float px, float py, float sxx, float syy, float A, float B, float C, float o,
-                              int& x0, int& y0, int& x1, int& y1, uint64_t& mask)
+// What is needed to test one tile of one Gaussian; a plain struct so that a whole wave can work on the tiles of ONE Gaussian
+// (fields are broadcast with shuffles) as well as a lane on its own.
+struct CullJob { float px, py, A, B, C, qmax, nbc, nba; int x0, y0, w, h; };
+enum { CULL_NONE = 0, CULL_AABB = 1, CULL_LANE = 2, CULL_WAVE = 3 };
+
+// Tightens the rectangle to the ellipse's extent and decides how its tiles are tested: CULL_NONE (nothing can pass: no tiles),
+// CULL_AABB (more than IBGS_CULL_MAX_TILES tiles, or a degenerate conic: keep the whole rectangle), CULL_LANE (<= 64 tiles: the
+// owning lane loops over them), CULL_WAVE (65..256 tiles: the wave tests them together, 64 per round, masks straight from ballots).
+__device__ __forceinline__ int cull_setup(float px, float py, float sxx, float syy, float A, float B, float C, float o,
+                                          int& x0, int& y0, int& x1, int& y1, CullJob& j)
 {
-    mask = ~0ull;
     const float x255 = 255.0f * o;
-    if (!(x255 >= 1.0f)) { x1 = x0; y1 = y0; mask = 0; return 0; }
+    if (!(x255 >= 1.0f)) { x1 = x0; y1 = y0; return CULL_NONE; }
     const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
     const float hx = sqrtf(qmax * sxx), hy = sqrtf(qmax * syy);
     int tx0 = (int)ceilf((px - hx - 15.0f) / 16.0f), tx1 = (int)floorf((px + hx) / 16.0f) + 1;
     int ty0 = (int)ceilf((py - hy - 15.0f) / 16.0f), ty1 = (int)floorf((py + hy) / 16.0f) + 1;
     tx0 = max(tx0, x0); tx1 = min(tx1, x1); ty0 = max(ty0, y0); ty1 = min(ty1, y1);
-    if (tx1 <= tx0 || ty1 <= ty0) { x1 = x0; y1 = y0; mask = 0; return 0; }
+    if (tx1 <= tx0 || ty1 <= ty0) { x1 = x0; y1 = y0; return CULL_NONE; }
     x0 = tx0; x1 = tx1; y0 = ty0; y1 = ty1;
     const int w = tx1 - tx0, h = ty1 - ty0;
-    if (w * h > 64 || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
-    uint64_t m = 0; uint32_t cnt = 0;
-    const float nbc = -B / C, nba = -B / A;      /* minimiser of q along an edge x = const / y = const, per unit of x / y */
-    for (int ty = ty0; ty < ty1; ty++)
-        for (int tx = tx0; tx < tx1; tx++) {
-            const float X0 = (float)(tx * 16) - px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
-            bool keep;
-            if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) keep = true;
-            else {
-                float qmin, t, q;
-                t = clampf_(nbc * X0, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
-                t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = __builtin_fminf(q, qmin);
-                t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = __builtin_fminf(q, qmin);
-                t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = __builtin_fminf(q, qmin);
-                keep = !(qmin > qmax);
-            }
-            if (keep) { m |= 1ull << ((ty - ty0) * w + (tx - tx0)); cnt++; }
-        }
-    mask = m;
-    return cnt;
+    if (w * h > IBGS_CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f)) return CULL_AABB;
+    j.px = px; j.py = py; j.A = A; j.B = B; j.C = C; j.qmax = qmax; j.x0 = tx0; j.y0 = ty0; j.w = w; j.h = h;
+    j.nbc = -B / C; j.nba = -B / A;          /* minimiser of q along an edge x = const / y = const, per unit of x / y */
+    return (w * h > 64) ? CULL_WAVE : CULL_LANE;
+}
+
+// Does the pixel-centre box of tile (tx, ty) reach into the ellipse q <= qmax?  (closest point of the quadratic on the box)
+__device__ __forceinline__ bool tile_keep(const CullJob& j, int tx, int ty)
+{
+    const float A = j.A, B = j.B, C = j.C, nbc = j.nbc, nba = j.nba, qmax = j.qmax;
+    const float X0 = (float)(tx * 16) - j.px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - j.py, Y1 = Y0 + 15.0f;
+    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return true;
+    float qmin, t, q;
+    t = clampf_(nbc * X0, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
+    t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = __builtin_fminf(q, qmin);
+    t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = __builtin_fminf(q, qmin);
+    t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = __builtin_fminf(q, qmin);
+    return !(qmin > qmax);
 }
 
 // One thread per Gaussian. The AoS inputs (12..192 B per Gaussian) are read with plain per-lane
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
-__global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
+__global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.P) return;
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = gi < p.P;          // lanes past the end stay in the wave: the cooperative tile test below needs all 64
+    const int i = valid ? gi : p.P - 1;   // (they recompute the last Gaussian and store nothing)
 
     // defaults: culled Gaussians keep radius 0, zero tiles and sort last
     float rec[REC_FLOATS];
 #pragma unroll
     for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     int radius = 0; uint32_t ntiles = 0; uint32_t rx = 0, ry = 0; float depth = 0.f; uint8_t clampbits = 0;
-    uint64_t tmask = 0;
+    uint64_t tmask[IBGS_CULL_WORDS] = {0, 0, 0, 0};
+    CullJob job; int cull_mode = CULL_NONE; bool big_rect = false;
     float c6loc[6] = {0, 0, 0, 0, 0, 0};
 
     const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
@@ -192,9 +199,22 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
             alive = ((x1 - x0) * (y1 - y0)) != 0;
             if (alive) {
                 radius = rad; ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-                tmask = ~0ull;
-                if (p.cull)
-                    ntiles = tile_cull(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, tmask);
+#pragma unroll
+                for (int k = 0; k < IBGS_CULL_WORDS; k++) tmask[k] = ~0ull;
+                if (p.cull) {
+                    cull_mode = cull_setup(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, job);
+                    if (cull_mode == CULL_NONE) { ntiles = 0; tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull; }
+                    else if (cull_mode == CULL_AABB) ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+                    else if (cull_mode == CULL_LANE) {
+                        uint64_t m = 0; uint32_t cnt = 0;
+                        for (int ty = job.y0; ty < job.y0 + job.h; ty++)
+                            for (int tx = job.x0; tx < job.x0 + job.w; tx++)
+                                if (tile_keep(job, tx, ty)) { m |= 1ull << ((ty - job.y0) * job.w + (tx - job.x0)); cnt++; }
+                        tmask[0] = m; tmask[1] = tmask[2] = tmask[3] = 0ull; ntiles = cnt;
+                    }
+                    // CULL_WAVE: counted below, by the whole wave
+                }
+                big_rect = (x1 - x0) * (y1 - y0) > 64;
                 rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
                 depth = zview;
                 rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
@@ -285,11 +305,47 @@ __global__ void __launch_bounds__(256) preprocess_kernel(PreParams p, Cam cam)
         for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     }
 
+    // ---- rectangles of 65..256 tiles: the wave tests the tiles of one such Gaussian at a time, 64 tiles per round; the mask
+    // words are the ballots themselves.  (A lane looping over 256 tiles on its own would hold its 63 neighbours for 256 rounds.)
+    {
+        const int lane = threadIdx.x & 63;
+        uint64_t pending = __ballot(valid && alive && cull_mode == CULL_WAVE);
+        while (pending != 0ull) {
+            const int src = __ffsll((unsigned long long)pending) - 1;
+            pending &= pending - 1ull;
+            CullJob b;
+            b.px = __shfl(job.px, src, WAVE); b.py = __shfl(job.py, src, WAVE); b.A = __shfl(job.A, src, WAVE); b.B = __shfl(job.B, src, WAVE);
+            b.C = __shfl(job.C, src, WAVE); b.qmax = __shfl(job.qmax, src, WAVE); b.nbc = __shfl(job.nbc, src, WAVE); b.nba = __shfl(job.nba, src, WAVE);
+            b.x0 = __shfl(job.x0, src, WAVE); b.y0 = __shfl(job.y0, src, WAVE); b.w = __shfl(job.w, src, WAVE); b.h = __shfl(job.h, src, WAVE);
+            const int area = b.w * b.h;
+            uint64_t words[IBGS_CULL_WORDS]; uint32_t cnt = 0;
+#pragma unroll
+            for (int r = 0; r < IBGS_CULL_WORDS; r++) {
+                const int t = r * 64 + lane;
+                bool keep = false;
+                if (t < area) { const int row = t / b.w; keep = tile_keep(b, b.x0 + (t - row * b.w), b.y0 + row); }
+                words[r] = __ballot(keep);
+                cnt += (uint32_t)__popcll(words[r]);
+            }
+            if (lane == src) {
+#pragma unroll
+                for (int r = 0; r < IBGS_CULL_WORDS; r++) tmask[r] = words[r];
+                ntiles = cnt;
+            }
+        }
+    }
+    if (!valid) return;
+
     const int o = p.inst0 + i;            // instance slot (= i for a single view)
     p.radii[o] = radius;
     p.tiles[o] = ntiles;
     p.rect[2 * o] = rx; p.rect[2 * o + 1] = ry;
-    p.tmask[o] = tmask;
+    // word 0 always; words 1..3 only matter (and are only read by emit) for rectangles of more than 64 tiles
+    p.tmask[(size_t)o * IBGS_CULL_WORDS] = tmask[0];
+    if (big_rect) {
+#pragma unroll
+        for (int k = 1; k < IBGS_CULL_WORDS; k++) p.tmask[(size_t)o * IBGS_CULL_WORDS + k] = tmask[k];
+    }
     p.depths[o] = depth;
     p.clamped[o] = clampbits;
     if (!p.cov3D_precomp) {

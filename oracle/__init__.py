@@ -120,7 +120,7 @@ def forward(inp, tex_quant=False, cull=False):
     st["depths"] = np.zeros(P, np.float32); st["cov3D"] = np.zeros((P, 6), np.float32)
     st["rgb"] = np.zeros((P, 3), np.float32); st["conic_opacity"] = np.zeros((P, 4), np.float32)
     st["tiles_touched"] = np.zeros(P, np.uint32); st["clamped"] = np.zeros((P, 3), np.uint8)
-    st["rect4"] = np.zeros((P, 4), np.int32); st["tmask"] = np.zeros(P, np.uint64)
+    st["rect4"] = np.zeros((P, 4), np.int32); st["tmask"] = np.zeros((P, 4), np.uint64)      # CULL_WORDS mask words per Gaussian
     out = {
         "color": np.zeros((3, H, W), np.float32), "normal_map": np.zeros((3, H, W), np.float32),
         "median_depth": np.zeros((1, H, W), np.float32), "cam_feat": np.zeros((4 * MAX_SRC, H, W), np.float32),

@@ -181,23 +181,25 @@ static inline float clampf_(float v, float lo, float hi) { return v < lo ? lo : 
 
 /* In: pixel centre, cov2D diagonal (with the 0.3), conic, opacity, reference rectangle.
  * Out: tightened rectangle, bit mask of surviving tiles (row-major inside the tightened rectangle,
- * only when it has <= 64 tiles; otherwise every tile of it survives). Returns the tile count. */
+ * CULL_WORDS x 64 bits, only when it has <= CULL_MAX_TILES tiles; otherwise every tile of it survives). Returns the tile count. */
+#define CULL_WORDS 4
+#define CULL_MAX_TILES (64 * CULL_WORDS)
 static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, float B, float C, float o,
-                          int* x0, int* y0, int* x1, int* y1, uint64_t* mask)
+                          int* x0, int* y0, int* x1, int* y1, uint64_t* mask /* [CULL_WORDS] */)
 {
-    *mask = ~0ull;
+    for (int k = 0; k < CULL_WORDS; k++) mask[k] = ~0ull;
     const float x255 = 255.0f * o;
-    if (!(x255 >= 1.0f)) { *x1 = *x0; *y1 = *y0; *mask = 0; return 0; }
+    if (!(x255 >= 1.0f)) { *x1 = *x0; *y1 = *y0; for (int k = 0; k < CULL_WORDS; k++) mask[k] = 0; return 0; }
     const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
     const float hx = sqrtf(qmax * sxx), hy = sqrtf(qmax * syy);
     int tx0 = (int)ceilf((px - hx - 15.0f) / 16.0f), tx1 = (int)floorf((px + hx) / 16.0f) + 1;
     int ty0 = (int)ceilf((py - hy - 15.0f) / 16.0f), ty1 = (int)floorf((py + hy) / 16.0f) + 1;
     tx0 = imax(tx0, *x0); tx1 = imin(tx1, *x1); ty0 = imax(ty0, *y0); ty1 = imin(ty1, *y1);
-    if (tx1 <= tx0 || ty1 <= ty0) { *x1 = *x0; *y1 = *y0; *mask = 0; return 0; }
+    if (tx1 <= tx0 || ty1 <= ty0) { *x1 = *x0; *y1 = *y0; for (int k = 0; k < CULL_WORDS; k++) mask[k] = 0; return 0; }
     *x0 = tx0; *x1 = tx1; *y0 = ty0; *y1 = ty1;
     const int w = tx1 - tx0, h = ty1 - ty0;
-    if (w * h > 64 || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
-    uint64_t m = 0; uint32_t cnt = 0;
+    if (w * h > CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
+    uint64_t m[CULL_WORDS] = {0, 0, 0, 0}; uint32_t cnt = 0;
     const float nbc = -B / C, nba = -B / A;      /* minimiser of q along an edge x = const / y = const, per unit of x / y */
     for (int ty = ty0; ty < ty1; ty++) for (int tx = tx0; tx < tx1; tx++) {
         const float X0 = (float)(tx * 16) - px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
@@ -211,9 +213,9 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
             t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
             keep = !(qmin > qmax);
         }
-        if (keep) { m |= 1ull << ((ty - ty0) * w + (tx - tx0)); cnt++; }
+        if (keep) { const int bit = (ty - ty0) * w + (tx - tx0); m[bit >> 6] |= 1ull << (bit & 63); cnt++; }
     }
-    *mask = m;
+    for (int k = 0; k < CULL_WORDS; k++) mask[k] = m[k];
     return cnt;
 }
 
@@ -238,7 +240,7 @@ int orc_preprocess(int P, int D, int M,
 #pragma omp parallel for schedule(static) reduction(+ : visible)
     for (int i = 0; i < P; i++) {
         radii[i] = 0; tiles_touched[i] = 0; depths[i] = 0.f;
-        rect4[4 * i] = rect4[4 * i + 1] = rect4[4 * i + 2] = rect4[4 * i + 3] = 0; tmask[i] = 0;
+        rect4[4 * i] = rect4[4 * i + 1] = rect4[4 * i + 2] = rect4[4 * i + 3] = 0; for (int k = 0; k < CULL_WORDS; k++) tmask[CULL_WORDS * i + k] = 0;
         means2D[2 * i] = means2D[2 * i + 1] = 0.f;
         for (int k = 0; k < 6; k++) cov3D[6 * i + k] = 0.f;
         for (int k = 0; k < 3; k++) { rgb[3 * i + k] = 0.f; clamped[3 * i + k] = 0; }
@@ -294,9 +296,9 @@ int orc_preprocess(int P, int D, int M,
         conic_opacity[4 * i + 2] = a * det_inv;
         conic_opacity[4 * i + 3] = opacities[i];
         uint32_t nt = (uint32_t)((y1 - y0) * (x1 - x0));
-        uint64_t mk = ~0ull;
-        if (cull) nt = tile_cull(px, py, a, c, c * det_inv, -b * det_inv, a * det_inv, opacities[i], &x0, &y0, &x1, &y1, &mk);
-        tiles_touched[i] = nt; tmask[i] = mk;
+        uint64_t mk[CULL_WORDS] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (cull) nt = tile_cull(px, py, a, c, c * det_inv, -b * det_inv, a * det_inv, opacities[i], &x0, &y0, &x1, &y1, mk);
+        tiles_touched[i] = nt; for (int k = 0; k < CULL_WORDS; k++) tmask[CULL_WORDS * i + k] = mk[k];
         rect4[4 * i] = x0; rect4[4 * i + 1] = y0; rect4[4 * i + 2] = x1; rect4[4 * i + 3] = y1;
         visible++;
     }
@@ -338,10 +340,11 @@ int orc_bin(int P, int64_t R, const int32_t* radii, const int32_t* rect4, const 
     for (int i = 0; i < P; i++) {
         if (radii[i] <= 0) continue;
         const int x0 = rect4[4 * i], y0 = rect4[4 * i + 1], x1 = rect4[4 * i + 2], y1 = rect4[4 * i + 3];
-        const int w = x1 - x0, dense = (w * (y1 - y0) > 64);
+        const int w = x1 - x0, dense = (w * (y1 - y0) > CULL_MAX_TILES);
         uint32_t dbits; memcpy(&dbits, depths + i, 4);
         for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
-            if (!dense && !((tmask[i] >> ((y - y0) * w + (x - x0))) & 1ull)) continue;
+            const int bit = (y - y0) * w + (x - x0);
+            if (!dense && !((tmask[CULL_WORDS * i + (bit >> 6)] >> (bit & 63)) & 1ull)) continue;
             k0[off] = ((uint64_t)(y * gx + x) << 32) | dbits;
             v0[off] = (uint32_t)i;
             off++;
