@@ -183,6 +183,21 @@ def test_tile_culling_changes_no_result(opacity):
     check_grads(leaves, gfull, tol=5e-3)
 
 
+def test_mid_size_rectangles_are_culled_by_the_whole_wave():
+    """Rectangles of 65..256 tiles take the wave-cooperative culling path (mask words = ballots, four words per Gaussian);
+    rectangles above 256 tiles keep the AABB list.  Lists must still equal the oracle's bit for bit, ragged P included."""
+    inp = scene(P=777, W=400, H=304, deg=1, seed=52, opacity="trained", scale_mul=1.3)
+    ref = oracle.forward(inp, cull=True)
+    r = ref["rect4"].astype(np.int64)
+    area = (r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])
+    mid = (area > 64) & (area <= 256)
+    assert mid.sum() > 100 and (area > 256).sum() > 5 and ((area > 0) & (area <= 64)).sum() > 50, (mid.sum(), (area > 256).sum())
+    assert (ref["tiles_touched"][mid] < area[mid]).mean() > 0.5          # the per-tile test really removes tiles there
+    ref2, o, ist, leaves, gb = run(inp, {"color": rnd((3, 304, 400), 3)}, cull=True)
+    check_stages(ist, o, ref2); check_color(o, ist, ref2); check_grads(leaves, gb)
+    assert np.array_equal(ist["tiles"], ref["tiles_touched"])
+
+
 def test_precomputed_colour_and_covariance_inputs():
     inp = scene(P=1500, deg=0, seed=4, opacity="trained")
     f0 = oracle.forward(inp)
