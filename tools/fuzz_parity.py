@@ -30,16 +30,25 @@ for case in range(n_cases):
     dc = l1(o["color"], ref["color"])
     nc = float((ist["n_contrib"] == ref["n_contrib"]).mean())
     g = rng.standard_normal((3, H, W)).astype(np.float32)
-    (outs["color"] * torch.as_tensor(g, device="cuda")).sum().backward()
-    gd = {"dL_dcolor": g}
-    rb = oracle.backward(inp, ref, g) if not geo else oracle.backward(inp, ref, g, None, None, None) if False else oracle.backward(inp, ref, g)
+    if geo:      # every differentiable geo output takes part
+        gn = rng.standard_normal((3, H, W)).astype(np.float32); gdp = rng.standard_normal((1, H, W)).astype(np.float32)
+        gw = rng.standard_normal((15, H, W)).astype(np.float32)
+        ((outs["color"] * torch.as_tensor(g, device="cuda")).sum() + (outs["normal_map"] * torch.as_tensor(gn, device="cuda")).sum()
+         + (outs["median_depth"] * torch.as_tensor(gdp, device="cuda")).sum() + (outs["warped_image"] * torch.as_tensor(gw, device="cuda")).sum()).backward()
+        rb = oracle.backward(inp, ref, g, gn, gdp, gw)
+    else:
+        (outs["color"] * torch.as_tensor(g, device="cuda")).sum().backward()
+        rb = oracle.backward(inp, ref, g)
     gr = 0.0
-    for k, v in {"dL_dmeans3D": "means3D", "dL_dopacity": "opacities", "dL_dscales": "scales"}.items():
+    names = {"dL_dmeans3D": "means3D", "dL_dopacity": "opacities", "dL_dscales": "scales"}
+    if geo:
+        names["dL_dall_map"] = "all_map"
+    for k, v in names.items():
         a = lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape)
         if np.abs(rb[k]).sum() > 0:
             gr = max(gr, float(rel_l2(a, rb[k])))
     worst["color"] = max(worst["color"], dc); worst["grad"] = max(worst["grad"], gr); worst["ncontrib"] = min(worst["ncontrib"], nc)
-    flag = ok and dc < 1e-5 and gr < 5e-3 and nc > 0.995
+    flag = ok and dc < 1e-5 and gr < (2e-2 if geo else 5e-3) and nc > 0.995
     bad += not flag
     print("%s case %2d: P=%5d %3dx%3d deg=%d geo=%d shape=%-8s R=%7d | lists %s colour L1 %.1e n_contrib eq %.4f grad relL2 %.1e"
           % ("ok  " if flag else "FAIL", case, P, W, H, deg, geo, rasterizer.WAVE_SHAPE, ist["R"], ok, dc, nc, gr), flush=True)
