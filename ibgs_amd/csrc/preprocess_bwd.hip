@@ -69,14 +69,28 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     __shared__ float4 s_t[FAST16 ? 64 * 13 : 1];     // row stride 13 quads: conflict-free b128 access
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < p.P;
-    const bool vis = valid && (p.radii[i] > 0);
+    bool vis = valid && (p.radii[i] > 0);
+    // A visible Gaussian that no pixel blended (everything in front of it was already opaque, or it fell off every tile list)
+    // has an all-zero moment row, hence all-zero gradients: it is handled like an invisible one and its 200+ bytes of SH,
+    // covariance and record reads are skipped.  Half of the Gaussians of the C3 bench scene are in that class.
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g3 = g0;
+    if (vis) {
+        float4* grow = reinterpret_cast<float4*>(p.gacc + (size_t)i * GACC_FLOATS);
+        g0 = grow[0]; g1 = grow[1]; g2 = grow[2]; g3 = grow[3];
+        const uint32_t any = (__float_as_uint(g0.x) | __float_as_uint(g0.y) | __float_as_uint(g0.z) | __float_as_uint(g0.w) |
+                              __float_as_uint(g1.x) | __float_as_uint(g1.y) | __float_as_uint(g1.z) | __float_as_uint(g1.w) |
+                              __float_as_uint(g2.x) | __float_as_uint(g2.y) | __float_as_uint(g2.z) | __float_as_uint(g2.w) |
+                              __float_as_uint(g3.x) | __float_as_uint(g3.y) | __float_as_uint(g3.z) | __float_as_uint(g3.w)) & 0x7FFFFFFFu;
+        if (any == 0u) vis = false;
+        else if (p.clear_gacc) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); grow[0] = z; grow[1] = z; grow[2] = z; grow[3] = z; }
+    }
     float gv[(FAST16 && WRITE_SH) ? 48 : 1];
     if (FAST16 && WRITE_SH) {
 #pragma unroll
         for (int k = 0; k < 48; k++) gv[k] = 0.f;
     }
     if (valid && !vis) {
-        // invisible Gaussian: every gradient is zero; written explicitly so that callers need no memset
+        // invisible (or untouched) Gaussian: every gradient is zero; written explicitly so that callers need no memset
         p.dL_dmean2D[3 * i] = 0.f; p.dL_dmean2D[3 * i + 1] = 0.f; p.dL_dmean2D[3 * i + 2] = 0.f;
         p.dL_dmean2D_abs[3 * i] = 0.f; p.dL_dmean2D_abs[3 * i + 1] = 0.f; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
         if (p.dL_dconic) { p.dL_dconic[4 * i] = 0.f; p.dL_dconic[4 * i + 1] = 0.f; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = 0.f; }
@@ -95,9 +109,6 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     }
     if (vis) {
 
-    float4* grow = reinterpret_cast<float4*>(p.gacc + (size_t)i * GACC_FLOATS);
-    const float4 g0 = grow[0], g1 = grow[1], g2 = grow[2], g3 = grow[3];
-    if (p.clear_gacc) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); grow[0] = z; grow[1] = z; grow[2] = z; grow[3] = z; }
     const float4* rrow = reinterpret_cast<const float4*>(p.rec + (size_t)i * REC_FLOATS);
     const float4 r0 = rrow[0], r1 = rrow[1];
     // Moments of q = o*G*dL/dalpha over all pixels (render_bwd.hip) -> the reference's quantities
