@@ -3,17 +3,25 @@
 train-step (rasterizer forward + backward) at 1920x1080 on 1M random-init Gaussians, SH degree 3
 (BASELINE.json configs[2], "C3" of SURVEY.md 8(d)); whole-job views per second over N GPUs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one view per rank: preprocess -> depth sort -> emit ->
 tile sort -> render (forward), L1 loss against a fixed random target, render backward -> preprocess
-backward, and for N > 1 one all-reduce (sum) of the Gaussian gradients over RCCL (view-parallel,
+backward, and for N > 1 the exchange (sum) of the Gaussian gradients over RCCL (view-parallel,
 SURVEY.md 8(e)).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with no WORLD_SIZE in the environment spawns the N ranks itself as child processes BEFORE
+anything in this process touches the GPU (a process that has initialised HIP must never exec), binds
+rank r to GPU r and fails (exit code 2) when the box has fewer than N devices.  IBGS_BENCH_SHARE_GPU=1
+with IBGS_DIST_BACKEND=gloo lets the ranks share one device (tests of the N > 1 code path on 1-GPU boxes).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,43 +33,223 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ibgs_amd import _lib, synthetic as syn  # noqa: E402
+from ibgs_amd._build import csrc_sha  # noqa: E402
 from ibgs_amd import dist as vdist  # noqa: E402
 from ibgs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 
-HBM_PEAK = 8.0e12  # bytes/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+HBM_PEAK = 8.0e12   # bytes/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+CLOCK_HZ = 2.4e9    # MI355X_MICROARCH.md "Max clock"
+SIMDS = 1024        # 256 CUs x 4 SIMDs
+VALU_CYCLES = 2.0   # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md "Wave scheduling")
 
 
-def algorithmic_bytes(P, R, HW, Mc, tiles):
-    """SURVEY.md 8(d) byte model (implementation independent). Returns (B_fwd, B_bwd, B_render_bwd)."""
+def algorithmic_bytes(P, R, HW, Mc, tiles, geo=False, n_src=0):
+    """SURVEY.md 8(d) byte model (implementation independent). Returns (B_fwd, B_bwd, B_render_fwd, B_render_bwd)."""
     bit = int(np.ceil(np.log2(max(tiles, 2))))
     n_pass = -(-(32 + bit) // 8)
     b_fwd = P * (44 + 12 * Mc + 79) + R * (12 + 24 * n_pass + 8 + 40) + HW * 20
+    b_render_fwd = HW * 20 + R * 40
     b_render_bwd = HW * 20 + R * 40 + P * 112
     b_bwd = b_render_bwd + P * (44 + 12 * Mc + 56) + P * (12 * Mc + 12 + 12 + 16 + 24)
-    return b_fwd, b_bwd, b_render_bwd
+    if geo:
+        b_fwd += P * 20 + R * 20 + HW * 228 + n_src * HW * 16
+        b_render_fwd += R * 20 + HW * 228 + n_src * HW * 16
+        b_bwd += HW * (16 + 60 + 4 + 52) + R * 20 + P * 40
+        b_render_bwd += HW * (16 + 60 + 4 + 52) + R * 20 + P * 40
+    return b_fwd, b_bwd, b_render_fwd, b_render_bwd
 
 
-def build_inputs(cfg, view, dev, opacity):
-    c = syn.CONFIGS[cfg]
-    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"], view=view, opacity=opacity)
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
-    P = c["P"]
-    leaves = {
-        "means3D": t(inp["means3D"]).requires_grad_(True), "shs": t(inp["shs"]).requires_grad_(True),
-        "opacities": t(inp["opacities"]).reshape(P, 1).requires_grad_(True),
-        "scales": t(inp["scales"]).requires_grad_(True), "rotations": t(inp["rotations"]).requires_grad_(True),
-        "means2D": torch.zeros(P, 3, device=dev, requires_grad=True),
-        "means2D_abs": torch.zeros(P, 3, device=dev, requires_grad=True),
-    }
-    H, W = c["H"], c["W"]
-    z = lambda *s: torch.zeros(*s, device=dev)
-    st = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=float(inp["tanfovx"]), tanfovy=float(inp["tanfovy"]), bg=t(inp["bg"]),
-        scale_modifier=1.0, viewmatrix=t(inp["viewmatrix"]), projmatrix=t(inp["projmatrix"]),
-        ref_to_src_list=z(1, 16), src_cam_pos=z(1, 3), src_images=z(1, 3, 1), src_rendered_depths=z(1, 1, 1),
-        nb_src_images=1, buffer_length=4, depth_error_threshold=0.01, sh_degree=c["sh_degree"], campos=t(inp["campos"]),
-        prefiltered=False, render_geo=False, render_depth_only=False, debug=False)
-    return inp, leaves, st, c
+def profile_counters(kernel_substr, workload_tag):
+    """Per-launch PMC counters of one kernel from the committed rocprofv3 summary (profiles/counters_latest.json, written by
+    profiles/summarize.py).  Returns (counters, source) -- (None, reason) when the summary was taken on other kernel
+    sources or another workload: stale numbers are dropped, not quoted next to fresh timings."""
+    path = os.path.join(ROOT, "profiles", "counters_latest.json")
+    if not os.path.exists(path):
+        return None, "no profiles/counters_latest.json"
+    try:
+        d = json.load(open(path))
+    except Exception as ex:   # noqa: BLE001
+        return None, "unreadable profile summary: %s" % ex
+    if d.get("csrc_sha") != csrc_sha():
+        return None, "profile taken on csrc %s, this build is %s" % (d.get("csrc_sha"), csrc_sha())
+    if d.get("workload") != workload_tag:
+        return None, "profile workload %r != %r" % (d.get("workload"), workload_tag)
+    for k, c in d.get("per_launch_counters", {}).items():
+        if kernel_substr in k:
+            return c, "profiles/%s @ csrc %s (%s)" % (d.get("tag", "counters_latest") + "_counters.json", d["csrc_sha"], d.get("date", "?"))
+    return None, "kernel %s not in the profile summary" % kernel_substr
+
+
+class Workload:
+    """One view of one BASELINE config resident on `dev`: leaves, settings, the step closure."""
+
+    def __init__(self, cfg, view, dev, opacity, geo, forward_only, target_seed):
+        c = syn.CONFIGS[cfg]
+        inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"], view=view, opacity=opacity)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+        P, H, W = c["P"], c["H"], c["W"]
+        self.c, self.cfg, self.inp, self.geo, self.forward_only, self.dev = c, cfg, inp, geo, forward_only, dev
+        self.P, self.H, self.W = P, H, W
+        lv = {
+            "means3D": t(inp["means3D"]).requires_grad_(True), "shs": t(inp["shs"]).requires_grad_(True),
+            "opacities": t(inp["opacities"]).reshape(P, 1).requires_grad_(True),
+            "scales": t(inp["scales"]).requires_grad_(True), "rotations": t(inp["rotations"]).requires_grad_(True),
+            "means2D": torch.zeros(P, 3, device=dev, requires_grad=True),
+            "means2D_abs": torch.zeros(P, 3, device=dev, requires_grad=True),
+        }
+        z = lambda *s: torch.zeros(*s, device=dev)
+        st = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=float(inp["tanfovx"]), tanfovy=float(inp["tanfovy"]), bg=t(inp["bg"]),
+            scale_modifier=1.0, viewmatrix=t(inp["viewmatrix"]), projmatrix=t(inp["projmatrix"]),
+            ref_to_src_list=z(1, 16), src_cam_pos=z(1, 3), src_images=z(1, 3, 1), src_rendered_depths=z(1, 1, 1),
+            nb_src_images=1, buffer_length=4, depth_error_threshold=0.01, sh_degree=c["sh_degree"], campos=t(inp["campos"]),
+            prefiltered=False, render_geo=False, render_depth_only=False, debug=False)
+        if geo:
+            # sources = the 4 nearest other orbit views; their images / depth maps are this op's own renders (untimed)
+            ref_cam = inp["_cam"]
+            src_ids = [(view + d) % 8 for d in (1, 7, 2, 6)]
+            src_cams = [syn.make_camera(W, H, azimuth_deg=45.0 * k) for k in src_ids]
+            imgs, deps = [], []
+            with torch.no_grad():
+                for sc in src_cams:
+                    am = t(syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], sc))
+                    for depth_only in (False, True):
+                        sst = st._replace(viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]), campos=t(sc["campos"]),
+                                          render_depth_only=depth_only)
+                        o = GaussianRasterizer(sst)(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"],
+                                                    opacities=lv["opacities"], shs=lv["shs"], scales=lv["scales"],
+                                                    rotations=lv["rotations"], all_map=am)
+                        (deps if depth_only else imgs).append(o[3].clone() if depth_only else o[0].clone())
+            r2s, scp = syn.ref_to_src(ref_cam, src_cams)
+            lv["all_map"] = t(syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], ref_cam)).requires_grad_(True)
+            st = st._replace(ref_to_src_list=t(r2s), src_cam_pos=t(scp), src_images=torch.stack(imgs), src_rendered_depths=torch.stack(deps),
+                             nb_src_images=4, buffer_length=4, depth_error_threshold=0.01, render_geo=True)
+        self.leaves, self.st = lv, st
+        self.rast = GaussianRasterizer(st)
+        self.target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(target_seed))
+        self.params = [lv[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        self.R = 0
+
+    def _call(self):
+        lv = self.leaves
+        return self.rast(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
+                         shs=lv["shs"], scales=lv["scales"], rotations=lv["rotations"], all_map=lv.get("all_map"))
+
+    def fwd_only(self):
+        from ibgs_amd import rasterizer as _r
+        with torch.no_grad():
+            self._call()
+        self.R = _r.LAST_NUM_RENDERED
+
+    def local_step(self, backward=None):
+        """forward + loss + backward of this rank's view; `backward(loss)` lets the caller wrap autograd (gradient capture)."""
+        if self.forward_only:
+            return self.fwd_only()
+        for v in self.leaves.values():
+            v.grad = None
+        outs = self._call()
+        loss = torch.nn.functional.l1_loss(outs[0], self.target)
+        if self.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
+            loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
+        self.R = outs[0].grad_fn.num_rendered
+        if backward is None:
+            loss.backward()
+        else:
+            backward(loss)
+
+    def kernel_names(self):
+        tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        big = tiles >= 4096
+        if self.geo:
+            return ("render_fwd_kernel<1, 2, 4>" if big else "render_fwd_kernel<1, 1, 4>"), ("render_bwd_geo2_kernel" if big else "render_bwd_geo_kernel")
+        return ("render_fwd_kernel<0, 4, 4>" if big else "render_fwd_kernel<0, 1, 4>"), ("render_bwd_color_kernel" if big else "render_bwd_color_small_kernel")
+
+    def describe(self, opacity, world, exchange):
+        c = self.c
+        return "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, opacity=%s%s, one view per GPU%s" % (
+            self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target",
+            opacity, ", render_geo n_src=4 L=4" if self.geo else "", (", RCCL gradient exchange (%s)" % exchange) if world > 1 else "")
+
+
+def fence(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
+    """W untimed warm-ups, then EXACTLY K steps between barrier + synchronize on both sides (wall clock, max over ranks);
+    every timed step is also bracketed by hipEvents on the op's stream (= torch's current stream) for the median."""
+    kstage = "render_fwd" if wl.forward_only else "render_bwd"
+    for _ in range(warmup):
+        step()
+    _lib.timing_enable([kstage])     # hipEvents around the dominant kernel only, on the op's stream
+    _lib.timing_collect()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    fence(world)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    fence(world)
+    dt = time.perf_counter() - t0
+    tm = _lib.timing_collect()
+    _lib.timing_enable([])
+    per_step = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        tt = torch.tensor([dt], device=wl.dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # forward-only time of the same workload (SURVEY 8(d): "report fwd-only and fwd+bwd separately"), untimed for `value`
+    fence(world)
+    tf = time.perf_counter()
+    for _ in range(n_fwd):
+        wl.fwd_only()
+    fence(world)
+    fwd_ms = (time.perf_counter() - tf) / n_fwd * 1e3
+    # per-stage breakdown from a few extra (untimed) steps
+    _lib.timing_enable(_lib.STAGES)
+    for _ in range(n_stage_steps):
+        step()
+    torch.cuda.synchronize()
+    stages = {k: v[0] / float(n_stage_steps) for k, v in _lib.timing_collect().items()}
+    _lib.timing_enable([])
+    return {"dt": dt, "ms_step": dt / steps * 1e3, "median_ms": statistics.median(per_step), "min_ms": min(per_step),
+            "kernel_ms": tm[kstage][0] / max(tm[kstage][1], 1), "fwd_ms": fwd_ms, "stages": stages}
+
+
+def roofline(wl, m, workload_tag):
+    """Roofline object of the dominant kernel.  The blend kernels are VALU-issue bound: `bound` says so and
+    `valu` holds the issue-rate fraction; achieved / peak / frac stay the HBM figures of SURVEY 8(d) (algorithmic bytes of
+    that launch / its live hipEvent duration / 8 TB/s)."""
+    P, H, W = wl.P, wl.H, wl.W
+    R = int(wl.R); HW = H * W; Mc = int(wl.inp["shs"].shape[1]); tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    b_fwd, b_bwd, b_rfwd, b_rbwd = algorithmic_bytes(P, R, HW, Mc, tiles, wl.geo, 4 if wl.geo else 0)
+    kf, kb = wl.kernel_names()
+    kernel, kbytes = (kf, b_rfwd) if wl.forward_only else (kb, b_rbwd)
+    k_ms = m["kernel_ms"]
+    achieved = kbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    ctr, src = profile_counters(kernel.split("<")[0] if not wl.forward_only else kernel, workload_tag)
+    traffic, valu, mfma = None, None, None
+    if ctr is not None:
+        if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            # MI355X_MICROARCH.md "HBM": counters in KiB; FETCH_SIZE reports half the bytes of 16-B-per-lane reads on gfx950
+            traffic = 2.0 * ctr["FETCH_SIZE"] * 1024.0 + ctr["WRITE_SIZE"] * 1024.0
+        if "SQ_INSTS_VALU" in ctr and k_ms > 0:
+            cyc = k_ms * 1e-3 * CLOCK_HZ
+            valu = {"wave_valu_insts_per_launch": ctr["SQ_INSTS_VALU"], "frac": ctr["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * cyc),
+                    "cycles_per_inst": SIMDS * cyc / ctr["SQ_INSTS_VALU"], "peak": "1 wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs at 2.4 GHz",
+                    "source": src}
+        if "SQ_INSTS_VALU_MFMA_MOPS_F32" in ctr or "SQ_VALU_MFMA_BUSY_CYCLES" in ctr:
+            mfma = {"busy_cycles": ctr.get("SQ_VALU_MFMA_BUSY_CYCLES"), "mops_f32": ctr.get("SQ_INSTS_VALU_MFMA_MOPS_F32"), "source": src}
+    step_bytes = b_fwd if wl.forward_only else b_fwd + b_bwd
+    return {"bound": "valu", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": src if traffic is not None else None,
+            "algorithmic_bytes_per_launch": kbytes, "kernel_ms": k_ms,
+            "valu": valu, "valu_note": None if valu is not None else src,
+            "mfma_utilisation": 0.0 if mfma is None else mfma,   # no kernel of this path is a dense contraction (DESIGN.md "MFMA", measured probe)
+            "step_algorithmic_bytes": step_bytes, "step_frac": step_bytes / (m["ms_step"] * 1e-3) / HBM_PEAK}
 
 
 def cpu_baseline(inp, c):
@@ -81,6 +269,46 @@ def cpu_baseline(inp, c):
                       % (t1 - t0, t2 - t1, c)}
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (this process has not touched the
+    GPU and never will), rank r on GPU r, rendezvous on 127.0.0.1.  Exit code = first failing rank's, 2 if devices are missing."""
+    n = a.gpus
+    ndev = torch.cuda.device_count()          # counting devices does not initialise HIP on this image
+    share = os.environ.get("IBGS_BENCH_SHARE_GPU") == "1"
+    if ndev < n and not share:
+        sys.stderr.write("bench.py: --gpus %d but this box has %d GPU(s); refusing to benchmark fewer ranks than asked for\n" % (n, ndev))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("IBGS_BENCH_TIMEOUT", "1500"))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:       # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        if alive and time.time() > deadline:
+            for q in alive:
+                q.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,171 +320,103 @@ def main():
     ap.add_argument("--exchange", default="factored", choices=["factored", "dense"],
                     help="N > 1: factored = all-gather 3-float dL/dRGB per view + local SH expansion (default); dense = all-reduce of every gradient")
     ap.add_argument("--forward-only", action="store_true", help="time the forward render alone (BASELINE configs[1]: --config C2 --forward-only)")
-    ap.add_argument("--geo", action="store_true", help="second line of SURVEY 8(d): render_geo=True, n_src=4, L=4")
+    ap.add_argument("--geo", action="store_true", help="make render_geo=True, n_src=4, L=4 the timed workload (second line of SURVEY 8(d))")
+    ap.add_argument("--no-geo-line", action="store_true", help="skip the extra (untimed for `value`) geo measurement in the default line")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))
+
     rank, world, local_rank = vdist.init_from_env(backend=os.environ.get("IBGS_DIST_BACKEND"))   # default: nccl (= RCCL)
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    local_rank %= max(torch.cuda.device_count(), 1)      # lets a 1-GPU box run the N > 1 code path over gloo
+    ndev = torch.cuda.device_count()
+    backend = dist.get_backend() if world > 1 else None
+    if world > ndev and not (os.environ.get("IBGS_BENCH_SHARE_GPU") == "1" and backend == "gloo"):
+        raise SystemExit("bench.py: %d ranks but %d GPU(s)" % (world, ndev))
+    local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.load()
 
-    inp, leaves, st, c = build_inputs(a.config, rank % 8, dev, a.opacity)
-    H, W, P = c["H"], c["W"], c["P"]
-    if a.geo:
-        # sources = the 4 nearest other orbit views; their images / depth maps are this op's own renders (untimed)
-        tt = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
-        ref_cam = inp["_cam"]
-        src_ids = [(rank + d) % 8 for d in (1, 7, 2, 6)]
-        src_cams = [syn.make_camera(W, H, azimuth_deg=45.0 * k) for k in src_ids]
-        imgs, deps = [], []
-        with torch.no_grad():
-            for sc in src_cams:
-                am = tt(syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], sc))
-                for depth_only in (False, True):
-                    sst = st._replace(viewmatrix=tt(sc["viewmatrix"]), projmatrix=tt(sc["projmatrix"]), campos=tt(sc["campos"]),
-                                      render_depth_only=depth_only)
-                    o = GaussianRasterizer(sst)(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
-                                                opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"],
-                                                rotations=leaves["rotations"], all_map=am)
-                    (deps if depth_only else imgs).append(o[3].clone() if depth_only else o[0].clone())
-        r2s, scp = syn.ref_to_src(ref_cam, src_cams)
-        leaves["all_map"] = tt(syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], ref_cam)).requires_grad_(True)
-        st = st._replace(ref_to_src_list=tt(r2s), src_cam_pos=tt(scp), src_images=torch.stack(imgs), src_rendered_depths=torch.stack(deps),
-                         nb_src_images=4, buffer_length=4, depth_error_threshold=0.01, render_geo=True)
-    rast = GaussianRasterizer(st)
-    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
-    params = [leaves[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
-    bucket = vdist.GradBucket(params) if world > 1 else None
-    reducer = vdist.ViewParallelReducer(params, sh=leaves["shs"], means3D=leaves["means3D"]) if (world > 1 and a.exchange == "factored") else None
-    R_seen = [0]
-
-    def fwd_only():
-        with torch.no_grad():
-            rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
-                 opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
-                 all_map=leaves.get("all_map"))
+    wl = Workload(a.config, rank % 8, dev, a.opacity, a.geo, a.forward_only, 1234 + rank)
+    reducer = None
+    if world > 1:
+        reducer = vdist.ViewParallelReducer(wl.params, sh=wl.leaves["shs"], means3D=wl.leaves["means3D"], factored=(a.exchange == "factored"))
 
     def step():
-        if a.forward_only:
-            return fwd_only()
-        for v in leaves.values():
-            v.grad = None
-        outs = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"],
-                    opacities=leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
-                    all_map=leaves.get("all_map"))
-        loss = torch.nn.functional.l1_loss(outs[0], target)
-        if a.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
-            loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
-        R_seen[0] = outs[0].grad_fn.num_rendered
-        if reducer is not None:
+        if reducer is None or a.forward_only:
+            return wl.local_step()
+
+        def bw(loss):
             with reducer.capture():
                 loss.backward()
-            reducer.reduce()
-        else:
-            loss.backward()
-            if world > 1:
-                vdist.allreduce_gradients(params, bucket)
+        wl.local_step(bw)
+        reducer.reduce()
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    m = measure(wl, step, a.steps, a.warmup, world)
+    rccl = None
+    if world > 1 and not a.forward_only:
+        # serial cost of the exchange alone (hipEvents around reduce() on the compute stream, which waits for the collectives),
+        # and the step without any exchange; neither enters `value`
+        n_x = 5
+        xs = []
+        for _ in range(n_x):
+            def bw(loss):
+                with reducer.capture():
+                    loss.backward()
+            wl.local_step(bw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); reducer.reduce(); e1.record()
+            torch.cuda.synchronize()
+            xs.append(e0.elapsed_time(e1))
+        fence(world)
+        t0 = time.perf_counter()
+        for _ in range(n_x):
+            wl.local_step()
+        fence(world)
+        local_ms = (time.perf_counter() - t0) / n_x * 1e3
+        rccl = {"world": dist.get_world_size(), "backend": backend, "exchange": a.exchange, "exchange_ms": statistics.median(xs),
+                "step_without_exchange_ms": local_ms, "exposed_ms": m["ms_step"] - local_ms,
+                "bytes_per_rank": reducer.last_bytes}
 
-    for _ in range(a.warmup):
-        step()
-    _lib.timing_enable(["render_fwd" if a.forward_only else "render_bwd"])   # hipEvents around the dominant kernel only, on the op's stream
-    _lib.timing_collect()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    tm = _lib.timing_collect()
-    _lib.timing_enable([])
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # forward-only time of the same workload ("report fwd-only and fwd+bwd separately"), untimed for `value`
-    fence()
-    tf = time.perf_counter()
-    for _ in range(10):
-        fwd_only()
-    fence()
-    fwd_ms = (time.perf_counter() - tf) / 10 * 1e3
-
-    # per-stage breakdown from a few extra (untimed) steps
-    _lib.timing_enable(_lib.STAGES)
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    stages = {k: (v[0] / max(v[1], 1)) * (v[1] / 3.0) for k, v in _lib.timing_collect().items()}
-    _lib.timing_enable([])
+    geo_line = None
+    if world == 1 and not (a.geo or a.forward_only or a.no_geo_line):
+        # second line of SURVEY 8(d) under the same clock: C3 + render_geo, n_src 4, L 4 (extra key; never part of `value`)
+        del step
+        gwl = Workload(a.config, rank % 8, dev, a.opacity, True, False, 1234 + rank)
+        gsteps = max(5, min(20, a.steps))
+        gm = measure(gwl, gwl.local_step, gsteps, 3, 1, n_fwd=5)
+        grf = roofline(gwl, gm, "%s geo opacity=%s" % (a.config, a.opacity))
+        geo_line = {"workload": gwl.describe(a.opacity, 1, a.exchange), "steps": gsteps, "ms_per_step": gm["ms_step"],
+                    "median_ms_hipevent": gm["median_ms"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
+                    "num_rendered": int(gwl.R), "stages_ms": gm["stages"], "roofline": grf}
+        del gwl
 
     if rank == 0:
-        ms_step = dt / a.steps * 1e3
-        if a.forward_only:
-            with torch.no_grad():
-                o = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], means2D_abs=leaves["means2D_abs"], opacities=leaves["opacities"],
-                         shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"], all_map=leaves.get("all_map"))
-            from ibgs_amd import rasterizer as _r
-            R_seen[0] = _r.LAST_NUM_RENDERED
-        R = int(R_seen[0]); HW = H * W; Mc = int(inp["shs"].shape[1]); tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        b_fwd, b_bwd, b_rbwd = algorithmic_bytes(P, R, HW, Mc, tiles)
-        kstage = "render_fwd" if a.forward_only else "render_bwd"
-        k_ms = tm[kstage][0] / max(tm[kstage][1], 1)
-        if a.forward_only:
-            b_rbwd = HW * 20 + R * 40          # the forward blend's share of B_fwd (records + per-pixel outputs)
-        achieved = b_rbwd / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and a.config == "C3" and not (a.geo or a.forward_only or a.opacity != "init"):   # the profiled workload only
-            try:
-                traffic = json.load(open(tpath)).get("render_bwd_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # what the dominant kernel is actually bound by: wave-VALU instructions per launch from the committed PMC pass,
-        # divided by this run's kernel time -> instructions per cycle per SIMD (the chip issues at most one per ~2.6 cycles)
-        valu = None
-        cpath = os.path.join(ROOT, "profiles", "r01_counters.json")
-        if traffic is not None and os.path.exists(cpath) and k_ms > 0:
-            try:
-                ctr = json.load(open(cpath))["per_launch_counters"]["render_bwd_color_kernel"]
-                ipc = ctr["SQ_INSTS_VALU"] / (1024.0 * k_ms * 1e-3 * 2.4e9)
-                valu = {"wave_valu_insts_per_launch": ctr["SQ_INSTS_VALU"], "insts_per_cycle_per_simd": ipc, "cycles_per_inst": 1.0 / ipc,
-                        "clock_ghz": 2.4, "simds": 1024}
-            except Exception:
-                valu = None
+        tag = "%s%s%s opacity=%s" % (a.config, " geo" if a.geo else "", " forward-only" if a.forward_only else "", a.opacity)
+        rf = roofline(wl, m, tag)
         out = {
             "metric": ("forward render fps " + a.config) if a.forward_only else
                       ("train-step fps (fwd+bwd raster) @1080p, 1M Gaussians" if a.config == "C3" else "train-step fps (fwd+bwd raster) " + a.config),
-            "value": world * a.steps / dt, "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": world * a.steps / m["dt"], "unit": "fps", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": m["ms_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, "
-                                   "opacity=%s%s, one view per GPU%s" % (a.config, P, W, H, c["sh_degree"], "forward only" if a.forward_only else "fwd+bwd, L1 loss vs fixed random target", a.opacity, ", render_geo n_src=4 L=4" if a.geo else "",
-                                                                        (", RCCL gradient exchange (%s)" % a.exchange) if world > 1 else ""),
-                       "num_rendered": R, "parallelism": "view-parallel x%d" % world},
-            "forward_only_ms": fwd_ms,
-            "roofline": {"bound": "hbm", "kernel": ("render_fwd_kernel" if a.forward_only else (("render_bwd_geo2_kernel" if tiles >= 4096 else "render_bwd_geo_kernel") if a.geo else ("render_bwd_color_kernel" if tiles >= 4096 else "render_bwd_color_small_kernel"))), "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_rbwd, "kernel_ms": k_ms,
-                         "valu_issue": valu,
-                         "mfma_utilisation": 0.0,        # by design: no kernel of this path is a dense contraction (DESIGN.md "MFMA")
-                         "step_algorithmic_bytes": b_fwd if a.forward_only else b_fwd + b_bwd,
-                         "step_frac": (b_fwd if a.forward_only else b_fwd + b_bwd) / (ms_step * 1e-3) / HBM_PEAK},
-            "stages_ms": stages,
+            "config": {"workload": wl.describe(a.opacity, world, a.exchange), "num_rendered": int(wl.R), "parallelism": "view-parallel x%d" % world},
+            "median_ms_hipevent": m["median_ms"], "min_ms_hipevent": m["min_ms"],
+            "forward_only_ms": m["fwd_ms"],
+            "roofline": rf,
+            "stages_ms": m["stages"],
         }
+        if rccl is not None:
+            out["rccl"] = rccl
+        if geo_line is not None:
+            out["geo"] = geo_line
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(inp, a.config)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(wl.inp, a.config)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,6 +37,19 @@ def _newest_dep():
     return max(os.path.getmtime(d) for d in deps)
 
 
+def csrc_sha():
+    """Fingerprint of the kernel sources (csrc/*.hip, csrc/*.h, include/ibgs_rast.h).  profiles/summarize.py stamps it into the
+    committed rocprofv3 summaries and bench.py quotes profile-derived numbers only when the stamp matches this tree."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "ibgs_rast.h"), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -75,8 +75,8 @@ def allreduce_gradients(params, bucket=None, group=None, average=False):
     Returns the bucket so that callers can reuse it across steps."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return bucket
-    if bucket is None:
-        bucket = GradBucket(params)
+    if bucket is None or bucket.numels != [p.numel() for p in params] or bucket.flat.device != params[0].device:
+        bucket = GradBucket(params)            # first call, or the trainer replaced its tensors (densification changes P)
     flat = bucket.pack([p.grad for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
@@ -89,6 +89,15 @@ def allreduce_gradients(params, bucket=None, group=None, average=False):
     return bucket
 
 
+def _resolve(x):
+    """tensor | list of tensors | zero-argument callable returning either -> list of tensors (or [])."""
+    if callable(x) and not isinstance(x, torch.Tensor):
+        x = x()
+    if x is None:
+        return []
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
 class ViewParallelReducer:
     """Gradient exchange of one view-parallel step, sized for xGMI (point-to-point links: bytes per rank are
     what costs).  For SH degree 3 the SH coefficients are 48 of the 59 gradient floats per Gaussian, but the
@@ -97,26 +106,66 @@ class ViewParallelReducer:
     the summed dL/dsh locally (`ibgs_sh_grad_from_views`); only the remaining parameters go through the flat
     all-reduce.  Per rank at P = 1M, 8 ranks: ~77 MB + 84 MB on the links instead of ~413 MB.
 
-        red = ViewParallelReducer(params, sh=shs_param, means3D=xyz_param)
+        red = ViewParallelReducer(params, sh=[f_dc, f_rest], means3D=xyz)
         with red.capture():            # one or more backward passes (views) per rank
             loss.backward()
         red.reduce()                   # every p.grad now holds the sum over all ranks' views
 
-    The result equals the sequential accumulation of the single-view gradients (summation order differs)."""
+    The result equals the sequential accumulation of the single-view gradients (summation order differs).
 
-    def __init__(self, params, sh=None, means3D=None, group=None, expand=None):
-        # `sh`: the SH tensor handed to the rasterizer, or -- when that is a torch.cat of leaves along dim 1 as in the
-        # reference's GaussianModel.get_features (scene/gaussian_model.py:140-143) -- the list of those leaves
-        self.sh_parts = list(sh) if isinstance(sh, (list, tuple)) else ([sh] if sh is not None else [])
-        self.sh, self.means3D, self.group = (self.sh_parts[0] if self.sh_parts else None), means3D, group
-        self.dense = [p for p in params if not any(p is q for q in self.sh_parts)]
+    `params`, `sh`, `means3D` may be tensors / lists OR zero-argument callables that return them.  Pass callables
+    (e.g. ``lambda: [g["params"][0] for g in optimizer.param_groups]``) when the trainer replaces its Parameters --
+    the reference's densification does (scene/gaussian_model.py:377-463: cat_tensors_to_optimizer, _prune_optimizer):
+    they are re-resolved on every reduce() and the flat bucket is rebuilt when sizes change.  A fixed list that has
+    gone stale (no gradient on any tensor, or a Gaussian count that differs from the captured views') raises.
+
+    Order of one reduce() (collectives are issued with async_op, i.e. on the backend's own stream):
+      1. agreement: a few integers (views captured, P, M, degree, "has a dense SH gradient") are all-reduced on the
+         HOST over a gloo side group, so ranks can never enter different collective sequences (a rank that captured
+         nothing would otherwise leave the others hanging in the all-gather); it costs no GPU time -- the GPU is still
+         running the backward kernels enqueued before;
+      2. all-gather of the dL/dRGB factors (ready first);  3. flat all-reduce of the dense gradients;
+      4. SH expansion on the compute stream as soon as the gather has landed, WHILE the all-reduce is in flight;
+      5. unpack.
+    SH gradients that did not come through the factored path (a backward outside capture(), colours converted in
+    Python, another loss term on the SH leaves) are detected in step 1 and all-reduced densely on every rank."""
+
+    def __init__(self, params, sh=None, means3D=None, group=None, expand=None, factored=True):
+        self._params, self._sh, self._means3D = params, sh, means3D
+        self.group, self._expand, self.factored = group, expand, factored
         self.bucket = None
         self.items = None
-        self._expand = expand
+        self.last_bytes = 0
+        self._agree = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # host-side agreement channel: the default group when it is gloo already, else a gloo twin of it
+            if dist.get_backend(group) == "gloo":
+                self._agree = group if group is not None else dist.group.WORLD
+            else:
+                self._agree = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend="gloo")
+
+    # kept for callers that used the old attribute names
+    @property
+    def sh_parts(self):
+        return _resolve(self._sh)
+
+    @property
+    def means3D(self):
+        m = _resolve(self._means3D)
+        return m[0] if m else None
 
     def capture(self):
         from . import rasterizer
         red = self
+        if not self.factored:
+            class _Null:
+                def __enter__(self):
+                    red.items = []
+                    return red.items
+
+                def __exit__(self, *exc):
+                    return False
+            return _Null()
 
         class _Ctx(rasterizer.capture_sh_factors):
             def __enter__(self):
@@ -124,37 +173,97 @@ class ViewParallelReducer:
                 return red.items
         return _Ctx()
 
+    def _bucket_for(self, tensors):
+        numels = [t.numel() for t in tensors]
+        if self.bucket is None or self.bucket.numels != numels or self.bucket.flat.device != tensors[0].device:
+            self.bucket = GradBucket(tensors)
+        return self.bucket
+
     def reduce(self, average=False):
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1:
-            self.bucket = allreduce_gradients(self.dense, self.bucket, self.group, average)
+        params, sh_parts, means3D = _resolve(self._params), self.sh_parts, self.means3D
         items, self.items = self.items or [], None
-        if self.sh is None or not items:
-            return
-        expand = self._expand
-        if expand is None:
-            from .shgrad import sh_grad_from_views as expand
-        degree, M = items[0]["degree"], items[0]["M"]
-        n_local, P = len(items), int(items[0]["dcolor"].shape[0])
-        # one buffer per exchange: each view's (P, 3) factor followed by its camera centre -> ONE all-gather
-        buf = torch.empty(n_local, P + 1, 3, dtype=torch.float32, device=items[0]["dcolor"].device)
-        for i, it in enumerate(items):
-            buf[i, :P] = it["dcolor"]
-            buf[i, P] = it["campos"].to(buf.device)
+        dense = [p for p in params if not any(p is q for q in sh_parts)]
+        # ---- local sanity (stale references after densification surface here, not as silently frozen parameters)
+        if params and all(p.grad is None for p in params) and not items:
+            raise RuntimeError("ViewParallelReducer.reduce(): no tensor in `params` has a gradient -- were the Parameters replaced "
+                               "(densification)? Pass callables for params / sh / means3D or rebuild the reducer.")
+        n_local = len(items)
+        P = int(items[0]["dcolor"].shape[0]) if items else (int(means3D.shape[0]) if means3D is not None else -1)
+        M = int(items[0]["M"]) if items else -1
+        degree = int(items[0]["degree"]) if items else -1
+        for it in items:
+            if int(it["dcolor"].shape[0]) != P or int(it["M"]) != M or int(it["degree"]) != degree:
+                raise RuntimeError("ViewParallelReducer: captured views disagree on (P, M, degree)")
+        if items and (means3D is None or int(means3D.shape[0]) != P):
+            raise RuntimeError("ViewParallelReducer: means3D has %s rows but the captured views have P = %d (stale reference after "
+                               "densification?)" % ("no" if means3D is None else int(means3D.shape[0]), P))
+        if items and sum(int(q.shape[1]) for q in sh_parts) != M:
+            raise RuntimeError("ViewParallelReducer: the `sh` leaves hold %d coefficients, the captured views M = %d"
+                               % (sum(int(q.shape[1]) for q in sh_parts), M))
+        # an SH gradient that did not come through the factored path must be reduced densely
+        sh_dense = any(q.grad is not None for q in sh_parts)
+        # ---- agreement across ranks, on the host
         if world > 1:
-            allb = torch.empty(world * n_local, P + 1, 3, dtype=buf.dtype, device=buf.device)
-            dist.all_gather_into_tensor(allb, buf, group=self.group)
-            buf = allb
-        dcolor, campos = buf[:, :P], buf[:, P].contiguous()      # dcolor keeps the (P + 1) * 3 view stride
-        g = expand(self.means3D.detach(), campos, dcolor, degree, M)
-        if average:
-            g = g / world
-        off = 0
-        for part in self.sh_parts:                      # (P, M_i, 3) slices of the (P, M, 3) result
-            m = part.shape[1]
-            gp = g[:, off:off + m, :].contiguous() if len(self.sh_parts) > 1 else g.view_as(part)
-            part.grad = gp if part.grad is None else part.grad + gp
-            off += m
+            mine = [n_local, P, M, degree, sum(p.numel() for p in dense), sum(q.numel() for q in sh_parts)]
+            v = torch.tensor(mine + [-x for x in mine] + [int(sh_dense)], dtype=torch.int64)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._agree)
+            k = len(mine)
+            hi, lo = v[:k].tolist(), [-x for x in v[k:2 * k].tolist()]
+            if hi != lo:
+                raise RuntimeError("ViewParallelReducer: ranks disagree on (views captured, P, M, degree, dense numel, sh numel): "
+                                   "max %s min %s -- every rank must run the same number of backward passes inside capture()" % (hi, lo))
+            sh_dense = bool(v[2 * k].item())
+        # ---- 2. factors on the wire first
+        work_g, buf = None, None
+        if items:
+            dev = items[0]["dcolor"].device
+            # one buffer per exchange: each view's (P, 3) factor followed by its camera centre -> ONE all-gather
+            buf = torch.empty(n_local, P + 1, 3, dtype=torch.float32, device=dev)
+            for i, it in enumerate(items):
+                buf[i, :P] = it["dcolor"]
+                buf[i, P] = it["campos"].to(dev)
+            if world > 1:
+                allb = torch.empty(world * n_local, P + 1, 3, dtype=buf.dtype, device=dev)
+                work_g = dist.all_gather_into_tensor(allb, buf, group=self.group, async_op=True)
+                buf = allb
+        # ---- 3. dense gradients (plus the SH leaves when some rank holds a dense SH gradient)
+        flat_list = dense + (sh_parts if sh_dense else [])
+        work_d, bucket = None, None
+        if world > 1 and flat_list:
+            bucket = self._bucket_for(flat_list)
+            flat = bucket.pack([p.grad for p in flat_list])
+            work_d = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.last_bytes = (0 if bucket is None else bucket.flat.numel() * 4) + (0 if (buf is None or world == 1) else n_local * (P + 1) * 12)
+        # ---- 4. SH expansion overlaps the all-reduce
+        g_sh = None
+        if items:
+            if work_g is not None:
+                work_g.wait()
+            expand = self._expand
+            if expand is None:
+                from .shgrad import sh_grad_from_views as expand
+            dcolor, campos = buf[:, :P], buf[:, P].contiguous()      # dcolor keeps the (P + 1) * 3 view stride
+            g_sh = expand(means3D.detach(), campos, dcolor, degree, M)
+        # ---- 5. unpack
+        if work_d is not None:
+            work_d.wait()
+            if average:
+                bucket.flat.div_(world)
+            for p, g in zip(flat_list, bucket.unpack()):
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+        if g_sh is not None:
+            if average:
+                g_sh = g_sh / world
+            off = 0
+            for part in sh_parts:                      # (P, M_i, 3) slices of the (P, M, 3) result
+                m = part.shape[1]
+                gp = g_sh[:, off:off + m, :].contiguous() if len(sh_parts) > 1 else g_sh.view_as(part)
+                part.grad = gp if part.grad is None else part.grad + gp      # part.grad (if any) is already the all-rank sum
+                off += m
 
 
 def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None):

@@ -33,7 +33,13 @@ def short(name):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    out = {}
+    # which bench workload the passes ran (bench.py's tag: "<config>[ geo][ forward-only] opacity=<init|trained>") and which kernel
+    # sources: bench.py drops these numbers as soon as either differs from what it is timing
+    workload = sys.argv[2] if len(sys.argv) > 2 else "C3 opacity=init"
+    sys.path.insert(0, ROOT)
+    from ibgs_amd._build import csrc_sha
+    import datetime
+    out = {"tag": tag, "workload": workload, "csrc_sha": csrc_sha(), "date": datetime.date.today().isoformat()}
     st = find(tag + "_stats", "kernel_stats.csv")
     if st:
         rows = list(csv.DictReader(open(st)))
@@ -49,7 +55,7 @@ def main():
             if "render_fwd" in r["Name"]:
                 out["render_fwd_avg_us_rocprof"] = float(r["AverageNs"]) / 1e3
     per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in ("_fetch", "_write", "_sq", "_tcc"):
+    for d in ("_fetch", "_write", "_sq", "_tcc", "_mfma"):
         cc = find(tag + d, "counter_collection.csv")
         if not cc:
             continue
@@ -69,7 +75,8 @@ def main():
             # records are gathered as 16-B-per-lane loads: apply the guide's x2 FETCH_SIZE correction
             out["render_bwd_bytes_per_launch"] = 2.0 * fetch + write
     json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_counters.json"), "w"), indent=1, sort_keys=True)
-    json.dump({k: out[k] for k in out if k.startswith("render_bwd")}, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1, sort_keys=True)
+    if workload == "C3 opacity=init":      # what the default bench line quotes (matched on csrc_sha + workload)
+        json.dump(out, open(os.path.join(ROOT, "profiles", "counters_latest.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({k: v for k, v in out.items() if k != "per_launch_counters"}, indent=1))
     for k, c in counters.items():
         print(k, {a: ("%.4g" % b) for a, b in c.items()})

@@ -127,3 +127,91 @@ def test_capture_restores_previous_sink():
             assert rasterizer._sh_factor_sink is inner
         assert rasterizer._sh_factor_sink is outer
     assert rasterizer._sh_factor_sink is None
+
+
+# ---- robustness of the reducer: ranks can never take different collective sequences, parameters that the
+# trainer replaced (densification) are picked up, dense SH gradients are never left rank-local ---------------------------------
+def _worker_robust(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(0)
+    P, M, deg = 30, 16, 3
+    state = {"xyz": torch.randn(P, 3, generator=g).requires_grad_(True), "sh": torch.randn(P, M, 3, generator=g).requires_grad_(True),
+             "opa": torch.rand(P, 1, generator=g).requires_grad_(True)}
+    red = vdist.ViewParallelReducer(lambda: [state["xyz"], state["sh"], state["opa"]], sh=lambda: state["sh"], means3D=lambda: state["xyz"],
+                                    expand=_expand_ref)
+    gr = torch.Generator().manual_seed(100 + rank)
+    out = {}
+
+    # (a) nothing captured (backward outside capture / colours converted in Python): the SH gradient is dense and must be summed
+    for k in state:
+        state[k].grad = torch.randn(state[k].shape, generator=gr)
+    out["a_local"] = {k: v.grad.clone() for k, v in state.items()}
+    red.reduce()
+    out["a"] = {k: v.grad.clone() for k, v in state.items()}
+
+    # (b) factored views PLUS another loss term that left a dense gradient on the SH leaf
+    for k in state:
+        state[k].grad = torch.randn(state[k].shape, generator=gr)
+    out["b_local"] = {k: v.grad.clone() for k, v in state.items()}
+    with red.capture() as sink:
+        it = {"dcolor": torch.randn(P, 3, generator=gr), "campos": torch.randn(3, generator=gr) * 4.0, "degree": deg, "M": M}
+        sink.append(it)
+    out["b_item"] = it
+    red.reduce()
+    out["b"] = {k: v.grad.clone() for k, v in state.items()}
+    out["b_means"] = state["xyz"].detach().clone()
+
+    # (c) the trainer replaces its Parameters with longer ones (densification): callables pick them up, the bucket is rebuilt
+    P2 = 41
+    state = {"xyz": torch.randn(P2, 3, generator=g).requires_grad_(True), "sh": torch.randn(P2, M, 3, generator=g).requires_grad_(True),
+             "opa": torch.rand(P2, 1, generator=g).requires_grad_(True)}
+    red._params = lambda: [state["xyz"], state["sh"], state["opa"]]; red._sh = lambda: state["sh"]; red._means3D = lambda: state["xyz"]
+    state["xyz"].grad = torch.randn(P2, 3, generator=gr); state["opa"].grad = torch.randn(P2, 1, generator=gr)
+    out["c_local"] = {k: state[k].grad.clone() for k in ("xyz", "opa")}
+    with red.capture() as sink:
+        sink.append({"dcolor": torch.randn(P2, 3, generator=gr), "campos": torch.randn(3, generator=gr), "degree": deg, "M": M})
+    red.reduce()
+    out["c"] = {k: state[k].grad.clone() for k in ("xyz", "opa")}
+    out["c_sh_shape"] = tuple(state["sh"].grad.shape)
+
+    # (d) ranks capture different numbers of views: every rank raises instead of hanging in the all-gather
+    with red.capture() as sink:
+        for _ in range(1 + rank):
+            sink.append({"dcolor": torch.randn(P2, 3, generator=gr), "campos": torch.randn(3, generator=gr), "degree": deg, "M": M})
+    try:
+        red.reduce()
+        out["d"] = "no error"
+    except RuntimeError as ex:
+        out["d"] = str(ex)
+
+    # (e) a fixed list gone stale (no gradients anywhere) raises locally
+    stale = vdist.ViewParallelReducer([torch.zeros(3, requires_grad=True)])
+    try:
+        stale.reduce()
+        out["e"] = "no error"
+    except RuntimeError as ex:
+        out["e"] = str(ex)
+    torch.save(out, os.path.join(out_dir, "g%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_never_diverges_or_hangs(tmp_path):
+    world = 2
+    mp.spawn(_worker_robust, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "g%d.pt" % r)) for r in range(world)]
+    for r in res:
+        for k in ("xyz", "sh", "opa"):       # (a) everything, the SH leaf included, is the two-rank sum
+            np.testing.assert_allclose(r["a"][k].numpy(), (res[0]["a_local"][k] + res[1]["a_local"][k]).numpy(), rtol=1e-6)
+        # (b) dense part summed over ranks + the expansion of both ranks' factors
+        campos = torch.stack([x["b_item"]["campos"] for x in res]); dcolor = torch.stack([x["b_item"]["dcolor"] for x in res])
+        want = res[0]["b_local"]["sh"] + res[1]["b_local"]["sh"] + _expand_ref(res[0]["b_means"], campos, dcolor, 3, 16)
+        np.testing.assert_allclose(r["b"]["sh"].numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r["b"]["xyz"].numpy(), (res[0]["b_local"]["xyz"] + res[1]["b_local"]["xyz"]).numpy(), rtol=1e-6)
+        for k in ("xyz", "opa"):             # (c)
+            np.testing.assert_allclose(r["c"][k].numpy(), (res[0]["c_local"][k] + res[1]["c_local"][k]).numpy(), rtol=1e-6)
+        assert r["c_sh_shape"] == (41, 16, 3)
+        assert "ranks disagree" in r["d"], r["d"]
+        assert "no tensor in `params` has a gradient" in r["e"], r["e"]
+    assert torch.equal(res[0]["b"]["sh"], res[1]["b"]["sh"])
