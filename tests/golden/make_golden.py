@@ -5,7 +5,7 @@ outputs); nothing from the reference is copied.  Re-run:  python tests/golden/ma
   sh_eval.npz      utils/sh_utils.py: eval_sh for degrees 0..3      -> pins the SH polynomial (A1)
   camera_mats.npz  utils/graphics_utils.py: getWorld2View2, getProjectionMatrix, and the
                    Camera matrix algebra of scene/cameras.py:102-105  -> pins the matrix conventions (A.1)
-  metrics.npz      utils/image_utils.py: psnr, utils/loss_utils.py: l1_loss -> parity metric definitions
+  metrics.npz      utils/image_utils.py: psnr, utils/loss_utils.py: l1_loss, ssim -> parity metric definitions
   depth_normal.npz utils/graphics_utils.py: normal_from_depth_image  -> glue row G(vii)
 """
 import math
@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 from utils.sh_utils import eval_sh  # noqa: E402
 from utils.graphics_utils import getWorld2View2, getProjectionMatrix, normal_from_depth_image, fov2focal, focal2fov  # noqa: E402
 from utils.image_utils import psnr  # noqa: E402
-from utils.loss_utils import l1_loss  # noqa: E402
+from utils.loss_utils import l1_loss, ssim  # noqa: E402
 
 rng = np.random.default_rng(20240501)
 
@@ -57,7 +57,9 @@ np.savez_compressed(os.path.join(HERE, "camera_mats.npz"), **cams)
 a = torch.tensor(rng.uniform(0, 1, size=(4, 3, 24, 32)).astype(np.float32))
 b = (a + torch.tensor(rng.normal(0, 0.05, size=a.shape).astype(np.float32))).clamp(0, 1)
 np.savez_compressed(os.path.join(HERE, "metrics.npz"), a=a.numpy(), b=b.numpy(),
-                    psnr=psnr(a, b).numpy(), l1=np.float32(l1_loss(a, b).item()))
+                    psnr=psnr(a, b).numpy(), l1=np.float32(l1_loss(a, b).item()),
+                    # utils/loss_utils.py:34-64: 11x11 Gaussian window (sigma 1.5), zero padding, C1 = 0.01^2, C2 = 0.03^2
+                    ssim=np.float32(ssim(a, b).item()), ssim_per_image=ssim(a, b, size_average=False).numpy())
 
 # ---- depth -> normal ------------------------------------------------------------------------
 depth = torch.tensor((3.0 + 0.3 * rng.normal(size=(20, 28))).astype(np.float32))

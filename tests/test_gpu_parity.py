@@ -30,32 +30,7 @@ L1_TOL = 1e-4          # north_star: forward renders within 1e-4 L1 per pixel
 GRAD_TOL = 1e-3        # gradient relative L2 <= 1e-3
 
 
-def scene(P=4000, W=208, H=144, deg=3, seed=1, opacity="init", planes=False, scale_mul=1.0):
-    inp = syn.make_scene(P, W, H, sh_degree=deg, seed=seed, opacity=opacity, with_planes=planes)
-    if scale_mul != 1.0:
-        inp["scales"] = (inp["scales"] * scale_mul).astype(np.float32)
-        if planes:
-            inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
-    return inp
-
-
-def add_sources(inp, n_src=3, L=4, seed=5, depth=None):
-    W, H = inp["W"], inp["H"]
-    srcs = [syn.make_camera(W, H, azimuth_deg=a) for a in (7.0, -7.0, 14.0, -14.0, 21.0)[:n_src]]
-    r2s, scp = syn.ref_to_src(inp["_cam"], srcs)
-    rng = np.random.default_rng(seed)
-    if depth is None:   # plausible source depths: the oracle's own depth-only render of each source view
-        deps = []
-        for s in srcs:
-            d = dict(inp); d.update(viewmatrix=s["viewmatrix"], projmatrix=s["projmatrix"], campos=s["campos"],
-                                    render_geo=False, render_depth_only=True, buffer_length=4,
-                                    all_map=syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], s))
-            deps.append(oracle.forward(d)["median_depth"])
-        depth = np.stack(deps)
-    inp = dict(inp)
-    inp.update(render_geo=True, n_src=n_src, buffer_length=L, ref_to_src=r2s, src_cam_pos=scp,
-               src_images=rng.uniform(0, 1, (n_src, 3, H, W)).astype(np.float32), src_depths=depth.astype(np.float32), depth_thr=0.05)
-    return inp
+from tests.scenes import scene, add_sources  # noqa: E402,F401  (seeded scenes shared with the fixture generators)
 
 
 def check_stages(ist, o, ref):

@@ -56,6 +56,9 @@ def test_metric_definitions():
     d = np.load(os.path.join(G, "metrics.npz"))
     np.testing.assert_allclose(metrics.psnr(d["a"], d["b"]), d["psnr"].reshape(-1), rtol=1e-5)
     assert abs(metrics.l1(d["a"], d["b"]) - float(d["l1"])) < 1e-7
+    # SSIM (utils/loss_utils.py:34-64), the third parity metric of the reference's evaluation
+    assert abs(metrics.ssim(d["a"], d["b"]) - float(d["ssim"])) < 2e-6
+    np.testing.assert_allclose(metrics.ssim(d["a"], d["b"], size_average=False), d["ssim_per_image"], atol=2e-6)
 
 
 def test_cov3d_matches_reference_covariance_activation():
