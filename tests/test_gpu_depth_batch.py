@@ -19,6 +19,7 @@ def _setup(P, W, H, n_views, seed):
     rng = np.random.default_rng(seed)
     g["normal"] = rng.normal(size=(P, 3)).astype(np.float32); g["offset"] = (0.03 * rng.normal(size=(P, 1))).astype(np.float32)
     pc = simple_scene.SimpleGaussians(g, sh_degree=1, device=dev)
+    pc._gnp = g                                       # the numpy originals, for the oracle comparison
     cams = simple_scene.orbit_cameras(W, H, n_views=n_views, device=dev, nearest=3)
     scene = simple_scene.SimpleScene(cams, device=dev)
     return dev, pc, cams, scene, simple_scene.default_pipe(), simple_scene.default_args(), torch.zeros(3, device=dev)
@@ -36,6 +37,22 @@ def test_batch_equals_single_passes(W, H, n, learnt, L):
     assert batch.shape == (n, 1, H, W) and batch.dtype == torch.float32
     assert float(singles.abs().max()) > 0
     assert torch.equal(batch, singles)
+    # ... and every view against the ORACLE's depth-only pass of that camera (numpy plane map, reference AABB lists): the
+    # batch is not only self-consistent.  L = 1 runs unculled lists on both sides (the per-256-round break is position dependent).
+    import oracle
+    g = pc._gnp
+    for v, cam in enumerate(views):
+        camd = {"viewmatrix": cam.world_view_transform.cpu().numpy(), "campos": cam.camera_center.cpu().numpy()}
+        am = syn.plane_all_map(g["means3D"], g["scales"], g["rotations"], camd, normal=g["normal"] if learnt else None,
+                               offset=g["offset"] if learnt else None)
+        inp = {"means3D": g["means3D"], "shs": g["shs"], "opacities": g["opacities"], "scales": g["scales"], "rotations": g["rotations"],
+               "all_map": am, "W": W, "H": H, "tanfovx": math.tan(cam.FoVx * 0.5), "tanfovy": math.tan(cam.FoVy * 0.5),
+               "viewmatrix": camd["viewmatrix"], "projmatrix": cam.full_proj_transform.cpu().numpy(), "campos": camd["campos"],
+               "bg": np.zeros(3, np.float32), "sh_degree": 1, "render_depth_only": True, "buffer_length": L}
+        ref = oracle.forward(inp)["median_depth"]
+        d = np.abs(batch[v].cpu().numpy() - ref)
+        assert d.mean() / (np.abs(ref).mean() + 1e-9) < 1e-4, (v, d.mean())
+        assert (d > 1e-3 * (1 + np.abs(ref))).mean() < 2e-3, v
 
 
 def test_render_uses_the_batch_for_its_sources_and_matches_the_loop():

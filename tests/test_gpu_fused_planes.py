@@ -12,6 +12,10 @@ from tests.metrics import l1, rel_l2
 
 pytestmark = pytest.mark.gpu
 
+# Relative-L2 bars of the geo gradients against the oracle.  1e-3 is BASELINE.md's bar; a term gets a looser one only with a
+# measured reason (filled in from the GPU runs of this round).
+GEO_BAR = {}
+
 
 def _scene(P=2500, W=160, H=112, seed=7):
     dev = torch.device("cuda")
@@ -72,6 +76,58 @@ def test_fused_glue_equals_torch_glue(learnt):
         assert rel_l2(g_fus[n], g_ref[n]) < (1e-4 if n in ("_normal", "_offset") else 2e-2), (n, rel_l2(g_fus[n], g_ref[n]))
     if not learnt:                       # raw normals / offsets take no part in smallest-axis mode
         assert g_fus["_normal"] is None and g_fus["_offset"] is None
+
+
+def _oracle_chain(learnt, g, dev, cams, scene, bg, seed=3):
+    """The same step as _run(fused=True, ...) WITHOUT any HIP kernel: the reference's torch glue (renderer._plane_map and
+    the activations of SimpleGaussians) on CPU tensors -> oracle.forward / oracle.backward -> torch.autograd through the glue."""
+    cpu = torch.device("cpu")
+    pc = simple_scene.SimpleGaussians(g, sh_degree=2, device=cpu)
+    cam = cams[0]
+    ccam = simple_scene.SimpleNamespace(world_view_transform=cam.world_view_transform.cpu(), camera_center=cam.camera_center.cpu())
+    am = renderer._plane_map(pc, ccam, learnt, pc.get_xyz)
+    chosen = cam.nearest_id[:3]
+    r2s, scp = syn.ref_to_src({"viewmatrix": cam.world_view_transform.cpu().numpy()},
+                              [{"viewmatrix": cams[j].world_view_transform.cpu().numpy()} for j in chosen])
+    acts = {"means3D": pc.get_xyz, "shs": pc.get_features, "opacities": pc.get_opacity, "scales": pc.get_scaling, "rotations": pc.get_rotation, "all_map": am}
+    H, W = cam.image_height, cam.image_width
+    inp = {k: v.detach().numpy() for k, v in acts.items()}
+    inp.update({"W": W, "H": H, "tanfovx": np.tan(cam.FoVx * 0.5), "tanfovy": np.tan(cam.FoVy * 0.5),
+                "viewmatrix": cam.world_view_transform.cpu().numpy(), "projmatrix": cam.full_proj_transform.cpu().numpy(),
+                "campos": cam.camera_center.cpu().numpy(), "bg": bg.cpu().numpy(), "sh_degree": 2, "render_geo": True, "n_src": 3,
+                "buffer_length": 4, "depth_thr": 0.01, "ref_to_src": r2s, "src_cam_pos": scp,
+                "src_images": scene.original_image_list[chosen].cpu().numpy(), "src_depths": scene.rendered_depth_list[chosen].cpu().numpy()})
+    ref = oracle.forward(inp, cull=True)
+    gen = torch.Generator(device=dev).manual_seed(seed)            # the very gradients _run() draws, in its order
+    gr = [torch.randn(c, H, W, device=dev, generator=gen).cpu().numpy() for c in (3, 3, 1, 15)]
+    rb = oracle.backward(inp, ref, gr[0], gr[1], gr[2], gr[3])
+    total = 0
+    for k, rk in (("means3D", "dL_dmeans3D"), ("shs", "dL_dsh"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
+                  ("rotations", "dL_drotations"), ("all_map", "dL_dall_map")):
+        total = total + (acts[k] * torch.as_tensor(rb[rk].reshape(tuple(acts[k].shape)))).sum()
+    total.backward()
+    grads = {n: (getattr(pc, n).grad.numpy() if getattr(pc, n).grad is not None else None)
+             for n in ("_xyz", "_normal", "_offset", "_rotation", "_scaling", "_opacity", "_features_dc")}
+    return ref, grads
+
+
+@pytest.mark.parametrize("learnt", [True, False])
+def test_fused_backward_equals_the_oracle_pushed_through_the_torch_glue(learnt):
+    """What the docstring of this file promises: the fused backward (dL/d_normal, dL/d_offset, and the glue's share of
+    dL/d_xyz / dL/d_rotation / dL/d_scaling written by preprocess_bwd) against oracle.backward's dL/dall_map pushed through
+    the reference-style torch glue by autograd -- no HIP kernel on the comparison side."""
+    dev, g, cams, scene, pipe, args, bg = _scene()
+    o_fus, g_fus = _run(True, learnt, g, dev, cams, scene, pipe, args, bg)
+    ref, g_orc = _oracle_chain(learnt, g, dev, cams, scene, bg)
+    assert l1(o_fus["render"].cpu().numpy(), ref["color"]) < 1e-6
+    assert l1(o_fus["rendered_normal"].cpu().numpy(), ref["normal_map"]) < 1e-5
+    names = ["_xyz", "_rotation", "_scaling", "_opacity", "_features_dc"] + (["_normal", "_offset"] if learnt else [])
+    errs = {n: rel_l2(g_fus[n], g_orc[n]) for n in names}
+    print("fused backward vs oracle chain (learnt=%s): %s" % (learnt, {k: "%.2e" % v for k, v in errs.items()}))
+    for n in names:
+        assert g_orc[n] is not None and np.abs(g_orc[n]).sum() > 0, n
+        # bar 1e-3 (BASELINE.md) except where noted in GEO_GRAD_BARS (tests/test_gpu_parity.py)
+        assert errs[n] < GEO_BAR.get(n, 1e-3), (n, errs[n])
 
 
 def test_fused_depth_only_pass_and_oracle_chain():
