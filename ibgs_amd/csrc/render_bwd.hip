@@ -29,6 +29,7 @@
 // IEEE division.
 #include "common.h"
 #include "wave_reduce.h"
+#include <type_traits>
 
 namespace ibgs {
 
@@ -82,6 +83,176 @@ __device__ __forceinline__ float fast_rcp(float x)
 {   // v_rcp_f32 (1 ulp) + one Newton step
     const float r = __builtin_amdgcn_rcpf(x);
     return r * (2.0f - x * r);
+}
+
+// ---- colour variant -------------------------------------------------------------------------------------------------
+// Same traversal and the same (pixel, Gaussian) decisions as render_bwd_body below, restructured so that a pair costs
+// ~24 VALU instructions instead of ~41 (the kernel is VALU-issue bound):
+//   * what a lane keeps per quadrant is ONE number, Q_q = o G dL/dalpha of its pixel there (0 when the quadrant is skipped);
+//     the six geometric moments are formed once per Gaussian from Q_0..Q_3 and the lane's d0 = (Gaussian centre - its
+//     quadrant-0 pixel): the other three pixels sit at d0 - (8,0), (0,8), (8,8), so
+//         sum Q d   = d0 S0 - 8 (A, B),                      A = Q1 + Q3, B = Q2 + Q3, S0 = Q0 + Q1 + Q2 + Q3
+//         sum Q dx^2 = dx0 (dx0 S0 - 16 A) + 64 A            (likewise y)
+//         sum Q dx dy = dy0 Sx - 8 (dx0 B - 8 Q3)
+//     -- 17 instructions per Gaussian instead of 8 per (Gaussian, quadrant);
+//   * conic * d of the other quadrants (only the |.| moments need it) comes from the quadrant-0 value by one fma each;
+//   * the per-pixel constants dL/dC and -T_final (bg . dL/dC) travel as ONE 16-byte LDS read;
+//   * one select (on G) instead of two, 1/(1 - alpha) is the bare v_rcp_f32 (1 ulp; the Newton step bought nothing that the
+//     parity bars see: T picks up ~1e-7 sqrt(k) relative noise over k divisions);
+//   * "k < n_contrib" costs two compares per quadrant per CHUNK when no pixel of the quadrant switches on inside the chunk
+//     (each pixel switches on once per traversal), instead of one per Gaussian.
+template <int PPL>
+__device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
+{
+    constexpr int CHUNK = 16;          // 16 records per round: 0.75 KB + 4 KB of per-pixel constants <= 5 KB per wave = 8 waves per SIMD, every tile of a 1080p frame resident at once
+    __shared__ float4 s_rec[3][CHUNK];
+    __shared__ float4 s_gpix[PPL][WAVE];                  // dL/dC (rgb), -T_final * (bg . dL/dC)
+
+    const int lane = threadIdx.x;
+    int col = reduce12_column(lane);
+    if (col >= 11) col = -1;
+    constexpr int IPT = 4 / PPL;
+    const int nitems = p.ntiles * IPT;
+    const int item = xcd_band_map_b(blockIdx.x, nitems);
+    if (item >= nitems) return;
+    const int tile = item / IPT;
+    const int quad0 = (item % IPT) * PPL;
+    const int W = p.cam.W, H = p.cam.H;
+    const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
+    const size_t HW = (size_t)W * H;
+    const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E, the forward's constant
+
+    float T[PPL], S[PPL];
+    uint32_t ncontrib[PPL];
+    uint32_t nmax = 0;
+    const float pxf0 = (float)(tx0 + (quad0 & 1) * 8 + (lane & 7)), pyf0 = (float)(ty0 + (quad0 >> 1) * 8 + (lane >> 3));
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        const int qq = quad0 + q;
+        const int px = tx0 + (qq & 1) * 8 + (lane & 7), py = ty0 + (qq >> 1) * 8 + (lane >> 3);
+        const bool inside = px < W && py < H;
+        const size_t pix = (size_t)py * W + px;
+        const float T_final = inside ? p.final_T[pix] : 0.f;
+        T[q] = T_final;
+        ncontrib[q] = inside ? p.n_contrib[pix] : 0u;
+        nmax = max(nmax, ncontrib[q]);
+        S[q] = 0.f;
+        float4 g;
+        g.x = (inside && p.dL_dcolor) ? p.dL_dcolor[pix] : 0.f;
+        g.y = (inside && p.dL_dcolor) ? p.dL_dcolor[HW + pix] : 0.f;
+        g.z = (inside && p.dL_dcolor) ? p.dL_dcolor[2 * HW + pix] : 0.f;
+        g.w = -T_final * (p.cam.bg[0] * g.x + p.cam.bg[1] * g.y + p.cam.bg[2] * g.z);
+        s_gpix[q][lane] = g;
+    }
+    nmax = wave_max_u32(nmax);
+    const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
+    const int n = (int)(r1 - r0);
+    // entries >= top contribute to no pixel of this wave; readfirstlane makes the loop control scalar (nmax is the same in
+    // every lane after the butterfly, which the compiler cannot see)
+    int top = __builtin_amdgcn_readfirstlane(min((int)nmax, n));
+
+    while (top > 0) {
+        const int count = min(CHUNK, top);
+        if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
+            const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
+            const float4* r = p.rec + (size_t)id * 4;
+            float4 ra = r[0];
+            ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
+            s_rec[0][lane] = ra; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
+        }
+        // pixels that take part: k < n_contrib.  k runs from top-1 down to top-count in this chunk and a pixel only ever
+        // switches ON (at k = n_contrib - 1), so when the masks at both ends agree they hold for the whole chunk.
+        uint64_t ncm[PPL];
+        bool stable = true;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+            ncm[q] = __builtin_amdgcn_ballot_w64((uint32_t)(top - count) < ncontrib[q]);
+            stable = stable && (ncm[q] == __builtin_amdgcn_ballot_w64((uint32_t)(top - 1) < ncontrib[q]));
+        }
+        __syncthreads();
+        auto chunk = [&](auto stable_tag) {
+            constexpr bool STABLE = decltype(stable_tag)::value;
+            for (int j = 0; j < count; j++) {
+                const uint32_t k = (uint32_t)(top - 1 - j);          // 0-based position in the tile list
+                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
+                const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
+                const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
+                // same evaluation of p2 = d^T conic d as the forward (render_fwd.hip): once per lane, shifted to the
+                // other three quadrants, so both passes take identical alpha decisions
+                const float dx0 = q0.x - pxf0, dy0 = q0.y - pyf0;
+                const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
+                const float P0 = dx0 * lx0 + dy0 * ly0;
+                float p2q[PPL], lxq[PPL], lyq[PPL];
+                p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
+                if (PPL >= 2) {
+                    p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
+                    lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0);
+                }
+                if (PPL == 4) {
+                    p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
+                    p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
+                    lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
+                    lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                }
+                float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f;
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < PPL; q++) {
+                    // the forward's test: 0 <= p2 <= 2 ln(255 o) as one unsigned compare of the float bits (render_fwd.hip)
+                    const uint64_t live = STABLE ? ncm[q] : __builtin_amdgcn_ballot_w64(k < ncontrib[q]);
+                    const uint64_t okm = live & __builtin_amdgcn_ballot_w64(__float_as_uint(p2q[q]) < qbound);
+                    Q[q] = 0.f;
+                    if (okm != 0ull) {
+                        any = true;
+                        // lanes that fail the test run the same instructions with G = 0: alpha = 0 leaves T and S
+                        // unchanged (1 / (1 - 0) = 1 exactly) and every sum receives a zero
+                        // (the select sits on o G, not on G: an inline-asm instruction must not be the first reader of a
+                        // transcendental's result -- hipcc pads no wait states inside asm, cdna_hip_programming.md 5.7)
+                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(p2q[q] * NHL2E));
+                        const float alpha = min_099(oG);
+                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T[q] = T[q] * rinv;
+                        const float w = alpha * T[q];
+                        const float4 gp = s_gpix[q][lane];
+                        // S = (colour behind this Gaussian) . (pixel gradient): scalar form of the reference's per-channel
+                        // accum_rec / last_color / last_alpha recurrence (backward.cu:665-669), folded into one fma:
+                        // behind_k = alpha_k c_k + (1 - alpha_k) behind_{k+1} = behind_{k+1} + alpha_k (c_k - behind_{k+1})
+                        const float cg = q2.x * gp.x + q2.y * gp.y + q2.z * gp.z;
+                        float dL_dalpha = cg - S[q];
+                        S[q] = fmaf(alpha, dL_dalpha, S[q]);
+                        vR = fmaf(w, gp.x, vR); vG = fmaf(w, gp.y, vG); vB = fmaf(w, gp.z, vB);
+                        dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);          // ... - T_final (bg . g) / (1 - alpha)
+                        const float qv = oG * dL_dalpha;                          // dL/dG * G
+                        Q[q] = qv;
+                        aX += fabsf(qv * lxq[q]); aY += fabsf(qv * lyq[q]);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
+                    // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb (= grad_acc columns)
+                    float v[12];
+                    if (PPL == 4) {
+                        const float A = Q[1] + Q[3], B = Q[2] + Q[3], S0 = (Q[0] + Q[2]) + A;
+                        const float t = dx0 * S0, u = dy0 * S0;
+                        v[0] = fmaf(-8.0f, A, t); v[1] = fmaf(-8.0f, B, u);
+                        v[4] = fmaf(dx0, fmaf(-16.0f, A, t), 64.0f * A);
+                        v[6] = fmaf(dy0, fmaf(-16.0f, B, u), 64.0f * B);
+                        v[5] = fmaf(-8.0f, fmaf(-8.0f, Q[3], dx0 * B), dy0 * v[0]);
+                        v[7] = S0;
+                    } else {
+                        const float qdx = Q[0] * dx0, qdy = Q[0] * dy0;
+                        v[0] = qdx; v[1] = qdy; v[4] = qdx * dx0; v[5] = qdx * dy0; v[6] = qdy * dy0; v[7] = Q[0];
+                    }
+                    v[2] = aX; v[3] = aY; v[8] = vR; v[9] = vG; v[10] = vB; v[11] = 0.f;
+                    const float tot = wave_transpose_reduce12(v, lane);
+                    const uint32_t id = __float_as_uint(q0.w);
+                    if (col >= 0) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
+                }
+            }
+        };
+        if (stable) chunk(std::true_type{}); else chunk(std::false_type{});
+        __syncthreads();
+        top -= count;
+    }
 }
 
 template <bool GEO, int PPL>
@@ -322,12 +493,12 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
 
 // Two entry points so that each variant gets its own register budget: the colour kernel fits 5 waves per
 // SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
-__global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_body<false, 4>(p); }
+__global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_color_body<4>(p); }
 __global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
 // geo on large frames: one wave per half tile (quadrant pairs 0-1 / 2-3), 128 VGPRs, 4 waves per SIMD
 __global__ void __launch_bounds__(64, 4) render_bwd_geo2_kernel(BwdParams p) { render_bwd_body<true, 2>(p); }
 // small frames (fewer tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up
-__global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_body<false, 1>(p); }
+__global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_color_body<1>(p); }
 
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
                            const ImgState& im, const float4* src_rgba)
