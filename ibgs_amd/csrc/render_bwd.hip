@@ -184,11 +184,11 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                 const float P0 = dx0 * lx0 + dy0 * ly0;
                 float p2q[PPL], lxq[PPL], lyq[PPL];
                 p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
-                if (PPL >= 2) {
+                if constexpr (PPL >= 2) {
                     p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
                     lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0);
                 }
-                if (PPL == 4) {
+                if constexpr (PPL == 4) {
                     p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
                     p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
                     lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
@@ -230,7 +230,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
                     // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb (= grad_acc columns)
                     float v[12];
-                    if (PPL == 4) {
+                    if constexpr (PPL == 4) {
                         const float A = Q[1] + Q[3], B = Q[2] + Q[3], S0 = (Q[0] + Q[2]) + A;
                         const float t = dx0 * S0, u = dy0 * S0;
                         v[0] = fmaf(-8.0f, A, t); v[1] = fmaf(-8.0f, B, u);
