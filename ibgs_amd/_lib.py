@@ -60,6 +60,13 @@ class AdamTensor(ctypes.Structure):
                 ("eps", ctypes.c_double), ("bias_correction1", ctypes.c_double), ("bias_correction2", ctypes.c_double)]
 
 
+class CompactTensor(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("append", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("width", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+COMPACT_MAX_TENSORS = 40
+
+
 class BackwardArgs(ctypes.Structure):
     _fields_ = [
         ("stream", ctypes.c_void_p),
@@ -94,6 +101,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
+           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -151,6 +159,12 @@ def load():
     lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     lib.ibgs_adam_step.restype = ctypes.c_int32
     lib.ibgs_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.ibgs_required_compact.restype = ctypes.c_size_t
+    lib.ibgs_required_compact.argtypes = [ctypes.c_int32]
+    lib.ibgs_compact_plan.restype = ctypes.c_int64
+    lib.ibgs_compact_plan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.ibgs_compact_apply.restype = ctypes.c_int32
+    lib.ibgs_compact_apply.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
     lib.ibgs_knn_mean_dist2.restype = ctypes.c_int32
     lib.ibgs_knn_mean_dist2.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ibgs_sizeof_forward_args.restype = ctypes.c_size_t

@@ -257,6 +257,27 @@ size_t ibgs_required_knn(int32_t P);
 int32_t ibgs_knn_mean_dist2(void* stream, int32_t P, const float* points /* P x 3 */, float* out /* P */,
                             char* scratch, size_t scratch_bytes);
 
+/* SURVEY 8(f) row 4 -- densification surgery as one data-movement pass.  Replaces the per-tensor boolean indexing and
+ * torch.cat of the reference's _prune_optimizer / cat_tensors_to_optimizer / prune_points (scene/gaussian_model.py:377-444):
+ *   dst[0 .. n_keep)              = the rows of src whose keep_mask byte is non-zero, in their original order
+ *   dst[n_keep .. n_keep + n_app) = the rows of `append` (copied), or zeros when `append` is NULL (Adam moments of new points)
+ * for EVERY tensor of the call (parameters, exp_avg, exp_avg_sq, per-point statistics ...) in one launch.
+ * ibgs_compact_plan scans the mask into `scratch` (>= ibgs_required_compact(n_old) bytes, caller-owned, must stay alive until
+ * ibgs_compact_apply has run) and returns n_keep -- the one host synchronisation, needed to size dst (the reference's boolean
+ * indexing synchronises per tensor).  keep_mask NULL keeps every row.  Pure data movement: bit-identical to the torch form. */
+#define IBGS_COMPACT_MAX_TENSORS 40
+typedef struct ibgs_compact_tensor {
+    const float* src;      /* n_old x width */
+    const float* append;   /* n_app x width, or NULL: appended rows are zeros */
+    float* dst;            /* (n_keep + n_app) x width, caller-allocated */
+    int32_t width;         /* 4-byte elements per row (any 4-byte type travels as float bits) */
+    int32_t reserved;
+} ibgs_compact_tensor;
+size_t ibgs_required_compact(int32_t n_old);
+int64_t ibgs_compact_plan(void* stream, int32_t n_old, const uint8_t* keep_mask /* n_old or NULL */, char* scratch, size_t scratch_bytes);
+int32_t ibgs_compact_apply(void* stream, int32_t n_tensors, const ibgs_compact_tensor* tensors, int32_t n_old, int32_t n_app,
+                           const char* scratch);
+
 /* Introspection for tests: byte offsets of the named sub-arrays inside the arenas.
  * Returns -1 for an unknown name. Names: see DESIGN.md "Arena layout". */
 int64_t ibgs_geom_offset(int32_t P, const char* name);
