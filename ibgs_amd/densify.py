@@ -62,6 +62,8 @@ def compact_append(tensors, keep_mask=None, appends=None):
         if n_keep < 0:
             raise RuntimeError("ibgs_compact_plan failed (%d): %s" % (n_keep, _lib.last_error()))
         outs = [torch.empty((int(n_keep) + n_app,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in srcs]
+        if int(n_keep) + n_app == 0:
+            return outs
         for i in range(0, len(srcs), _lib.COMPACT_MAX_TENSORS):
             part = []
             for t, a, o in zip(srcs[i:i + _lib.COMPACT_MAX_TENSORS], apps[i:i + _lib.COMPACT_MAX_TENSORS], outs[i:i + _lib.COMPACT_MAX_TENSORS]):
