@@ -153,6 +153,7 @@ size_t ibgs_sizeof_backward_args(void) { return sizeof(ibgs_backward_args); }
 size_t ibgs_required_geom(int32_t P) { size_t t; GeomState::carve(nullptr, (size_t)(P > 0 ? P : 0), &t); return t; }
 size_t ibgs_required_img(int32_t W, int32_t H) { size_t t; ImgState::carve(nullptr, W, H, &t); return t; }
 size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H) { size_t t; BinState::carve(nullptr, (size_t)(R > 0 ? R : 0), W, H, &t); return t; }
+size_t ibgs_required_deterministic(int64_t R, int32_t P) { size_t t; DetState::carve(nullptr, (size_t)(R > 0 ? R : 0) * 4, (size_t)(P > 0 ? P : 0), &t); return t; }   // x 4: up to four waves per tile
 size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H) { return (size_t)n_src * W * H * sizeof(float4) + 128; }
 
 #define OFF(base_struct, field) if (!strcmp(name, #field)) return (int64_t)((char*)base_struct.field - (char*)nullptr)
@@ -343,7 +344,18 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         rgba = t;
     }
     if (a.R > 0) {
-        { StageTimer t(s, IBGS_STAGE_RENDER_BWD); if ((rc = launch_render_backward(s, a, g, b, im, rgba))) return rc; }
+        const bool det = (a.flags & IBGS_FLAG_DETERMINISTIC) != 0;
+        DetState ds{};
+        int ipt = 1;
+        if (det) {
+            if (!a.det_scratch || a.det_scratch_bytes < ibgs_required_deterministic(a.R, a.P)) { set_error("det_scratch too small"); return -IBGS_ERR_ALLOC; }
+            ipt = render_backward_waves_per_tile(a);
+            ds = DetState::carve(a.det_scratch, (size_t)a.R * ipt, (size_t)a.P, nullptr);
+            if ((rc = launch_det_prepare(s, ds, (size_t)a.R * ipt))) return rc;
+        }
+        { StageTimer t(s, IBGS_STAGE_RENDER_BWD);
+          if ((rc = launch_render_backward(s, a, g, b, im, rgba, det ? ds.slab : nullptr))) return rc;
+          if (det && (rc = launch_det_reduce(s, ds, b.point_list, (size_t)a.R, ipt, a.P, a.grad_acc))) return rc; }
         if ((rc = stage_check(s, debug, "render backward"))) return rc;
     }
     { StageTimer t(s, IBGS_STAGE_PREPROCESS_BWD); if ((rc = launch_preprocess_backward(s, a, g))) return rc; }

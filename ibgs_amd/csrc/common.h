@@ -183,8 +183,21 @@ int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H,
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
                           const ImgState& im, const float4* src_rgba);
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
-                           const ImgState& im, const float4* src_rgba);
+                           const ImgState& im, const float4* src_rgba, float* slab = nullptr);
 int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g);
+
+// IBGS_FLAG_DETERMINISTIC (deterministic.hip): slab of per-(Gaussian, tile) sums + its sort scratch, carved from det_scratch
+struct DetState {
+    float* slab;           // (R x ipt) x 16, row = position in the sorted list x waves per tile + wave of the tile
+    uint32_t* keys[2];     // R   Gaussian ids (ping-pong)
+    uint32_t* vals[2];     // R   list positions (ping-pong)
+    uint32_t* seg;         // P+1 first sorted slot of every Gaussian
+    uint32_t* hist; size_t hist_elems;
+    static DetState carve(char* base, size_t rows, size_t P, size_t* total);          // rows = R x waves per tile
+};
+int render_backward_waves_per_tile(const ibgs_backward_args& a);
+int launch_det_prepare(hipStream_t s, const DetState& d, size_t rows);                    // zero the slab
+int launch_det_reduce(hipStream_t s, const DetState& d, const uint32_t* point_list, size_t R, int ipt, int P, float* gacc);
 int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, const float* means3D, const float* camposes,
                               const float* dcolor, size_t view_stride, float* dL_dsh);
 

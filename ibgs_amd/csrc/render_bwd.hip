@@ -44,6 +44,7 @@ struct BwdParams {
     const float* depth_pixels; const float* warped_pixels;
     const float* dL_dcolor; const float* dL_dnormal; const float* dL_ddepth; const float* dL_dwarped;
     float* gacc;
+    float* slab;          // IBGS_FLAG_DETERMINISTIC: (R x waves per tile) x 16, one row per (list entry, wave of its tile), written instead of the atomics (else nullptr)
 };
 
 __device__ __forceinline__ float quant8b(float a, int quant) { return quant ? floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f) : a; }
@@ -245,7 +246,10 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                     v[2] = aX; v[3] = aY; v[8] = vR; v[9] = vG; v[10] = vB; v[11] = 0.f;
                     const float tot = wave_transpose_reduce12(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);
-                    if (col >= 0) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
+                    if (col >= 0) {
+                        if (p.slab) p.slab[((size_t)(r0 + k) * IPT + (size_t)(item % IPT)) * GACC_FLOATS + col] = tot;      // wave-uniform choice
+                        else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
+                    }
                 }
             }
         };
@@ -483,7 +487,10 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
                 float tot;
                 if constexpr (GEO) tot = wave_transpose_reduce16(v, lane); else tot = wave_transpose_reduce12(v, lane);
                 const uint32_t id = __float_as_uint(q0.w);
-                if (col >= 0) atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
+                if (col >= 0) {
+                    if (p.slab) p.slab[((size_t)(r0 + k) * IPT + (size_t)(item % IPT)) * GACC_FLOATS + col] = tot;          // wave-uniform choice
+                    else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
+                }
             }
         }
         __syncthreads();
@@ -500,8 +507,16 @@ __global__ void __launch_bounds__(64, 4) render_bwd_geo2_kernel(BwdParams p) { r
 // small frames (fewer tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_color_body<1>(p); }
 
+// how many waves share one tile in the variant launch_render_backward picks (1, 2 or 4): rows per list entry of the deterministic slab
+int render_backward_waves_per_tile(const ibgs_backward_args& a)
+{
+    const int nt = ((a.W + TILE - 1) / TILE) * ((a.H + TILE - 1) / TILE);
+    if (a.render_geo) return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096)) ? 2 : 4;
+    return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) ? 4 : 1;
+}
+
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
-                           const ImgState& im, const float4* src_rgba)
+                           const ImgState& im, const float4* src_rgba, float* slab)
 {
     BwdParams p;
     p.ranges = im.ranges; p.point_list = b.point_list; p.rec = reinterpret_cast<const float4*>(g.rec);
@@ -513,7 +528,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
     p.depth_pixels = a.out_depth; p.warped_pixels = a.out_warped;
     p.dL_dcolor = a.dL_dcolor; p.dL_dnormal = a.dL_dnormal; p.dL_ddepth = a.dL_ddepth; p.dL_dwarped = a.dL_dwarped;
-    p.gacc = a.grad_acc;
+    p.gacc = a.grad_acc; p.slab = slab;
     const int nt = p.ntiles;
     if (a.render_geo) {
         // geo: half tiles (two quadrants per lane: half the per-Gaussian overhead and reductions) on large frames

@@ -32,6 +32,9 @@ TEX_QUANT = False
 # Exact tile culling (shorter per-tile lists, identical outputs).  False reproduces the reference's AABB lists.
 TILE_CULL = True
 
+# Deterministic backward (IBGS_FLAG_DETERMINISTIC): no float atomics, gradients bit-identical from run to run (CI mode, slower).
+DETERMINISTIC = False
+
 # Work decomposition of the colour blend kernels: None = by frame size (one wave per 16x16 tile from 4096 tiles on,
 # one wave per 8x8 quadrant below), "tile" / "quadrant" force one of them (tests run both against the oracle).
 WAVE_SHAPE = None
@@ -368,6 +371,10 @@ class _CModule:
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
                            | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag())
+                if DETERMINISTIC and int(R) > 0:
+                    det = torch.empty(lib.ibgs_required_deterministic(int(R), P), dtype=torch.uint8, device=device)
+                    a.det_scratch = det.data_ptr(); a.det_scratch_bytes = det.numel()
+                    a.flags |= _lib.FLAG_DETERMINISTIC
                 rc = lib.ibgs_backward(ctypes.byref(a))
                 if rc < 0:
                     raise RuntimeError("ibgs_backward failed (%d): %s" % (rc, _lib.last_error()))
