@@ -47,7 +47,7 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.clamped = c.take<uint8_t>(P);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
-    g.offsets = c.take<uint32_t>(P + 1);
+    g.offsets = c.take<uint32_t>(P + 2);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -253,7 +253,8 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     { StageTimer t(s, IBGS_STAGE_PREPROCESS); if ((rc = launch_preprocess(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess"))) return rc;
     { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
-      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems))) return rc; }
+      IBGS_HIP(hipMemsetAsync(g.offsets + Pn + 1, 0, sizeof(uint32_t), s));          // look-back error flag, travels back with R
+      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, nullptr, false, g.offsets + Pn + 1))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
     { StageTimer t(s, IBGS_STAGE_SCAN);
       if ((rc = launch_gather_tiles(s, Pn, g))) return rc;
@@ -265,12 +266,15 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
     const uint32_t* R_dev = g.offsets + Pn;
-    IBGS_HIP(hipMemcpyAsync(rs->host, R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    IBGS_HIP(hipMemcpyAsync(rs->host, R_dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
     IBGS_HIP(hipEventRecord(rs->ev, s));
     const bool deferred = a.rendered_hint > 0 && !debug;
     int64_t R = 0, cap = 0;
     if (deferred) cap = a.rendered_hint < (int64_t)0xFFFF0000ll ? a.rendered_hint : (int64_t)0xFFFF0000ll;
-    else { IBGS_HIP(hipEventSynchronize(rs->ev)); R = (int64_t)*rs->host; cap = R; }
+    else {
+        IBGS_HIP(hipEventSynchronize(rs->ev)); R = (int64_t)rs->host[0]; cap = R;
+        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
+    }
 
     const int bit = (int)higher_msb((uint32_t)(gx * gy));
     const bool key16 = gx * gy <= 65536;          // tile ids fit 16 bits: the binning keys travel as uint16_t
@@ -298,7 +302,8 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if ((rc = tail(cap, deferred ? R_dev : nullptr))) return rc;
     if (deferred) {
         IBGS_HIP(hipEventSynchronize(rs->ev));
-        R = (int64_t)*rs->host;
+        R = (int64_t)rs->host[0];
+        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
         if (R > cap) {
             // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be
             // released by the second callback) and redo binning + render with the exact size (every output

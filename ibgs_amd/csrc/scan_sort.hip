@@ -428,7 +428,7 @@ static size_t onesweep_elems(size_t n)
 }
 
 static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
-                                     uint32_t* scratch, size_t scratch_elems)
+                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev)
 {
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int nbins = 1 << dbits;
@@ -445,7 +445,7 @@ static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t*
     for (int pass = 0; pass < npass; pass++) {
         hipLaunchKernelGGL(onesweep_pass_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
                            n, pass * dbits, dbits, nbins, ghist + pass * RS_MAX_BINS, status + (size_t)pass * nblocks * RS_MAX_BINS,
-                           tickets + pass, tickets + 32);
+                           tickets + pass, err_dev ? err_dev : tickets + 32);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
@@ -466,7 +466,7 @@ size_t radix_hist_elems(size_t n)
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev, bool key16)
+                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev, bool key16, uint32_t* err_dev)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -475,7 +475,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
     if (want_os && !n_dev && !key16 && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
-        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems);
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;

@@ -76,7 +76,7 @@ LAST_NUM_RENDERED = 0         # diagnostic: R of the most recent forward
 LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent forward carved its binning arena for
 
 _tex_scratch = {}
-_gacc_scratch = {}   # (device index, P) -> [zeroed P x 16 tensor, dirty flag]; ibgs_backward re-zeroes what it consumed
+_gacc_scratch = {}   # (device index, stream, P) -> [zeroed P x 16 tensor, dirty flag]; ibgs_backward re-zeroes what it consumed
 
 
 def cpu_deep_copy_tuple(input_tuple):
@@ -99,8 +99,17 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _stream_key(device):
+    """Scratch is reused across calls, so it is owned by ONE stream: two streams (or threads with their own streams) that run
+    rasterizer calls side by side get separate buffers instead of racing on a shared one."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _tex(device, nbytes):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = _stream_key(device)
+    if len(_tex_scratch) > 8 and key not in _tex_scratch:
+        _tex_scratch.clear()
     buf = _tex_scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -109,7 +118,7 @@ def _tex(device, nbytes):
 
 
 def _gacc(device, P):
-    key = (device.index if device.index is not None else torch.cuda.current_device(), P)
+    key = _stream_key(device) + (P,)
     ent = _gacc_scratch.get(key)
     if ent is None:
         if len(_gacc_scratch) > 8:
