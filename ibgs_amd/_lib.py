@@ -180,7 +180,9 @@ def load():
     return lib
 
 
-STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render_fwd", "render_bwd",
+# "binning" = coarse emit + coarse sort + per-tile counts + ranges, "list_scatter" = the ids to their slots (two-level binning,
+# csrc/binning.hip); "ranges" has no kernel of its own any more (always 0)
+STAGES = ["preprocess", "depth_sort", "scan", "binning", "list_scatter", "ranges", "render_fwd", "render_bwd",
           "preprocess_bwd"]
 
 

@@ -42,12 +42,14 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.depths = c.take<float>(P);
     g.cov3D = c.take<float>(P * 6);
     g.tiles = c.take<uint32_t>(P);
+    g.tc = c.take<uint32_t>(P);
     g.rect = c.take<uint32_t>(P * 2);
     g.tmask = c.take<uint64_t>(P * IBGS_CULL_WORDS);
     g.clamped = c.take<uint8_t>(P);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
-    g.offsets = c.take<uint32_t>(P + 2);
+    g.offsets = c.take<uint32_t>(P + 3);
+    g.coffs = c.take<uint32_t>(P + 1);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -73,15 +75,24 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
 
 BinState BinState::carve(char* base, size_t R, int W, int H, size_t* total)
 {
-    (void)W; (void)H;
     Carver c(base);
     BinState b;
+    const size_t gx = (size_t)((W + TILE - 1) / TILE), gy = (size_t)((H + TILE - 1) / TILE), ntiles = gx * gy;
+    const size_t ncells = ((gx + BIN_CELL - 1) / BIN_CELL) * ((gy + BIN_CELL - 1) / BIN_CELL);
     // The sorted Gaussian ids come first: their offset does not depend on R, so ibgs_backward finds them
     // whether the forward carved the arena for the exact R or for a larger rendered_hint.
-    b.vals[0] = c.take<uint32_t>(R);
-    b.point_list = b.vals[0];            // the tile sort leaves its result in buffer 0
-    b.keys[0] = c.take<uint32_t>(R); b.keys[1] = c.take<uint32_t>(R);
-    b.vals[1] = c.take<uint32_t>(R);
+    b.point_list = c.take<uint32_t>(R);
+    b.ccap = R;                                     // a coarse entry stands for at least one tile entry: C <= R
+    b.cid = c.take<uint32_t>(R);
+    b.cmask = c.take<uint64_t>(R);
+    b.ckeys[0] = c.take<uint32_t>(R); b.ckeys[1] = c.take<uint32_t>(R);
+    b.cvals[0] = c.take<uint32_t>(R); b.cvals[1] = c.take<uint32_t>(R);
+    b.cell_start = c.take<uint32_t>(ncells + 1);
+    b.cell_chunk0 = c.take<uint32_t>(ncells + 1);
+    b.chunk_cnt = c.take<uint32_t>((R / BIN_XCHUNK + ncells + 1) * 64);
+    b.tile_total = c.take<uint32_t>(ntiles + 1);
+    b.scan_elems = scan_scratch_elems(ntiles + 1);
+    b.scan_scratch = c.take<uint32_t>(b.scan_elems);
     b.hist_elems = radix_hist_elems(R);
     b.hist = c.take<uint32_t>(b.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -175,7 +186,6 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
 {
     size_t t; BinState b = BinState::carve(nullptr, (size_t)R, W, H, &t);
     OFF(b, point_list);
-    if (!strcmp(name, "sorted_tile_keys")) return (int64_t)((char*)b.keys[0] - (char*)nullptr);
     return -1;
 }
 #undef OFF
@@ -256,40 +266,46 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
       IBGS_HIP(hipMemsetAsync(g.offsets + Pn + 1, 0, sizeof(uint32_t), s));          // look-back error flag, travels back with R
       if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, nullptr, false, g.offsets + Pn + 1))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
+    // R = total number of (Gaussian, tile) pairs.  The binning arena is sized from it, and it is only known on the device.
+    //  * no hint (first call of a shape, or debug): the tiles-touched counts are scanned, R travels to the host through a pinned
+    //    word + event and the host waits for it here, as the reference does (rasterizer_impl.cu:430);
+    //  * with args->rendered_hint the arena is carved for the hint at once, every remaining stage is enqueued, and R falls out of
+    //    the binning itself (the scan over the per-tile totals) -- the host reads it, the coarse slot count and the depth sort's
+    //    error flag only after everything is queued: the GPU never idles on the round trip and one scan less runs.
+    const bool deferred = a.rendered_hint > 0 && !debug;
     { StageTimer t(s, IBGS_STAGE_SCAN);
-      if ((rc = launch_gather_tiles(s, Pn, g))) return rc;
-      if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
-    // R = total number of (Gaussian, tile) pairs, known only on the device at this point.  It travels to the host
-    // through a pinned word + event.  Without a hint the host waits for it here (the binning arena is sized from
-    // it); with args->rendered_hint the remaining stages are enqueued first, sized for the hint and reading the real
-    // count from device memory, and the host waits only afterwards -- the GPU never idles on the round trip.
+      if ((rc = launch_gather_tiles(s, Pn, g, !deferred))) return rc;
+      if (!deferred && (rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
+      if ((rc = exclusive_scan_u32(s, g.coffs, g.coffs, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
-    const uint32_t* R_dev = g.offsets + Pn;
-    IBGS_HIP(hipMemcpyAsync(rs->host, R_dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
-    IBGS_HIP(hipEventRecord(rs->ev, s));
-    const bool deferred = a.rendered_hint > 0 && !debug;
+    auto exact_R = [&](int64_t* R_out) -> int {       // synchronous path: R from the scanned tile counts
+        IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
+        IBGS_HIP(hipEventRecord(rs->ev, s));
+        IBGS_HIP(hipEventSynchronize(rs->ev));
+        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
+        *R_out = (int64_t)rs->host[0];
+        return 0;
+    };
     int64_t R = 0, cap = 0;
     if (deferred) cap = a.rendered_hint < (int64_t)0xFFFF0000ll ? a.rendered_hint : (int64_t)0xFFFF0000ll;
-    else {
-        IBGS_HIP(hipEventSynchronize(rs->ev)); R = (int64_t)rs->host[0]; cap = R;
-        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
-    }
+    else { if ((rc = exact_R(&R))) return rc; cap = R; }
 
-    const int bit = (int)higher_msb((uint32_t)(gx * gy));
-    const bool key16 = gx * gy <= 65536;          // tile ids fit 16 bits: the binning keys travel as uint16_t
-    auto tail = [&](int64_t n, const uint32_t* n_dev) -> int {
+    auto tail = [&](int64_t n, bool read_back) -> int {
         int rc;
-        char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, a.H), a.binning_user);
+        char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, Hn), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
-        BinState b = BinState::carve(bin_mem, (size_t)n, a.W, a.H, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_emit(s, Pn, n, gx, g, b, n_dev, key16))) return rc; }
-        if ((rc = stage_check(s, debug, "emit"))) return rc;
-        { StageTimer t(s, IBGS_STAGE_TILE_SORT);
-          if ((rc = radix_sort_pairs(s, b.keys, b.vals, (size_t)n, bit, b.hist, b.hist_elems, n_dev, key16))) return rc; }
-        if ((rc = stage_check(s, debug, "tile sort"))) return rc;
-        { StageTimer t(s, IBGS_STAGE_RANGES); if ((rc = launch_ranges(s, n, gx * gy, b.keys[0], im.ranges, n_dev, key16))) return rc; }
-        if ((rc = stage_check(s, debug, "ranges"))) return rc;
+        BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
+        int cur;
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((cur = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges)) < 0) return cur; }
+        if (read_back) {
+            // R as the binning counted it, the depth sort's error flag, the coarse slots in use: adjacent words, one copy, queued
+            // HERE so that the host is served while the list scatter and the render still run
+            IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            IBGS_HIP(hipEventRecord(rs->ev, s));
+        }
+        { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b, cur))) return rc; }
+        if ((rc = stage_check(s, debug, "binning"))) return rc;
         const float4* rgba = nullptr;
         if (a.render_geo) {
             float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
@@ -299,17 +315,24 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }
         return stage_check(s, debug, "render");
     };
-    if ((rc = tail(cap, deferred ? R_dev : nullptr))) return rc;
+    if ((rc = tail(cap, deferred))) return rc;
     if (deferred) {
         IBGS_HIP(hipEventSynchronize(rs->ev));
-        R = (int64_t)rs->host[0];
         if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
-        if (R > cap) {
-            // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be
-            // released by the second callback) and redo binning + render with the exact size (every output
-            // element is rewritten).  Same results as without a hint, one wasted pass.
+        R = (int64_t)rs->host[0];
+        const bool coarse_overflow = (int64_t)rs->host[2] > cap;      // Gaussians were dropped: the binning's own R is incomplete too
+        if (R > cap || coarse_overflow) {
+            // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be released by the
+            // second callback) and redo binning + render with the exact size (every output element is rewritten).  Same results
+            // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
-            if ((rc = tail(R, nullptr))) return rc;
+            if (coarse_overflow) {
+                if ((rc = launch_gather_tiles(s, Pn, g, true))) return rc;          // (rewrites coffs' input too: scan it again)
+                if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
+                if ((rc = exclusive_scan_u32(s, g.coffs, g.coffs, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
+                if ((rc = exact_R(&R))) return rc;
+            }
+            if ((rc = tail(R, false))) return rc;
         }
     }
     return R;

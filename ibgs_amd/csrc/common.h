@@ -42,12 +42,14 @@ struct GeomState {
     float* depths;         // P
     float* cov3D;          // P x 6
     uint32_t* tiles;       // P   tiles touched
+    uint32_t* tc;          // P   tiles | (coarse cells of the rectangle) << 18, what the binning stage gathers
     uint32_t* rect;        // P x 2  (x0 | x1<<16, y0 | y1<<16), tightened by the tile cull
     uint64_t* tmask;       // P x IBGS_CULL_WORDS  surviving tiles inside rect (row-major bit mask, rects of <= IBGS_CULL_MAX_TILES tiles)
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered
-    uint32_t* offsets;     // P+2: exclusive scan of tiles in depth order, [P] = R, [P+1] = sort error flag (read back with R)
+    uint32_t* offsets;     // P+3: exclusive scan of tiles in depth order (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back together
+    uint32_t* coffs;       // P+1: exclusive scan of coarse cells touched, in depth order; [P] = C (binning.hip)
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
     static GeomState carve(char* base, size_t P, size_t* total);
@@ -64,13 +66,24 @@ struct ImgState {
     static ImgState carve(char* base, int W, int H, size_t* total);
 };
 
+constexpr int BIN_CELL = 8;        // two-level binning (binning.hip): a coarse cell = 8 x 8 tiles
+constexpr int BIN_XCHUNK = 256;    // coarse entries per expansion chunk (one wave, four rounds)
+
 struct BinState {
-    uint32_t* point_list;  // R   sorted Gaussian ids (final)
-    uint32_t* keys[2];     // R   tile ids (ping-pong)
-    uint32_t* vals[2];     // R   Gaussian ids (ping-pong)
+    uint32_t* point_list;  // R     sorted Gaussian ids (final); FIRST in the arena so that its offset does not depend on the capacity
+    uint32_t* cid;         // ccap  coarse entry e (emission = depth order): Gaussian id
+    uint64_t* cmask;       // ccap  ... its surviving tiles inside the cell, bit ly * 8 + lx
+    uint32_t* ckeys[2];    // ccap  cell ids (ping-pong of the coarse sort)
+    uint32_t* cvals[2];    // ccap  coarse entry indices (ping-pong)
+    uint32_t* cell_start;  // ncells + 1   first sorted coarse entry of every cell
+    uint32_t* cell_chunk0; // ncells + 1   first expansion chunk of every cell ([ncells] = number of chunks)
+    uint32_t* chunk_cnt;   // nchunks_max x 64   per chunk and tile of its cell: count, then prefix within the cell
+    uint32_t* tile_total;  // ntiles + 1   entries per tile, scanned in place to the tile starts
+    uint32_t* scan_scratch; size_t scan_elems;
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
-    static BinState carve(char* base, size_t R, int W, int H, size_t* total);
+    size_t ccap;           // capacity of the coarse arrays (= the capacity the arena was carved for: C <= R always)
+    static BinState carve(char* base, size_t R, int W, int H, size_t* total);       // H = height of the (stacked) tile grid in pixels
 };
 
 // ---- error plumbing -------------------------------------------------------------------------
@@ -167,7 +180,9 @@ int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float*
 size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by radix_sort_pairs on n items
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev = nullptr, bool key16 = false, uint32_t* err_dev = nullptr);
+                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev = nullptr, bool key16 = false, uint32_t* err_dev = nullptr,
+                     int* result_buf = nullptr);
+// result_buf: when given, an odd number of passes is NOT copied back to buffer 0; *result_buf says which buffer holds the result
 // key16: keys[] hold uint16_t values (tile ids of frames with <= 65536 tiles)
 // err_dev: device word (zeroed by the caller) that the single-launch look-back passes set to 1 when their bounded spin gives up --
 //          the pass has then scattered with a partial prefix; the caller must read it back and fail the call
@@ -177,9 +192,11 @@ int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t 
 size_t scan_scratch_elems(size_t n);
 void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatter launches per pass
 
-int launch_gather_tiles(hipStream_t s, int P, const GeomState& g);   // tiles in depth order -> offsets input
-int launch_emit(hipStream_t s, int P, int64_t R, int gx, const GeomState& g, const BinState& b, const uint32_t* R_dev = nullptr, bool key16 = false);
-int launch_ranges(hipStream_t s, int64_t R, int ntiles, const uint32_t* sorted_keys, uint32_t* ranges, const uint32_t* R_dev = nullptr, bool key16 = false);
+int launch_gather_tiles(hipStream_t s, int P, const GeomState& g, bool want_tiles);   // tiles / coarse slots in depth order -> scan inputs
+// per-tile lists + tile ranges from the depth-ordered Gaussians (two-level binning, binning.hip); `cap` = capacity of point_list
+// part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
+int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges);
+int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, int cur);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,

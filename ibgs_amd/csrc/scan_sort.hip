@@ -466,15 +466,16 @@ size_t radix_hist_elems(size_t n)
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev, bool key16, uint32_t* err_dev)
+                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev, bool key16, uint32_t* err_dev, int* result_buf)
 {
+    if (result_buf) *result_buf = 0;
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int npass = (nbits_total + 7) / 8;
     const int dbits = (nbits_total + npass - 1) / npass;
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
-    if (want_os && !n_dev && !key16 && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
+    if (want_os && !n_dev && !key16 && !result_buf && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
         return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
@@ -495,6 +496,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
+    if (result_buf) { *result_buf = cur; return 0; }
     if (cur != 0) {   // odd number of passes: bring the result back to buffer 0
         IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * (key16 ? sizeof(uint16_t) : sizeof(uint32_t)), hipMemcpyDeviceToDevice, s));
         IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));

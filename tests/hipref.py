@@ -107,8 +107,12 @@ def internal_state(outs, inp):
         st["binning_capacity"] = lo
         bo = lambda n: lib.ibgs_binning_offset(lo, W, H, n.encode())
         st["point_list"] = view(bb, bo("point_list"), np.uint32, Rr)
-        # tile ids travel as uint16 when the frame has <= 65536 tiles (api.hip), as uint32 otherwise
-        st["sorted_tile_keys"] = view(bb, bo("sorted_tile_keys"), np.uint16 if gx * gy <= 65536 else np.uint32, Rr).astype(np.uint32)
+        # the two-level binning keeps no key array: the tile of every list entry follows from the ranges (which must tile [0, R))
+        rg = st["ranges"].astype(np.int64)
+        keys = np.full(Rr, 0xFFFFFFFF, np.uint32)
+        for t in np.flatnonzero(rg[:, 1] > rg[:, 0]):
+            keys[rg[t, 0]:rg[t, 1]] = t
+        st["sorted_tile_keys"] = keys
     else:
         st["point_list"] = np.zeros(0, np.uint32); st["sorted_tile_keys"] = np.zeros(0, np.uint32)
     return st
