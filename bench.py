@@ -161,7 +161,7 @@ class Workload:
         tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         big = tiles >= 4096
         if self.geo:
-            return ("render_fwd_kernel<1, 2, 4>" if big else "render_fwd_kernel<1, 1, 4>"), ("render_bwd_geo2_kernel" if big else "render_bwd_geo_kernel")
+            return ("render_fwd_kernel<1, 2, 4>" if big else "render_fwd_kernel<1, 1, 4>"), ("render_bwd_geo4_kernel" if big else "render_bwd_geo_kernel")
         return ("render_fwd_kernel<0, 4, 4>" if big else "render_fwd_kernel<0, 1, 4>"), ("render_bwd_color_kernel" if big else "render_bwd_color_small_kernel")
 
     def describe(self, opacity, world, exchange):

@@ -19,6 +19,7 @@ FLAG_SH_FACTORED = 16
 FLAG_TILE_WAVES = 32
 FLAG_QUADRANT_WAVES = 64
 FLAG_DETERMINISTIC = 128
+FLAG_TEX_PACKED = 256
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 MAX_VIEWS = 8
 
@@ -93,6 +94,7 @@ class BackwardArgs(ctypes.Structure):
         ("render_geo", ctypes.c_int32), ("flags", ctypes.c_uint32),
         ("plane_normal", c_float_p), ("plane_offset", c_float_p), ("plane_mode", ctypes.c_int32),
         ("dL_dplane_normal", c_float_p), ("dL_dplane_offset", c_float_p),
+        ("geo_table", ctypes.c_void_p), ("geo_table_bytes", ctypes.c_size_t),
         ("det_scratch", ctypes.c_void_p), ("det_scratch_bytes", ctypes.c_size_t),
     ]
 
@@ -103,7 +105,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
-           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_required_deterministic",
+           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_required_deterministic", "ibgs_required_geo_table",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -161,6 +163,8 @@ def load():
     lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     lib.ibgs_adam_step.restype = ctypes.c_int32
     lib.ibgs_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.ibgs_required_geo_table.restype = ctypes.c_size_t
+    lib.ibgs_required_geo_table.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.ibgs_required_deterministic.restype = ctypes.c_size_t
     lib.ibgs_required_deterministic.argtypes = [ctypes.c_int64, ctypes.c_int32]
     lib.ibgs_required_compact.restype = ctypes.c_size_t

@@ -69,6 +69,8 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.low_high = c.take<uint32_t>(HW * 2);
     im.valid_idx = c.take<int32_t>(HW * IBGS_MAX_SRC);
     im.valid_w = c.take<float>(HW * IBGS_MAX_SRC);
+    im.meta = c.take<uint32_t>(32);
+    im.slot_c = c.take<uint32_t>(HW * IBGS_MAX_BUFFER_LENGTH);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;
 }
@@ -166,6 +168,7 @@ size_t ibgs_required_img(int32_t W, int32_t H) { size_t t; ImgState::carve(nullp
 size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H) { size_t t; BinState::carve(nullptr, (size_t)(R > 0 ? R : 0), W, H, &t); return t; }
 size_t ibgs_required_deterministic(int64_t R, int32_t P) { size_t t; DetState::carve(nullptr, (size_t)(R > 0 ? R : 0) * 4, (size_t)(P > 0 ? P : 0), &t); return t; }   // x 4: up to four waves per tile
 size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H) { return (size_t)n_src * W * H * sizeof(float4) + 128; }
+size_t ibgs_required_geo_table(int32_t W, int32_t H) { return geo_table_floats(W, H) * sizeof(float) + 128; }
 
 #define OFF(base_struct, field) if (!strcmp(name, #field)) return (int64_t)((char*)base_struct.field - (char*)nullptr)
 int64_t ibgs_geom_offset(int32_t P, const char* name)
@@ -179,7 +182,7 @@ int64_t ibgs_geom_offset(int32_t P, const char* name)
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
 {
     size_t t; ImgState im = ImgState::carve(nullptr, W, H, &t);
-    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w);
+    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c);
     return -1;
 }
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
@@ -360,16 +363,19 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         }
         if (!a.out_depth || !a.out_warped || !a.ref_to_src || !a.src_images) { set_error("geo backward inputs missing"); return -IBGS_ERR_INVALID; }
         if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
+        if (!a.geo_table || a.geo_table_bytes < ibgs_required_geo_table(a.W, a.H)) { set_error("geo_table scratch too small"); return -IBGS_ERR_ALLOC; }
     }
     int rc;
     GeomState g = GeomState::carve(a.geom, (size_t)a.P, nullptr);
     ImgState im = ImgState::carve(a.img, a.W, a.H, nullptr);
     BinState b = BinState::carve(a.binning, (size_t)a.R, a.W, a.H, nullptr);
     const float4* rgba = nullptr;
+    float* geo_tab = nullptr;
     if (a.render_geo) {
         float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
-        if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
+        if (!(a.flags & IBGS_FLAG_TEX_PACKED) && (rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
         rgba = t;
+        geo_tab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(a.geo_table) + 127) & ~uintptr_t(127));
     }
     if (a.R > 0) {
         const bool det = (a.flags & IBGS_FLAG_DETERMINISTIC) != 0;
@@ -382,7 +388,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
             if ((rc = launch_det_prepare(s, ds, (size_t)a.R * ipt))) return rc;
         }
         { StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-          if ((rc = launch_render_backward(s, a, g, b, im, rgba, det ? ds.slab : nullptr))) return rc;
+          if ((rc = launch_render_backward(s, a, g, b, im, rgba, det ? ds.slab : nullptr, geo_tab))) return rc;
           if (det && (rc = launch_det_reduce(s, ds, b.point_list, (size_t)a.R, ipt, a.P, a.grad_acc))) return rc; }
         if ((rc = stage_check(s, debug, "render backward"))) return rc;
     }

@@ -63,6 +63,8 @@ struct ImgState {
     uint32_t* low_high;    // HW x 2 (geo) min / max contributor of the median buffer
     int32_t* valid_idx;    // 5 x HW (geo)
     float* valid_w;        // 5 x HW (geo)
+    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass
+    uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
     static ImgState carve(char* base, int W, int H, size_t* total);
 };
 
@@ -199,10 +201,13 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
 int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, int cur);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
+// geo backward: per-pixel table of the median / warp terms of every buffered contributor (render_bwd.hip), 6 words per slot
+constexpr int GEO_TAB_FIELDS = 6;
+inline size_t geo_table_floats(int W, int H) { return (size_t)W * H * IBGS_MAX_BUFFER_LENGTH * GEO_TAB_FIELDS; }
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
                           const ImgState& im, const float4* src_rgba);
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
-                           const ImgState& im, const float4* src_rgba, float* slab = nullptr);
+                           const ImgState& im, const float4* src_rgba, float* slab = nullptr, float* geo_tab = nullptr);
 int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g);
 
 // IBGS_FLAG_DETERMINISTIC (deterministic.hip): slab of per-(Gaussian, tile) sums + its sort scratch, carved from det_scratch

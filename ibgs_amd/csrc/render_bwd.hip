@@ -4,29 +4,32 @@
 // Behaviour: DPR/cuda_rasterizer/backward.cu:496-807 (renderCUDA) + bilinearInterpolateBackward
 // (backward.cu:55-109).  The reference issues up to 16 global atomicAdd per (pixel, Gaussian) pair
 // into five separate arrays.  On MI355X global float atomics run at ~1.3 TB/s chip-wide only when
-// they arrive as contiguous 64-byte requests (MI355X_MICROARCH.md "Global float atomics"), so here:
+// they arrive as contiguous 64-byte requests (MI355X_MICROARCH.md "Global float atomics"), and the blend
+// kernels are VALU-issue bound, so here:
 //
-//   * one wave owns a 16x16 tile (PPL = 4) or an 8x8 quadrant (PPL = 1: geo variant, and the colour variant on
-//     frames with fewer than 4096 tiles, where tiles alone would leave the chip mostly empty); a lane first
-//     sums its own pixels' contributions in registers;
-//   * what is summed per pixel are MOMENTS of q = o*G*dL/dalpha -- sum q, q dx, q dy, q dx^2, q dx dy,
-//     q dy^2, |q lx|, |q ly| -- instead of the reference's eight final quantities; the per-Gaussian
-//     constants (conic, opacity, 0.5*W) are factored out of the pixel sums and applied once per Gaussian
-//     in preprocess_bwd.hip.  Same mathematics (the sums are linear), ~2x fewer VALU ops per pair;
-//   * the 16 per-lane partial sums are reduced over the 64 lanes with a butterfly TRANSPOSE-reduce
-//     (v_permlane32_swap, v_permlane16_swap, DPP row rotates / mirrors, quad_perm): 31 VALU ops for the 12 values of
-//     the colour variant (40 for 16), after which one lane per value holds its wave total -- no LDS traffic;
+//   * one wave owns a 16x16 tile (4 pixels per lane: lane l = pixel (l%8, l/8) of each 8x8 quadrant) or, on frames with
+//     fewer than 4096 tiles, one 8x8 quadrant (the chip would stay mostly empty otherwise); no cross-wave synchronisation;
+//   * per pixel and Gaussian a lane keeps ONE number, Q = o G dL/dalpha; the six geometric moments sum Q, Q d, Q d d^T
+//     (d = Gaussian centre - pixel) are assembled once per Gaussian from the lane's four Q and its d0 (the other pixels sit at
+//     d0 - (8,0), (0,8), (8,8)); the per-Gaussian constants (conic, opacity, 0.5 W) are applied in preprocess_bwd.hip.
+//     Same mathematics as the reference's eight per-pair quantities (the sums are linear), ~24 instead of ~41 VALU
+//     instructions per pair;
+//   * the 12 (colour) / 16 (geo) per-lane partial sums are reduced over the 64 lanes with a butterfly TRANSPOSE-reduce
+//     (v_permlane32_swap, v_permlane16_swap, DPP row rotates / mirrors, quad_perm; wave_reduce.h), after which one lane per
+//     value holds its wave total -- no LDS traffic; measured cost ~145 cycles per Gaussian (profiles/r02_probe_xlane.txt);
 //   * the wave then issues ONE atomic instruction per Gaussian: 11 (colour) / 15 (geo) lanes add their totals to that
-//     Gaussian's 64-byte accumulation row (grad_acc[P][16]) -- one 64-byte memory-side request per
-//     (Gaussian, tile) instead of 11-16 scattered dword atomics per (Gaussian, pixel);
-//   * Gaussians that no pixel of the wave uses (ballot == 0, or behind every pixel's last contributor)
-//     cost a few VALU instructions and no memory traffic.
+//     Gaussian's 64-byte accumulation row (grad_acc[P][16]) -- one 64-byte memory-side request per (Gaussian, tile)
+//     instead of 11-16 scattered dword atomics per (Gaussian, pixel).  IBGS_FLAG_DETERMINISTIC stores the totals in a slab
+//     instead (deterministic.hip);
+//   * Gaussians that no pixel of the wave uses (ballot == 0, or behind every pixel's last contributor) cost a few VALU
+//     instructions and no memory traffic;
+//   * geo: the median / warp block (B2) runs as a pixel-parallel pre-pass that leaves a per-pixel table; the blend loop only
+//     looks entries up (geo_window_kernel below).
 //
 // Deviations (documented in DESIGN.md): the skip tests are the forward's single compare of p2 against the per-Gaussian
-// bound 2 ln(255 o) (render_fwd.hip), so both passes visit exactly the same (pixel, Gaussian) pairs; alpha is recomputed with the same fast exp2 as the forward
-// (the reference uses __expf forward / exp backward) so that T/(1-alpha) retraces the
-// forward transmittance; 1/(1-alpha) is a hardware reciprocal refined by one Newton step instead of an
-// IEEE division.
+// bound 2 ln(255 o) (render_fwd.hip), so both passes visit exactly the same (pixel, Gaussian) pairs; alpha is recomputed with the
+// same fast exp2 as the forward (the reference uses __expf forward / exp backward); 1/(1-alpha) is the hardware
+// reciprocal (1 ulp) instead of an IEEE division.
 #include "common.h"
 #include "wave_reduce.h"
 #include <type_traits>
@@ -44,6 +47,7 @@ struct BwdParams {
     const float* depth_pixels; const float* warped_pixels;
     const float* dL_dcolor; const float* dL_dnormal; const float* dL_ddepth; const float* dL_dwarped;
     float* gacc;
+    const uint32_t* slot_c; const uint32_t* meta; float* tab;     // geo: the forward's buffered contributor numbers (+ slot count); the window pass's table
     float* slab;          // IBGS_FLAG_DETERMINISTIC: (R x waves per tile) x 16, one row per (list entry, wave of its tile), written instead of the atomics (else nullptr)
 };
 
@@ -259,25 +263,144 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
     }
 }
 
-template <bool GEO, int PPL>
-__device__ __forceinline__ void render_bwd_body(const BwdParams& p)
+// ---- geo variant, pass 1: the median / warp terms of every buffered contributor, per pixel ---------------------------------
+// The reference evaluates the block of backward.cu:692-771 inside the blend loop for every accepted pair whose list position lies
+// in the pixel's window [min - 1, max - 1] with a positive ray/plane depth -- exactly the contributors the forward buffered (the
+// last ceil(L/2) before T crosses 0.5, the first floor(L/2) after it).  Everything in that block except the blend
+// weight w = alpha T of the pair is a function of (pixel, Gaussian) alone, and w enters linearly.  So one thread per PIXEL
+// computes, for each of its <= L buffered contributors (numbers saved by the forward, img arena `slot_c`):
+//     E   what the block adds to dL/dalpha:  dL/dmedian (d - median) / sum_w + sum_m dL/dwarped[m] . (c_m - warped[m]) / sw_m
+//     K   what it adds to dL/d(plane parameters) PER UNIT of w (with the cumulative depth gradient of quirk Q2 already summed
+//         over the in-bounds sources):  Kx, Ky, Kz for the normal, Kd for the distance
+// and writes them sorted by contributor number, descending = the order the back-to-front traversal meets them, closed by a zero.
+// The blend loop (pass 2) then handles a window pair with one compare, five loads and five fma instead of ~300 instructions and
+// 25 texel gathers under a one-lane exec mask, and no longer carries the warp code's registers.
+// Table layout: tab[(slot * 6 + field) * HW + pixel], fields = {contributor number (uint bits), E, Kx, Ky, Kz, Kd}.
+__global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
 {
-    constexpr int NQ = GEO ? 4 : 3;
-    constexpr bool SEL = !GEO;            // branch-free blend step (see the active block)
-    constexpr int NV = GEO ? 16 : 12;     // per-lane partial sums handed to the transpose-reduce
-    // Colour variant: 8 waves per SIMD (<= 64 VGPRs, <= 5 KB LDS per wave) keep all tiles of a 1080p frame resident
-    // at once -- no second, half-empty round of workgroups.  To get there the per-pixel loss gradient lives in a
-    // per-lane LDS slot instead of 12 registers and records are staged 32 at a time.
-    constexpr int CHUNK = GEO ? WAVE : 32;
-    constexpr bool GLDS = !GEO;
-    __shared__ float4 s_rec[NQ][CHUNK];
-    __shared__ float s_gpix[GLDS ? PPL : 1][GLDS ? WAVE : 1][3];
+    const int W = p.cam.W, H = p.cam.H;
+    const size_t HW = (size_t)W * H;
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int px = (int)(pix % W), py = (int)(pix / W);
+    const float pxf = (float)px, pyf = (float)py;
+    const float fx = p.cam.fx, fy = p.cam.fy;
+    const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
+    const int L = min((int)p.meta[0], IBGS_MAX_BUFFER_LENGTH);
+    float* tab = p.tab + pix;
+    auto put = [&](int slot, int field, float v) { tab[(size_t)(slot * GEO_TAB_FIELDS + field) * HW] = v; };
+
+    // buffered contributors, sorted by number, descending (L <= 8: insertion sort in registers)
+    uint32_t cs[IBGS_MAX_BUFFER_LENGTH];
+    int ns = 0;
+    const uint32_t lo = p.low_high[2 * pix];
+    if (lo != 0u) {           // Q4: slot 0 empty -> min contributor 0 -> the unsigned window test never passes: no entry for this pixel
+        for (int s = 0; s < L; s++) {
+            const uint32_t c = p.slot_c[(size_t)s * HW + pix];
+            if (c == 0u) continue;
+            int at = ns++;
+#pragma unroll
+            for (int k = IBGS_MAX_BUFFER_LENGTH - 1; k > 0; k--) if (k <= at && cs[k - 1] < c) { cs[k] = cs[k - 1]; at = k - 1; }
+            cs[at] = c;
+        }
+    }
+    if (ns == 0) { put(0, 0, __uint_as_float(0u)); return; }
+
+    const int tile = (py / TILE) * p.cam.gx + px / TILE;
+    const uint32_t r0 = p.ranges[2 * tile];
+    // dbl: backward.cu:545 evaluates (pix - W*0.5)/fx in double
+    const float rayx = (float)(((double)pxf - W * 0.5) / (double)fx), rayy = (float)(((double)pyf - H * 0.5) / (double)fy);
+    const float sumw = p.sum_w[pix];
+    const float g_d = p.dL_ddepth ? p.dL_ddepth[pix] : 0.f;
+    const float med = p.depth_pixels[pix];
+    int out = 0;
+    for (int i = 0; i < ns; i++) {
+        const uint32_t c = cs[i];
+        const uint32_t gid = p.point_list[r0 + c - 1u];
+        const float4 q1 = p.rec[(size_t)gid * 4 + 1], q3 = p.rec[(size_t)gid * 4 + 3];
+        const float dist = q1.w;
+        const float dotn = q3.x * rayx + q3.y * rayy + q3.z;
+        const float tmp = (float)((double)dotn + 1.0e-8);                 // dbl, backward.cu:697
+        const float tmp2 = dist / (tmp * tmp);
+        const float dep = (float)(-(double)dist / ((double)dotn + 1.0e-8));  // dbl, backward.cu:699
+        if (!(dep > 0.0f)) continue;            // (cannot happen for a buffered contributor; kept as the reference's gate)
+        const float X = (pxf - cx) * dep / fx, Y = (pyf - cy) * dep / fy, Z = dep;
+        float kd = g_d / sumw;                  // depth gradient per unit of w
+        float E = g_d * (dep - med) / sumw;
+        float Kd = 0.f, Kx = 0.f, Ky = 0.f, Kz = 0.f;
+        for (int m = 0; m < IBGS_MAX_SRC; m++) {
+            const int si = p.valid_idx[(size_t)m * HW + pix];
+            if (si == -1) break;
+            const float* r = p.ref_to_src + 16 * si;
+            const float tx = r[0] * X + r[1] * Y + r[2] * Z + r[3];
+            const float ty = r[4] * X + r[5] * Y + r[6] * Z + r[7];
+            const float tz = r[8] * X + r[9] * Y + r[10] * Z + r[11];
+            const float u = (tx * fx / tz) + cx, vv_ = (ty * fy / tz) + cy;
+            if (u >= 0 && u <= W - 1 && vv_ >= 0 && vv_ <= H - 1) {
+                const float4* img = p.src_rgba + (size_t)si * HW;
+                const float4 c4 = tex_rgba_b(img, W, H, u + 0.5f, vv_ + 0.5f, p.tex_quant);
+                const float cc3[3] = {c4.x, c4.y, c4.z};
+                const float sw = p.valid_w[(size_t)m * HW + pix];
+                float gc[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float gw = p.dL_dwarped ? p.dL_dwarped[((size_t)m * 3 + ch) * HW + pix] : 0.f;
+                    gc[ch] = gw / sw;
+                    E += gw * (cc3[ch] - p.warped_pixels[((size_t)m * 3 + ch) * HW + pix]) / sw;
+                }
+                const float Av = (pxf - cx) / fx, Bv = (pyf - cy) / fy;
+                const float U = r[0] * Av + r[1] * Bv + r[2];
+                const float V = r[4] * Av + r[5] * Bv + r[6];
+                const float Wc = r[8] * Av + r[9] * Bv + r[10];
+                const float den = (Wc * dep + r[11]);
+                const float dpx = fx * (U * r[11] - Wc * r[3]) / (den * den);
+                const float dpy = fy * (V * r[11] - Wc * r[7]) / (den * den);
+                // four linear-filtered fetches at integer coordinates
+                const float uu = u + 0.5f, vv2 = vv_ + 0.5f;
+                const int u0 = (int)floorf(uu), v0 = (int)floorf(vv2);
+                const float fu = uu - (float)u0, fv = vv2 - (float)v0, fu1 = 1.0f - fu, fv1 = 1.0f - fv;
+                const float4 I00 = tex_rgba_b(img, W, H, (float)u0, (float)v0, p.tex_quant);
+                const float4 I01 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)v0, p.tex_quant);
+                const float4 I10 = tex_rgba_b(img, W, H, (float)u0, (float)(v0 + 1), p.tex_quant);
+                const float4 I11 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)(v0 + 1), p.tex_quant);
+                const float dIu0 = -fv1 * I00.x + fv1 * I01.x - fv * I10.x + fv * I11.x;
+                const float dIu1 = -fv1 * I00.y + fv1 * I01.y - fv * I10.y + fv * I11.y;
+                const float dIu2 = -fv1 * I00.z + fv1 * I01.z - fv * I10.z + fv * I11.z;
+                const float dIv0 = -fu1 * I00.x - fu * I01.x + fu1 * I10.x + fu * I11.x;
+                const float dIv1 = -fu1 * I00.y - fu * I01.y + fu1 * I10.y + fu * I11.y;
+                const float dIv2 = -fu1 * I00.z - fu * I01.z + fu1 * I10.z + fu * I11.z;
+                const float du = gc[0] * dIu0 + gc[1] * dIu1 + gc[2] * dIu2;
+                const float dv = gc[0] * dIv0 + gc[1] * dIv1 + gc[2] * dIv2;
+                kd += du * dpx + dv * dpy;
+                // the plane parameters receive the depth gradient inside the per-source in-bounds branch, cumulatively
+                Kd += (-kd / tmp);
+                Kx += kd * tmp2 * rayx;
+                Ky += kd * tmp2 * rayy;
+                Kz += kd * tmp2;
+            }
+        }
+        put(out, 0, __uint_as_float(c)); put(out, 1, E); put(out, 2, Kx); put(out, 3, Ky); put(out, 4, Kz); put(out, 5, Kd);
+        out++;
+    }
+    if (out < IBGS_MAX_BUFFER_LENGTH) put(out, 0, __uint_as_float(0u));
+}
+
+// ---- geo variant, pass 2: the blend loop -----------------------------------------------------------------------------------
+// render_bwd_color_body plus (i) the three normal channels, blended like colour channels (they share S), (ii) the window pairs:
+// a pixel's next buffered contributor number sits in a register; when the traversal reaches it (one integer compare per quadrant
+// and Gaussian) the lane loads that entry of the window table, adds E to dL/dalpha and w K to the plane sums, and moves on.
+template <int PPL>
+__device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
+{
+    constexpr int CHUNK = 16;
+    __shared__ float4 s_rec[4][CHUNK];
+    __shared__ float4 s_gpix[PPL][WAVE];                  // dL/dC (rgb), -T_final * (bg . dL/dC)
+    __shared__ float4 s_gnrm[PPL][WAVE];                  // dL/dN (xyz)
 
     const int lane = threadIdx.x;
-    // the lane that ends up with the wave total of grad_acc column `col` after the reduce (-1: none)
-    int col = GEO ? reduce16_column(lane) : reduce12_column(lane);
-    if (col >= (GEO ? 15 : 11)) col = -1;
-    constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
+    int col = reduce16_column(lane);
+    if (col >= 15) col = -1;
+    constexpr int IPT = 4 / PPL;
     const int nitems = p.ntiles * IPT;
     const int item = xcd_band_map_b(blockIdx.x, nitems);
     if (item >= nitems) return;
@@ -286,237 +409,175 @@ __device__ __forceinline__ void render_bwd_body(const BwdParams& p)
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
     const size_t HW = (size_t)W * H;
-    const float fx = p.cam.fx, fy = p.cam.fy;
-    const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
-    const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E, the forward's constant
+    const float NHL2E = -0.5f * 1.4426950408889634f;
 
-    float pxf[PPL], pyf[PPL];
-    size_t pixid[PPL];
-    float T[PPL], Tfbg[PPL], S[PPL], g_pix[GLDS ? 1 : PPL][3];
-    uint32_t ncontrib[PPL];
-    // geo
-    float g_n[PPL][3], g_d[PPL], rayx[PPL], rayy[PPL];
-    uint32_t min_med[PPL], max_med[PPL];
-
+    float T[PPL], S[PPL];
+    uint32_t ncontrib[PPL], next_c[PPL], slot[PPL], pixo[PPL];
     uint32_t nmax = 0;
+    const float pxf0 = (float)(tx0 + (quad0 & 1) * 8 + (lane & 7)), pyf0 = (float)(ty0 + (quad0 >> 1) * 8 + (lane >> 3));
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
         const int qq = quad0 + q;
         const int px = tx0 + (qq & 1) * 8 + (lane & 7), py = ty0 + (qq >> 1) * 8 + (lane >> 3);
-        pxf[q] = (float)px; pyf[q] = (float)py;
         const bool inside = px < W && py < H;
-        pixid[q] = (size_t)py * W + px;
-        const float T_final = inside ? p.final_T[pixid[q]] : 0.f;
+        const size_t pix = (size_t)py * W + px;
+        pixo[q] = inside ? (uint32_t)pix : 0u;
+        const float T_final = inside ? p.final_T[pix] : 0.f;
         T[q] = T_final;
-        ncontrib[q] = inside ? p.n_contrib[pixid[q]] : 0u;
+        ncontrib[q] = inside ? p.n_contrib[pix] : 0u;
         nmax = max(nmax, ncontrib[q]);
         S[q] = 0.f;
-        float bg_dot = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const float gp = (inside && p.dL_dcolor) ? p.dL_dcolor[ch * HW + pixid[q]] : 0.f;
-            if (GLDS) s_gpix[q][lane][ch] = gp; else g_pix[q][ch] = gp;
-            bg_dot += p.cam.bg[ch] * gp;
-        }
-        Tfbg[q] = -T_final * bg_dot;
-        if (GEO) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) g_n[q][ch] = (inside && p.dL_dnormal) ? p.dL_dnormal[ch * HW + pixid[q]] : 0.f;
-            g_d[q] = (inside && p.dL_ddepth) ? p.dL_ddepth[pixid[q]] : 0.f;
-            min_med[q] = inside ? p.low_high[2 * pixid[q]] : 0u;
-            max_med[q] = inside ? p.low_high[2 * pixid[q] + 1] : 0u;
-            // dbl: backward.cu:545 evaluates (pix - W*0.5)/fx in double
-            rayx[q] = (float)(((double)pxf[q] - W * 0.5) / (double)fx);
-            rayy[q] = (float)(((double)pyf[q] - H * 0.5) / (double)fy);
-        }
+        float4 g, gn;
+        g.x = (inside && p.dL_dcolor) ? p.dL_dcolor[pix] : 0.f;
+        g.y = (inside && p.dL_dcolor) ? p.dL_dcolor[HW + pix] : 0.f;
+        g.z = (inside && p.dL_dcolor) ? p.dL_dcolor[2 * HW + pix] : 0.f;
+        g.w = -T_final * (p.cam.bg[0] * g.x + p.cam.bg[1] * g.y + p.cam.bg[2] * g.z);
+        gn.x = (inside && p.dL_dnormal) ? p.dL_dnormal[pix] : 0.f;
+        gn.y = (inside && p.dL_dnormal) ? p.dL_dnormal[HW + pix] : 0.f;
+        gn.z = (inside && p.dL_dnormal) ? p.dL_dnormal[2 * HW + pix] : 0.f;
+        gn.w = 0.f;
+        s_gpix[q][lane] = g; s_gnrm[q][lane] = gn;
+        slot[q] = 0;
+        next_c[q] = inside ? __float_as_uint(p.tab[pix]) : 0u;          // table entry 0, field 0 (0 = no window pair at all)
     }
     nmax = wave_max_u32(nmax);
     const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
     const int n = (int)(r1 - r0);
-    int top = min((int)nmax, n);           // entries >= top contribute to no pixel of this wave
+    int top = __builtin_amdgcn_readfirstlane(min((int)nmax, n));
 
     while (top > 0) {
         const int count = min(CHUNK, top);
-        if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
+        if (lane < count) {
             const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
-            ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
-            s_rec[0][lane] = ra; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
-            if constexpr (GEO) s_rec[3][lane] = r[3];
+            ra.w = __uint_as_float(id);
+            s_rec[0][lane] = ra; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2]; s_rec[3][lane] = r[3];
+        }
+        uint64_t ncm[PPL];
+        bool stable = true;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+            ncm[q] = __builtin_amdgcn_ballot_w64((uint32_t)(top - count) < ncontrib[q]);
+            stable = stable && (ncm[q] == __builtin_amdgcn_ballot_w64((uint32_t)(top - 1) < ncontrib[q]));
         }
         __syncthreads();
-        for (int j = 0; j < count; j++) {
-            const uint32_t k = (uint32_t)(top - 1 - j);          // 0-based position in the tile list
-            const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
-            float4 q3 = q2;
-            if constexpr (GEO) q3 = s_rec[3][j];
-            const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
-            const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
-            // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist (= grad_acc columns)
-            float v[NV];
+        auto chunk = [&](auto stable_tag) {
+            constexpr bool STABLE = decltype(stable_tag)::value;
+            for (int j = 0; j < count; j++) {
+                const uint32_t k = (uint32_t)(top - 1 - j);
+                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j];
+                const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
+                const uint32_t qbound = __float_as_uint(q2.w);
+                const float dx0 = q0.x - pxf0, dy0 = q0.y - pyf0;
+                const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
+                const float P0 = dx0 * lx0 + dy0 * ly0;
+                float p2q[PPL], lxq[PPL], lyq[PPL];
+                p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
+                if constexpr (PPL >= 2) {
+                    p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
+                    lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0);
+                }
+                if constexpr (PPL == 4) {
+                    p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
+                    p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
+                    lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
+                    lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                }
+                float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f;
+                bool any = false;
 #pragma unroll
-            for (int i = 0; i < NV; i++) v[i] = 0.f;
-            bool any = false;
-            // same evaluation of p2 = d^T conic d as the forward (render_fwd.hip): once per lane, shifted to the
-            // other three quadrants, so both passes take identical alpha decisions
-            const float dx0 = q0.x - pxf[0], dy0 = q0.y - pyf[0];
-            const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
-            const float P0 = dx0 * lx0 + dy0 * ly0;
-            float p2q[PPL];
-            p2q[0] = P0;
-            if (PPL >= 2) p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
-            if (PPL == 4) {
-                p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
-                p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
-            }
-#pragma unroll
-            for (int q = 0; q < PPL; q++) {
-                // the forward's test: 0 <= p2 <= 2 ln(255 o) as one unsigned compare of the float bits (render_fwd.hip)
-                const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(__float_as_uint(p2q[q]) < qbound);
-                if (okm != 0ull) {
-                    any = true;
-                    const float G = __builtin_amdgcn_exp2f(p2q[q] * NHL2E);
-                    const float oG = op * G;
-                    const float alpha = min_099(oG);
-                    // Colour variant: no per-lane branch.  Lanes that fail the test run the same instructions with
-                    // alpha = o G = 0, which leaves T and S unchanged (1/(1-0) = 1 exactly) and adds zeros.
-                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
-                    const float oGs = SEL ? select_or_zero(okm, oG) : oG;
-                    const float alpha_s = SEL ? select_or_zero(okm, alpha) : alpha;
-                    if (SEL || ok) {
-                        // only the moments need d and conic*d per quadrant; the lane's other pixels sit 8 px right / down
-                        const float dx = (PPL >= 2) ? dx0 - ((q & 1) ? 8.0f : 0.0f) : q0.x - pxf[q];
-                        const float dy = (PPL >= 2) ? dy0 - ((q >> 1) ? 8.0f : 0.0f) : q0.y - pyf[q];
-                        const float lx = ca * dx + cb * dy, ly = cb * dx + cc * dy;
-                        const float rinv = fast_rcp(1.f - alpha_s);
+                for (int q = 0; q < PPL; q++) {
+                    const uint64_t live = STABLE ? ncm[q] : __builtin_amdgcn_ballot_w64(k < ncontrib[q]);
+                    const uint64_t okm = live & __builtin_amdgcn_ballot_w64(__float_as_uint(p2q[q]) < qbound);
+                    Q[q] = 0.f;
+                    if (okm != 0ull) {
+                        any = true;
+                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(p2q[q] * NHL2E));
+                        const float alpha = min_099(oG);
+                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T[q] = T[q] * rinv;
-                        const float w = alpha_s * T[q];
-                        // S = (colour behind this Gaussian) . (pixel gradient): scalar form of the reference's per-channel
-                        // accum_rec / last_color / last_alpha recurrence (backward.cu:665-669), folded into one fma:
-                        // behind_k = alpha_k c_k + (1 - alpha_k) behind_{k+1} = behind_{k+1} + alpha_k (c_k - behind_{k+1})
-                        float gp0, gp1, gp2;
-                        if (GLDS) { gp0 = s_gpix[q][lane][0]; gp1 = s_gpix[q][lane][1]; gp2 = s_gpix[q][lane][2]; }
-                        else { gp0 = g_pix[q][0]; gp1 = g_pix[q][1]; gp2 = g_pix[q][2]; }
-                        float cg = q2.x * gp0 + q2.y * gp1 + q2.z * gp2;
+                        const float w = alpha * T[q];
+                        const float4 gp = s_gpix[q][lane], gn = s_gnrm[q][lane];
                         // the normal channels are blended like three more colour channels: they share S
-                        if (GEO) cg += q3.x * g_n[q][0] + q3.y * g_n[q][1] + q3.z * g_n[q][2];
+                        const float cg = q2.x * gp.x + q2.y * gp.y + q2.z * gp.z + q3.x * gn.x + q3.y * gn.y + q3.z * gn.z;
                         float dL_dalpha = cg - S[q];
-                        S[q] = fmaf(alpha_s, dL_dalpha, S[q]);
-                        v[8] += w * gp0; v[9] += w * gp1; v[10] += w * gp2;
-                        if (GEO) {
-                            float gm0 = w * g_n[q][0], gm1 = w * g_n[q][1], gm2 = w * g_n[q][2], gm4 = 0.f;
-                            // unsigned comparison: min_med == 0 disables the branch
-                            if ((k >= (uint32_t)((int)min_med[q] - 1)) && (k <= (uint32_t)((int)max_med[q] - 1))) {
-                                const float dist = q1.w;
-                                const float dotn = q3.x * rayx[q] + q3.y * rayy[q] + q3.z;
-                                const float tmp = (float)((double)dotn + 1.0e-8);                 // dbl, backward.cu:697
-                                const float tmp2 = dist / (tmp * tmp);
-                                const float dep = (float)(-(double)dist / ((double)dotn + 1.0e-8));  // dbl, backward.cu:699
-                                if (dep > 0.0f) {
-                                    const float X = (pxf[q] - cx) * dep / fx, Y = (pyf[q] - cy) * dep / fy, Z = dep;
-                                    const float sumw = p.sum_w[pixid[q]];
-                                    float gdep = g_d[q] * w / sumw;
-                                    dL_dalpha += g_d[q] * (dep - p.depth_pixels[pixid[q]]) / sumw;
-                                    for (int m = 0; m < IBGS_MAX_SRC; m++) {
-                                        const int si = p.valid_idx[(size_t)m * HW + pixid[q]];
-                                        if (si == -1) break;
-                                        const float* r = p.ref_to_src + 16 * si;
-                                        const float tx = r[0] * X + r[1] * Y + r[2] * Z + r[3];
-                                        const float ty = r[4] * X + r[5] * Y + r[6] * Z + r[7];
-                                        const float tz = r[8] * X + r[9] * Y + r[10] * Z + r[11];
-                                        const float u = (tx * fx / tz) + cx, vv_ = (ty * fy / tz) + cy;
-                                        if (u >= 0 && u <= W - 1 && vv_ >= 0 && vv_ <= H - 1) {
-                                            const float4* img = p.src_rgba + (size_t)si * HW;
-                                            const float4 c4 = tex_rgba_b(img, W, H, u + 0.5f, vv_ + 0.5f, p.tex_quant);
-                                            const float cc3[3] = {c4.x, c4.y, c4.z};
-                                            const float sw = p.valid_w[(size_t)m * HW + pixid[q]];
-                                            float gc[3];
-#pragma unroll
-                                            for (int ch = 0; ch < 3; ch++) {
-                                                const float gw = p.dL_dwarped ? p.dL_dwarped[((size_t)m * 3 + ch) * HW + pixid[q]] : 0.f;
-                                                gc[ch] = gw * w / sw;
-                                                dL_dalpha += gw * (cc3[ch] - p.warped_pixels[((size_t)m * 3 + ch) * HW + pixid[q]]) / sw;
-                                            }
-                                            const float Av = (pxf[q] - cx) / fx, Bv = (pyf[q] - cy) / fy;
-                                            const float U = r[0] * Av + r[1] * Bv + r[2];
-                                            const float V = r[4] * Av + r[5] * Bv + r[6];
-                                            const float Wc = r[8] * Av + r[9] * Bv + r[10];
-                                            const float den = (Wc * dep + r[11]);
-                                            const float dpx = fx * (U * r[11] - Wc * r[3]) / (den * den);
-                                            const float dpy = fy * (V * r[11] - Wc * r[7]) / (den * den);
-                                            // four linear-filtered fetches at integer coordinates
-                                            const float uu = u + 0.5f, vv2 = vv_ + 0.5f;
-                                            const int u0 = (int)floorf(uu), v0 = (int)floorf(vv2);
-                                            const float fu = uu - (float)u0, fv = vv2 - (float)v0, fu1 = 1.0f - fu, fv1 = 1.0f - fv;
-                                            const float4 I00 = tex_rgba_b(img, W, H, (float)u0, (float)v0, p.tex_quant);
-                                            const float4 I01 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)v0, p.tex_quant);
-                                            const float4 I10 = tex_rgba_b(img, W, H, (float)u0, (float)(v0 + 1), p.tex_quant);
-                                            const float4 I11 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)(v0 + 1), p.tex_quant);
-                                            const float dIu0 = -fv1 * I00.x + fv1 * I01.x - fv * I10.x + fv * I11.x;
-                                            const float dIu1 = -fv1 * I00.y + fv1 * I01.y - fv * I10.y + fv * I11.y;
-                                            const float dIu2 = -fv1 * I00.z + fv1 * I01.z - fv * I10.z + fv * I11.z;
-                                            const float dIv0 = -fu1 * I00.x - fu * I01.x + fu1 * I10.x + fu * I11.x;
-                                            const float dIv1 = -fu1 * I00.y - fu * I01.y + fu1 * I10.y + fu * I11.y;
-                                            const float dIv2 = -fu1 * I00.z - fu * I01.z + fu1 * I10.z + fu * I11.z;
-                                            const float du = gc[0] * dIu0 + gc[1] * dIu1 + gc[2] * dIu2;
-                                            const float dv = gc[0] * dIv0 + gc[1] * dIv1 + gc[2] * dIv2;
-                                            gdep += du * dpx + dv * dpy;
-                                            // emitted inside the per-source in-bounds branch
-                                            gm4 += (-gdep / tmp);
-                                            gm0 += gdep * tmp2 * rayx[q];
-                                            gm1 += gdep * tmp2 * rayy[q];
-                                            gm2 += gdep * tmp2;
-                                        }
-                                    }
-                                }
+                        S[q] = fmaf(alpha, dL_dalpha, S[q]);
+                        vR = fmaf(w, gp.x, vR); vG = fmaf(w, gp.y, vG); vB = fmaf(w, gp.z, vB);
+                        vNx = fmaf(w, gn.x, vNx); vNy = fmaf(w, gn.y, vNy); vNz = fmaf(w, gn.z, vNz);
+                        // window pair?  (a buffered contributor is an accepted pair by construction; the test is taken under okm anyway)
+                        const uint64_t hit = okm & __builtin_amdgcn_ballot_w64(k + 1u == next_c[q]);
+                        if (hit != 0ull) {                                           // wave-uniform
+                            if (__builtin_amdgcn_inverse_ballot_w64(hit)) {
+                                const float* e = p.tab + (size_t)(slot[q] * GEO_TAB_FIELDS) * HW + pixo[q];
+                                dL_dalpha += e[HW];
+                                vNx = fmaf(w, e[2 * HW], vNx); vNy = fmaf(w, e[3 * HW], vNy); vNz = fmaf(w, e[4 * HW], vNz);
+                                vD = fmaf(w, e[5 * HW], vD);
+                                slot[q]++;
+                                next_c[q] = (slot[q] < (uint32_t)IBGS_MAX_BUFFER_LENGTH) ? __float_as_uint(e[(size_t)GEO_TAB_FIELDS * HW]) : 0u;
                             }
-                            v[11] += gm0; v[12] += gm1; v[13] += gm2; v[14] += gm4;
                         }
-                        dL_dalpha = dL_dalpha * T[q] + Tfbg[q] * rinv;
-                        const float qq = oGs * dL_dalpha;             // dL/dG * G
-                        const float qdx = qq * dx, qdy = qq * dy;
-                        v[0] += qdx; v[1] += qdy;
-                        v[2] += fabsf(qq * lx); v[3] += fabsf(qq * ly);
-                        v[4] += qdx * dx; v[5] += qdx * dy; v[6] += qdy * dy;
-                        v[7] += qq;
+                        dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);
+                        const float qv = oG * dL_dalpha;
+                        Q[q] = qv;
+                        aX += fabsf(qv * lxq[q]); aY += fabsf(qv * lyq[q]);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                    // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist (= grad_acc columns)
+                    float v[16];
+                    if constexpr (PPL == 4) {
+                        const float A = Q[1] + Q[3], B = Q[2] + Q[3], S0 = (Q[0] + Q[2]) + A;
+                        const float t = dx0 * S0, u = dy0 * S0;
+                        v[0] = fmaf(-8.0f, A, t); v[1] = fmaf(-8.0f, B, u);
+                        v[4] = fmaf(dx0, fmaf(-16.0f, A, t), 64.0f * A);
+                        v[6] = fmaf(dy0, fmaf(-16.0f, B, u), 64.0f * B);
+                        v[5] = fmaf(-8.0f, fmaf(-8.0f, Q[3], dx0 * B), dy0 * v[0]);
+                        v[7] = S0;
+                    } else if constexpr (PPL == 2) {       // two quadrants side by side: d1 = d0 - (8, 0)
+                        const float S0 = Q[0] + Q[1];
+                        const float t = dx0 * S0;
+                        v[0] = fmaf(-8.0f, Q[1], t); v[1] = dy0 * S0;
+                        v[4] = fmaf(dx0, fmaf(-16.0f, Q[1], t), 64.0f * Q[1]);
+                        v[5] = dy0 * v[0]; v[6] = dy0 * v[1];
+                        v[7] = S0;
+                    } else {
+                        const float qdx = Q[0] * dx0, qdy = Q[0] * dy0;
+                        v[0] = qdx; v[1] = qdy; v[4] = qdx * dx0; v[5] = qdx * dy0; v[6] = qdy * dy0; v[7] = Q[0];
+                    }
+                    v[2] = aX; v[3] = aY; v[8] = vR; v[9] = vG; v[10] = vB; v[11] = vNx; v[12] = vNy; v[13] = vNz; v[14] = vD; v[15] = 0.f;
+                    const float tot = wave_transpose_reduce16(v, lane);
+                    const uint32_t id = __float_as_uint(q0.w);
+                    if (col >= 0) {
+                        if (p.slab) p.slab[((size_t)(r0 + k) * IPT + (size_t)(item % IPT)) * GACC_FLOATS + col] = tot;
+                        else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
                     }
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
-                float tot;
-                if constexpr (GEO) tot = wave_transpose_reduce16(v, lane); else tot = wave_transpose_reduce12(v, lane);
-                const uint32_t id = __float_as_uint(q0.w);
-                if (col >= 0) {
-                    if (p.slab) p.slab[((size_t)(r0 + k) * IPT + (size_t)(item % IPT)) * GACC_FLOATS + col] = tot;          // wave-uniform choice
-                    else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
-                }
-            }
-        }
+        };
+        if (stable) chunk(std::true_type{}); else chunk(std::false_type{});
         __syncthreads();
         top -= count;
     }
 }
 
-// Two entry points so that each variant gets its own register budget: the colour kernel fits 5 waves per
-// SIMD (<= 96 VGPRs) without spilling, the geo kernel (texture gathers, median window) does not.
+// One entry point per variant so that each gets its own register budget.  Large frames: one wave per tile; small frames (fewer
+// tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up.
 __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_color_body<4>(p); }
-__global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_body<true, 1>(p); }
-// geo on large frames: one wave per half tile (quadrant pairs 0-1 / 2-3), 128 VGPRs, 4 waves per SIMD
-__global__ void __launch_bounds__(64, 4) render_bwd_geo2_kernel(BwdParams p) { render_bwd_body<true, 2>(p); }
-// small frames (fewer tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_color_body<1>(p); }
+__global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_body<4>(p); }
+__global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_geo_body<1>(p); }
 
 // how many waves share one tile in the variant launch_render_backward picks (1, 2 or 4): rows per list entry of the deterministic slab
 int render_backward_waves_per_tile(const ibgs_backward_args& a)
 {
     const int nt = ((a.W + TILE - 1) / TILE) * ((a.H + TILE - 1) / TILE);
-    if (a.render_geo) return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096)) ? 2 : 4;
+    if (a.render_geo) return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096)) ? 1 : 4;
     return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) ? 4 : 1;
 }
 
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
-                           const ImgState& im, const float4* src_rgba, float* slab)
+                           const ImgState& im, const float4* src_rgba, float* slab, float* geo_tab)
 {
     BwdParams p;
     p.ranges = im.ranges; p.point_list = b.point_list; p.rec = reinterpret_cast<const float4*>(g.rec);
@@ -529,11 +590,16 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.depth_pixels = a.out_depth; p.warped_pixels = a.out_warped;
     p.dL_dcolor = a.dL_dcolor; p.dL_dnormal = a.dL_dnormal; p.dL_ddepth = a.dL_ddepth; p.dL_dwarped = a.dL_dwarped;
     p.gacc = a.grad_acc; p.slab = slab;
+    p.slot_c = im.slot_c; p.meta = im.meta; p.tab = geo_tab;
     const int nt = p.ntiles;
     if (a.render_geo) {
-        // geo: half tiles (two quadrants per lane: half the per-Gaussian overhead and reductions) on large frames
-        const bool half = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
-        if (half) hipLaunchKernelGGL(render_bwd_geo2_kernel, dim3(((nt * 2 + 7) / 8) * 8), dim3(64), 0, s, p);
+        // geo: one wave per tile on large frames (measured at C3-geo: 1.61 ms against 1.83 ms with one wave per half tile), one per
+        // 8x8 quadrant on small ones
+        const bool big = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
+        if (!geo_tab) { set_error("geo backward needs the window table scratch"); return -IBGS_ERR_INVALID; }
+        hipLaunchKernelGGL(geo_window_kernel, dim3((unsigned)(((size_t)a.W * a.H + 255) / 256)), dim3(256), 0, s, p);
+        IBGS_HIP(hipGetLastError());
+        if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3(((nt + 7) / 8) * 8), dim3(64), 0, s, p);
         else hipLaunchKernelGGL(render_bwd_geo_kernel, dim3(((nt * 4 + 7) / 8) * 8), dim3(64), 0, s, p);
     } else {
         if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {

@@ -35,7 +35,7 @@ struct FwdParams {
     int n_src; int L; float thr; int tex_quant;
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
-    float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w;
+    float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta;
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
     float* out_min_depth_diff; float* out_camera_ray; int32_t* out_mask;
@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     int resume[PPL]; uint32_t cnt[PPL];
     float rayx[PPL], rayy[PPL];
     const int L = p.L;
+    if (GEO && blockIdx.x == 0 && lane == 0) p.meta[0] = (uint32_t)L;      // the backward's window pass reads the slot count from here
     const int before_cap = (L % 2 == 0) ? (L / 2) : ((L + 1) / 2);
     const int below_cap = L - before_cap;
     if (GEO || DEPTH) {
@@ -324,6 +325,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 #pragma unroll
                 for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (!RING_LDS && k == s) { w = bw[q][k]; c = bc[q][k]; }
                 if (RING_LDS) { w = s_bw[q][s][lane]; c = s_bc[q][s][lane]; }
+                p.slot_c[(size_t)s * HW + pix] = (w == 0.0f) ? 0u : c;      // the backward's window pass starts from these (render_bwd.hip)
                 if (w == 0.0f) continue;
                 {   // depth of buffered contributor c (1-based list position): same expression as the blend loop would use
                     const uint32_t gid = p.point_list[r0 + c - 1u];
@@ -425,7 +427,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.tex_quant = (a.flags & IBGS_FLAG_TEX_QUANT) ? 1 : 0;
     p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
-    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
+    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta;
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;

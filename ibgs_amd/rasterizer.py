@@ -106,8 +106,8 @@ def _stream_key(device):
     return (idx, torch.cuda.current_stream(device).cuda_stream)
 
 
-def _tex(device, nbytes):
-    key = _stream_key(device)
+def _tex(device, nbytes, what="tex"):
+    key = _stream_key(device) + (what,)
     if len(_tex_scratch) > 8 and key not in _tex_scratch:
         _tex_scratch.clear()
     buf = _tex_scratch.get(key)
@@ -153,6 +153,7 @@ def _zero_plane(c, H, W, device, dtype=torch.float32):
 
 class _CModule:
     """Stand-in for the reference's pybind module ``diff_plane_rasterization._C``."""
+    last_tex = None        # packed source RGBA of the most recent geo forward with gradients enabled (picked up by the autograd node)
 
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
@@ -257,7 +258,11 @@ class _CModule:
                         raise RuntimeError("src_images must hold nb_src_images x 3 x H x W values")
                     if sdep_c is None or sdep_c.numel() < int(nb_src_images) * H * W:
                         raise RuntimeError("src_rendered_depths must hold nb_src_images x 1 x H x W values")
-                    tex = _tex(device, lib.ibgs_required_tex(int(nb_src_images), W, H))
+                    # the packed RGBA of the sources: its own buffer when a backward may follow (kept by the autograd node, so that
+                    # ibgs_backward does not pack the same images again), the shared per-stream scratch otherwise
+                    nbytes = lib.ibgs_required_tex(int(nb_src_images), W, H)
+                    tex = torch.empty(nbytes, dtype=torch.uint8, device=device) if torch.is_grad_enabled() else _tex(device, nbytes)
+                    _CModule.last_tex = tex if torch.is_grad_enabled() else None
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
                 a.out_color = out_color.data_ptr() if write_color else None
                 a.radii = radii.data_ptr()
@@ -297,7 +302,7 @@ class _CModule:
                                      src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
                                      dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, render_geo, debug, plane=None):
+                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None):
         """The reference's 34 positional arguments and 10 results; with `plane` (see rasterize_gaussians) two more
         results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1)."""
         lib = _lib.load()
@@ -361,9 +366,16 @@ class _CModule:
                 a.out_depth = _ptr(depth_c); a.out_warped = _ptr(warped_c)
                 a.geom = geomBuffer.data_ptr(); a.binning = binningBuffer.data_ptr() if binningBuffer.numel() else None
                 a.img = imageBuffer.data_ptr()
+                tex_flag = 0
                 if render_geo:
-                    tex = _tex(device, lib.ibgs_required_tex(int(nb_src_images), W, H))
+                    nbytes = lib.ibgs_required_tex(int(nb_src_images), W, H)
+                    if packed_tex is not None and packed_tex.numel() >= nbytes and packed_tex.device == device:
+                        tex, tex_flag = packed_tex, _lib.FLAG_TEX_PACKED          # the forward's buffer: no second pack (T1)
+                    else:
+                        tex = _tex(device, nbytes)
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
+                    tab = _tex(device, lib.ibgs_required_geo_table(W, H), "geo_table")
+                    a.geo_table = tab.data_ptr(); a.geo_table_bytes = tab.numel()
                 a.dL_dcolor = _ptr(g_color); a.dL_dnormal = _ptr(g_normal); a.dL_ddepth = _ptr(g_depth); a.dL_dwarped = _ptr(g_warp)
                 a.grad_acc = grad_acc.data_ptr()
                 a.dL_dmean2D = dL_dmeans2D.data_ptr(); a.dL_dmean2D_abs = dL_dmeans2D_abs.data_ptr()
@@ -379,7 +391,7 @@ class _CModule:
                     a.dL_dplane_normal = _ptr(dL_dplane_normal); a.dL_dplane_offset = _ptr(dL_dplane_offset)
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag())
+                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag() | tex_flag)
                 if DETERMINISTIC and int(R) > 0:
                     det = torch.empty(lib.ibgs_required_deterministic(int(R), P), dtype=torch.uint8, device=device)
                     a.det_scratch = det.data_ptr(); a.det_scratch_bytes = det.numel()
@@ -525,6 +537,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          out_min_depth_diff, out_camera_ray, out_use_first_src_frame, geomBuffer, binningBuffer, imgBuffer) = res
 
         ctx.raster_settings = raster_settings
+        ctx.packed_tex, _CModule.last_tex = _CModule.last_tex, None
         ctx.plane_mode = int(plane_mode) if plane is not None else 0
         ctx.num_rendered = num_rendered
         # outputs that the loss does not touch arrive as None instead of freshly zero-filled planes
@@ -549,6 +562,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         kw = {}
         if ctx.plane_mode:
             kw["plane"] = (plane_normal if plane_normal.numel() else None, plane_offset if plane_offset.numel() else None, ctx.plane_mode)
+        if getattr(ctx, "packed_tex", None) is not None:
+            kw["packed_tex"] = ctx.packed_tex
 
         # argument order of the reference's _C.rasterize_gaussians_backward (reference __init__.py:182-221)
         args = (raster_settings.bg, normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels,

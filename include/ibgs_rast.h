@@ -72,6 +72,8 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                        sequentially in that order (SURVEY 7.2 "alternative without atomics"; replaces the atomicAdds of
                                        backward.cu:673, 770, 793-804).  Gradients are then bit-identical from run to run; they differ from
                                        the default mode only in summation order.  Needs det_scratch.  For CI, ~0.7 ms slower at C3. */
+#define IBGS_FLAG_TEX_PACKED 256u /* ibgs_backward only: `tex` still holds the packed RGBA that the ibgs_forward of this very call pair wrote
+                                     (the caller kept the buffer for the autograd node instead of sharing one scratch): skip the re-pack */
 #define IBGS_FLAG_SH_FACTORED 16u /* ibgs_backward only, view-parallel training: dL/dsh of ONE view is the outer product
                                      basis(dir) x dL/dRGB (backward.cu:114-160), so leave dL_dsh unwritten (may be NULL) and
                                      write the clamp-masked dL/dRGB (P x 3) to dL_dcolors; after the ranks exchanged those
@@ -222,11 +224,15 @@ typedef struct ibgs_backward_args {
     int32_t plane_mode;
     float* dL_dplane_normal;
     float* dL_dplane_offset;
+    /* render_geo: transient scratch of >= ibgs_required_geo_table(W, H) bytes -- the per-pixel table of median / warp terms that
+     * the pixel-parallel window pass leaves for the blend loop (6 words per median buffer slot) */
+    char* geo_table; size_t geo_table_bytes;
     /* IBGS_FLAG_DETERMINISTIC: transient scratch of >= ibgs_required_deterministic(R, P) bytes (slab R x 16 floats + sort buffers) */
     char* det_scratch; size_t det_scratch_bytes;
 } ibgs_backward_args;
 
 size_t ibgs_required_deterministic(int64_t R, int32_t P);
+size_t ibgs_required_geo_table(int32_t W, int32_t H);
 size_t ibgs_required_geom(int32_t P);
 size_t ibgs_required_img(int32_t W, int32_t H);
 size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H);
