@@ -215,7 +215,7 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     torch.cuda.synchronize()
     stages = {k: v[0] / float(n_stage_steps) for k, v in _lib.timing_collect().items()}
     _lib.timing_enable([])
-    return {"dt": dt, "ms_step": dt / steps * 1e3, "median_ms": statistics.median(per_step), "min_ms": min(per_step),
+    return {"dt": dt, "ms_step": dt / steps * 1e3, "median_ms": statistics.median(per_step), "min_ms": min(per_step), "max_ms": max(per_step),
             "kernel_ms": tm[kstage][0] / max(tm[kstage][1], 1), "fwd_ms": fwd_ms, "stages": stages}
 
 
@@ -397,7 +397,7 @@ def main():
         gm = measure(gwl, gwl.local_step, gsteps, 5, 1, n_fwd=5)
         grf = roofline(gwl, gm, "%s geo opacity=%s" % (a.config, a.opacity))
         geo_line = {"workload": gwl.describe(a.opacity, 1, a.exchange), "steps": gsteps, "ms_per_step": gm["ms_step"],
-                    "median_ms_hipevent": gm["median_ms"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
+                    "median_ms_hipevent": gm["median_ms"], "max_ms_hipevent": gm["max_ms"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
                     "num_rendered": int(gwl.R), "stages_ms": gm["stages"], "roofline": grf}
         del gwl
 
@@ -411,7 +411,7 @@ def main():
             "ms_per_step": m["ms_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(a.opacity, world, a.exchange), "num_rendered": int(wl.R), "parallelism": "view-parallel x%d" % world},
-            "median_ms_hipevent": m["median_ms"], "min_ms_hipevent": m["min_ms"],
+            "median_ms_hipevent": m["median_ms"], "min_ms_hipevent": m["min_ms"], "max_ms_hipevent": m["max_ms"],
             "forward_only_ms": m["fwd_ms"],
             "roofline": rf,
             "stages_ms": m["stages"],

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     float pxf[PPL], pyf[PPL];
     bool inside[PPL];
     uint64_t live[PPL];          // wave-uniform lane masks (SGPR pairs): pixels of quadrant q still blending
+    uint64_t recm[PPL];          // geo: ... still feeding their median buffer
     float T[PPL], C[PPL][3];
     uint32_t lastc[PPL];
 #pragma unroll
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         pxf[q] = (float)px[q]; pyf[q] = (float)py[q];
         inside[q] = px[q] < W && py[q] < H;
         live[q] = __builtin_amdgcn_ballot_w64(inside[q]);
+        recm[q] = live[q];
         T[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.f; lastc[q] = 0;
     }
     const float fx = (DEPTH && p.n_views > 1) ? p.fxv[view] : p.cam.fx, fy = (DEPTH && p.n_views > 1) ? p.fyv[view] : p.cam.fy;
@@ -247,14 +249,17 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 const bool acc = __builtin_amdgcn_inverse_ballot_w64(m);
                 const uint32_t contributor = DEPTH ? cnt[q] : (uint32_t)(e + 1);
                 if (!DEPTH) { C[q][0] += q2.x * aT; C[q][1] += q2.y * aT; C[q][2] += q2.z * aT; }
-                if (GEO || DEPTH) {
+                if (GEO) { Nacc[q][0] += q3.x * aT; Nacc[q][1] += q3.y * aT; Nacc[q][2] += q3.z * aT; }
+                // Geo: a pixel feeds its median buffer only until T has dropped to 0.5 AND the "below" half is full -- a handful of
+                // contributors; `recm` (an SGPR lane mask like `live`) holds the pixels of the quadrant that still record, and once
+                // none of the lanes that blend this Gaussian does, the whole buffer block is skipped (most of a tile's list).
+                if ((GEO && (m & recm[q]) != 0ull) || DEPTH) {
                     // ray/plane depth = -dist / denom (forward.cu:439-442).  The geo pass only needs its SIGN inside the
                     // loop (the "depth > 0" gate); the value is recomputed in the epilogue for the <= L buffered entries,
                     // so neither the division nor a depth ring lives in the hot loop.
                     const float denom = q3.x * rayx[q] + q3.y * rayy[q] + q3.z + eps;
                     float dep = 0.f;
                     if (DEPTH) dep = -q1.w / denom;
-                    if (GEO) { Nacc[q][0] += q3.x * aT; Nacc[q][1] += q3.y * aT; Nacc[q][2] += q3.z * aT; }
                     const bool pos = DEPTH ? (dep > 0.0f) : (q1.w * denom < 0.0f);       // sign of -dist / denom (|dist * denom| cannot underflow: |denom| >= 1e-8)
                     const bool hit = acc && pos;
                     const bool front = T[q] > 0.5f;
@@ -287,6 +292,8 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                         // internal final_T / n_contrib of a depth-only pass differ, its output does not.
                         live[q] &= ~__builtin_amdgcn_ballot_w64(hit && below_count[q] == below_cap);
                     }
+                    // T only falls and the below-half only fills: a pixel that has both never records again
+                    if (GEO) recm[q] &= ~__builtin_amdgcn_ballot_w64(test_T <= 0.5f && below_count[q] >= below_cap);
                 }
                 T[q] = test_T;
                 lastc[q] = acc ? contributor : lastc[q];
