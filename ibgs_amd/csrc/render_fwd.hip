@@ -206,6 +206,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             if constexpr (GEO) q3 = s_rec[3][j];          // normal
             const int e = base + j;
             const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
+            // 1-based list position as ONE vector register per Gaussian (opaque to the optimiser, which otherwise re-materialises
+            // the scalar -> vector move inside every quadrant's branch)
+            uint32_t e1v = (uint32_t)(e + 1);
+            asm volatile("" : "+v"(e1v));
             // p2 = d^T conic d = -2 * power.  With 4 pixels per lane the quadratic form is evaluated once for the
             // lane's pixel in quadrant 0 and shifted to the other three (pixel offsets (8,0), (0,8), (8,8)):
             // p2(d - s) = p2(d) - 2 s^T conic d + s^T conic s -- 14 VALU ops for four pixels instead of 32.
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     m &= ~fin;
                 }
                 const bool acc = __builtin_amdgcn_inverse_ballot_w64(m);
-                const uint32_t contributor = DEPTH ? cnt[q] : (uint32_t)(e + 1);
+                const uint32_t contributor = DEPTH ? cnt[q] : e1v;
                 if (!DEPTH) { C[q][0] += q2.x * aT; C[q][1] += q2.y * aT; C[q][2] += q2.z * aT; }
                 if (GEO) { Nacc[q][0] += q3.x * aT; Nacc[q][1] += q3.y * aT; Nacc[q][2] += q3.z * aT; }
                 // Geo: a pixel feeds its median buffer only until T has dropped to 0.5 AND the "below" half is full -- a handful of
