@@ -54,7 +54,7 @@ def test_two_runs_are_bit_identical_and_match_the_atomic_mode(geo, shape):
         ref = oracle.forward(inp, cull=True)
         rb = oracle.backward(inp, ref, gr["color"], gr.get("normal_map"), gr.get("median_depth"), gr.get("warped_image"))
         for k, rk in (("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("shs", "dL_dsh"), ("scales", "dL_dscales")):
-            assert rel_l2(a[k].cpu().numpy().reshape(rb[rk].shape), rb[rk]) < (5e-3 if geo else 1e-3), k
+            assert rel_l2(a[k].cpu().numpy().reshape(rb[rk].shape), rb[rk]) < 1e-3, k
     finally:
         rasterizer.WAVE_SHAPE = old
 

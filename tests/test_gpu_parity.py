@@ -28,6 +28,7 @@ def wave_shape(request):
 
 L1_TOL = 1e-4          # north_star: forward renders within 1e-4 L1 per pixel
 GRAD_TOL = 1e-3        # gradient relative L2 <= 1e-3
+GEO_GRAD_TOL = 1e-3    # ... also with the median / warp terms in the loss (round 1 accepted 5e-3 here)
 
 
 from tests.scenes import scene, add_sources  # noqa: E402,F401  (seeded scenes shared with the fixture generators)
@@ -155,7 +156,7 @@ def test_tile_culling_changes_no_result(opacity):
     assert ist["R"] == culled["num_rendered"]
     assert l1(o["color"], full["color"]) < 1e-6 and np.array_equal(o["radii"], full["radii"])
     assert l1(o["normal_map"], full["normal_map"]) < 1e-6
-    check_grads(leaves, gfull, tol=5e-3)
+    check_grads(leaves, gfull, tol=GEO_GRAD_TOL)
 
 
 def test_mid_size_rectangles_are_culled_by_the_whole_wave():
@@ -238,7 +239,7 @@ def test_geo_path_forward_backward(L, n_src):
         scale = np.abs(ref[k][:, ok]).mean() + 1e-9
         assert d.mean() / scale < tol, "%s: mean rel err %.3e" % (k, d.mean() / scale)
     assert np.array_equal(o["use_first_src_frame_mask"][0][ok], ref["use_first_src_frame_mask"][0][ok])
-    check_grads(leaves, gb, tol=5e-3)               # the median/warp terms divide by small buffer weights
+    check_grads(leaves, gb, tol=GEO_GRAD_TOL)       # see GEO_GRAD_TOL
 
 
 def test_geo_path_texture_weight_quantisation_switch():
