@@ -117,6 +117,28 @@ def _tex(device, nbytes, what="tex"):
     return buf
 
 
+_tex_writes = [0]
+
+
+def _tex_packed(device, nbytes):
+    """The per-stream scratch that receives the packed source RGBA (T1), plus a ticket that names this pack: a later call that
+    holds the ticket and finds it still current (`_tex_still(ticket)`) knows that nothing overwrote the buffer in between."""
+    buf = _tex(device, nbytes)
+    _tex_writes[0] += 1
+    buf._ibgs_ticket = _tex_writes[0]
+    return buf, (_stream_key(device) + ("tex",), _tex_writes[0], nbytes)
+
+
+def _tex_still(ticket, device, nbytes):
+    if ticket is None:
+        return None
+    key, serial, had = ticket
+    buf = _tex_scratch.get(key)
+    if buf is None or key != _stream_key(device) + ("tex",) or had < nbytes or getattr(buf, "_ibgs_ticket", None) != serial:
+        return None
+    return buf
+
+
 def _gacc(device, P):
     key = _stream_key(device) + (P,)
     ent = _gacc_scratch.get(key)
@@ -153,7 +175,7 @@ def _zero_plane(c, H, W, device, dtype=torch.float32):
 
 class _CModule:
     """Stand-in for the reference's pybind module ``diff_plane_rasterization._C``."""
-    last_tex = None        # packed source RGBA of the most recent geo forward with gradients enabled (picked up by the autograd node)
+    last_tex = None        # ticket of the most recent pack of source RGBA (picked up by the autograd node)
 
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
@@ -258,11 +280,10 @@ class _CModule:
                         raise RuntimeError("src_images must hold nb_src_images x 3 x H x W values")
                     if sdep_c is None or sdep_c.numel() < int(nb_src_images) * H * W:
                         raise RuntimeError("src_rendered_depths must hold nb_src_images x 1 x H x W values")
-                    # the packed RGBA of the sources: its own buffer when a backward may follow (kept by the autograd node, so that
-                    # ibgs_backward does not pack the same images again), the shared per-stream scratch otherwise
+                    # the packed RGBA of the sources goes to the per-stream scratch; the ticket lets the backward of this call
+                    # skip its own pack when no other geo call used the scratch in between (the training loop's normal case)
                     nbytes = lib.ibgs_required_tex(int(nb_src_images), W, H)
-                    tex = torch.empty(nbytes, dtype=torch.uint8, device=device) if torch.is_grad_enabled() else _tex(device, nbytes)
-                    _CModule.last_tex = tex if torch.is_grad_enabled() else None
+                    tex, _CModule.last_tex = _tex_packed(device, nbytes)
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
                 a.out_color = out_color.data_ptr() if write_color else None
                 a.radii = radii.data_ptr()
@@ -369,10 +390,11 @@ class _CModule:
                 tex_flag = 0
                 if render_geo:
                     nbytes = lib.ibgs_required_tex(int(nb_src_images), W, H)
-                    if packed_tex is not None and packed_tex.numel() >= nbytes and packed_tex.device == device:
-                        tex, tex_flag = packed_tex, _lib.FLAG_TEX_PACKED          # the forward's buffer: no second pack (T1)
+                    tex = _tex_still(packed_tex, device, nbytes)
+                    if tex is not None:
+                        tex_flag = _lib.FLAG_TEX_PACKED          # still the forward's pack of the same images: no second pack (T1)
                     else:
-                        tex = _tex(device, nbytes)
+                        tex, _ = _tex_packed(device, nbytes)
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
                     tab = _tex(device, lib.ibgs_required_geo_table(W, H), "geo_table")
                     a.geo_table = tab.data_ptr(); a.geo_table_bytes = tab.numel()

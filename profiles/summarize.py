@@ -63,7 +63,7 @@ def main():
             per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = {}
     for k, v in per_kernel.items():
-        if not any(s in k for s in ("render_", "preprocess", "radix_", "emit", "scan_", "ranges")):
+        if not any(s in k for s in ("render_", "preprocess", "radix_", "onesweep", "emit", "scan", "ranges", "expand_", "cell_", "gather_", "geo_window", "pack_rgba")):
             continue
         counters[k] = {c: sum(x) / len(x) for c, x in v.items()}      # mean per launch
     out["per_launch_counters"] = counters

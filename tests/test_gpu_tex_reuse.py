@@ -1,0 +1,58 @@
+"""T1 (rasterizer_impl.cu:34-148): the reference packs the source images into textures in the forward AND again in the
+backward of every geo call.  Here the backward reuses the forward's pack when nothing else used the per-stream scratch in
+between, and packs again when something did.  Both cases must give the gradients of an isolated forward + backward."""
+import numpy as np
+import pytest
+import torch
+
+from ibgs_amd import rasterizer, renderer, simple_scene
+from tests.metrics import rel_l2
+from tests.test_gpu_fused_planes import _scene
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc")
+
+
+def _forward(view, g, dev, cams, scene, pipe, args, bg):
+    pc = simple_scene.SimpleGaussians(g, sh_degree=2, device=dev)
+    out = renderer.render(cams[view], pc, scene, pipe, args, bg, learnt_normal=False, nb_src_frames=3, buffer_length=4,
+                          render_geo=True, return_depth_normal=False)
+    gen = torch.Generator(device=dev).manual_seed(11 + view)
+    loss = (out["warped_image"] * torch.randn(out["warped_image"].shape, device=dev, generator=gen)).sum() + out["render"].sum()
+    return pc, loss
+
+
+def _grads(pc):
+    return {n: getattr(pc, n).grad.detach().cpu().numpy() for n in NAMES}
+
+
+def test_backward_reuses_or_repacks_the_source_rgba():
+    dev, g, cams, scene, pipe, args, bg = _scene()
+    with torch.no_grad():
+        pc0 = simple_scene.SimpleGaussians(g, sh_degree=2, device=dev)
+        for j in sorted(set(cams[0].nearest_id) | set(cams[1].nearest_id)):
+            scene.rendered_depth_list[j] = renderer.render_depth(cams[j], pc0, scene, pipe, args, bg, True, 3, 4)
+    assert list(cams[0].nearest_id) != list(cams[1].nearest_id)
+
+    alone = {}
+    for v in (0, 1):
+        pc, loss = _forward(v, g, dev, cams, scene, pipe, args, bg)
+        before = rasterizer._tex_writes[0]
+        loss.backward()
+        assert rasterizer._tex_writes[0] == before, "an isolated backward must not pack again"
+        alone[v] = _grads(pc)
+
+    # two forwards, then the two backwards: view 0's pack was overwritten by view 1's forward
+    pc_a, loss_a = _forward(0, g, dev, cams, scene, pipe, args, bg)
+    pc_b, loss_b = _forward(1, g, dev, cams, scene, pipe, args, bg)
+    before = rasterizer._tex_writes[0]
+    loss_a.backward()
+    assert rasterizer._tex_writes[0] == before + 1, "view 0's backward has to pack its own sources again"
+    loss_b.backward()                                  # ... which overwrote view 1's pack in turn
+    assert rasterizer._tex_writes[0] == before + 2
+    for v, pc in ((0, pc_a), (1, pc_b)):
+        got = _grads(pc)
+        for n in NAMES:
+            assert np.abs(alone[v][n]).sum() > 0, n
+            assert rel_l2(got[n], alone[v][n]) < 1e-5, (v, n, rel_l2(got[n], alone[v][n]))
