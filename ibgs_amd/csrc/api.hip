@@ -42,14 +42,13 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.depths = c.take<float>(P);
     g.cov3D = c.take<float>(P * 6);
     g.tiles = c.take<uint32_t>(P);
-    g.tc = c.take<uint32_t>(P);
-    g.rect = c.take<uint32_t>(P * 2);
-    g.tmask = c.take<uint64_t>(P * IBGS_CULL_WORDS);
+    g.fp = c.take<uint4>(P);
+    g.tmask_hi = c.take<uint64_t>(P * (IBGS_CULL_WORDS - 1));
+    g.fp_sorted = c.take<uint4>(P);
     g.clamped = c.take<uint8_t>(P);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
     g.offsets = c.take<uint32_t>(P + 3);
-    g.coffs = c.take<uint32_t>(P + 1);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -85,18 +84,18 @@ BinState BinState::carve(char* base, size_t R, int W, int H, size_t* total)
     // whether the forward carved the arena for the exact R or for a larger rendered_hint.
     b.point_list = c.take<uint32_t>(R);
     b.ccap = R;                                     // a coarse entry stands for at least one tile entry: C <= R
-    b.cid = c.take<uint32_t>(R);
-    b.cmask = c.take<uint64_t>(R);
-    b.ckeys[0] = c.take<uint32_t>(R); b.ckeys[1] = c.take<uint32_t>(R);
-    b.cvals[0] = c.take<uint32_t>(R); b.cvals[1] = c.take<uint32_t>(R);
+    b.cent = c.take<uint4>(R);
+    // count matrix of the placement (binning.hip): one column per block of >= 256 depth ranks.  Its share of the arena follows R,
+    // the only size this function knows; the launcher makes the blocks larger when P / 256 columns do not fit
+    b.cnt_elems = (R / 4 > (size_t)65536 ? R / 4 : (size_t)65536) + ncells;
+    b.cnt = c.take<uint32_t>(b.cnt_elems);
+    b.cell_total = c.take<uint32_t>(ncells);
     b.cell_start = c.take<uint32_t>(ncells + 1);
     b.cell_chunk0 = c.take<uint32_t>(ncells + 1);
     b.chunk_cnt = c.take<uint32_t>((R / BIN_XCHUNK + ncells + 1) * 64);
     b.tile_total = c.take<uint32_t>(ntiles + 1);
     b.scan_elems = scan_scratch_elems(ntiles + 1);
     b.scan_scratch = c.take<uint32_t>(b.scan_elems);
-    b.hist_elems = radix_hist_elems(R);
-    b.hist = c.take<uint32_t>(b.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return b;
 }
@@ -174,7 +173,7 @@ size_t ibgs_required_geo_table(int32_t W, int32_t H) { return geo_table_floats(W
 int64_t ibgs_geom_offset(int32_t P, const char* name)
 {
     size_t t; GeomState g = GeomState::carve(nullptr, (size_t)P, &t);
-    OFF(g, rec); OFF(g, depths); OFF(g, cov3D); OFF(g, tiles); OFF(g, rect); OFF(g, tmask); OFF(g, clamped); OFF(g, offsets);
+    OFF(g, rec); OFF(g, depths); OFF(g, cov3D); OFF(g, tiles); OFF(g, fp); OFF(g, tmask_hi); OFF(g, clamped); OFF(g, offsets);
     if (!strcmp(name, "order")) return (int64_t)((char*)g.sort_val[0] - (char*)nullptr);
     if (!strcmp(name, "sorted_depth_keys")) return (int64_t)((char*)g.sort_key[0] - (char*)nullptr);
     return -1;
@@ -277,9 +276,8 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     //    error flag only after everything is queued: the GPU never idles on the round trip and one scan less runs.
     const bool deferred = a.rendered_hint > 0 && !debug;
     { StageTimer t(s, IBGS_STAGE_SCAN);
-      if ((rc = launch_gather_tiles(s, Pn, g, !deferred))) return rc;
-      if (!deferred && (rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
-      if ((rc = exclusive_scan_u32(s, g.coffs, g.coffs, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
+      // (the total does not depend on the order: the per-Gaussian counts are scanned as they lie)
+      if (!deferred && (rc = exclusive_scan_u32(s, g.tiles, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
     auto exact_R = [&](int64_t* R_out) -> int {       // synchronous path: R from the scanned tile counts
@@ -299,15 +297,14 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, Hn), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
-        int cur;
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((cur = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges)) < 0) return cur; }
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges))) return rc; }
         if (read_back) {
             // R as the binning counted it, the depth sort's error flag, the coarse slots in use: adjacent words, one copy, queued
             // HERE so that the host is served while the list scatter and the render still run
             IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             IBGS_HIP(hipEventRecord(rs->ev, s));
         }
-        { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b, cur))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b))) return rc; }
         if ((rc = stage_check(s, debug, "binning"))) return rc;
         const float4* rgba = nullptr;
         if (a.render_geo) {
@@ -330,9 +327,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
             if (coarse_overflow) {
-                if ((rc = launch_gather_tiles(s, Pn, g, true))) return rc;          // (rewrites coffs' input too: scan it again)
-                if ((rc = exclusive_scan_u32(s, g.offsets, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
-                if ((rc = exclusive_scan_u32(s, g.coffs, g.coffs, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
+                if ((rc = exclusive_scan_u32(s, g.tiles, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
                 if ((rc = exact_R(&R))) return rc;
             }
             if ((rc = tail(R, false))) return rc;

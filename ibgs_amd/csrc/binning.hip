@@ -1,160 +1,241 @@
 // A3-A5: per-tile lists (duplicate emission, tile sort, tile ranges) by TWO-LEVEL binning.
 //
 // The reference emits one 64-bit (tile, depth) key per (Gaussian, tile) pair and sorts all R of them with a 6-pass radix sort
-// (DPR/cuda_rasterizer/rasterizer_impl.cu:187-228, 449-457).  Round 1 here sorted the P Gaussians by depth first and the R
-// duplicates by tile id only (2 x 7-bit passes over R).  This round the R-sized sort is gone:
+// (DPR/cuda_rasterizer/rasterizer_impl.cu:187-228, 449-457).  Here the P Gaussians are sorted by depth first (scan_sort.hip) and no
+// R-sized (nor any other) key array exists after that:
 //
-//   1. coarse cells of 8 x 8 tiles: every Gaussian (in depth order) emits ONE entry per cell that holds at least one of its
-//      surviving tiles -- (cell id, entry index) plus the 64-bit mask of its tiles inside the cell.  C3: 2.6 M entries
-//      instead of 12.4 M;
-//   2. the coarse entries are stably sorted by cell id (one 8-bit pass for a 1080p frame): every cell now holds its Gaussians
-//      in depth order;
-//   3. each cell is cut into chunks of 256 entries (one wave each).  A first kernel counts, per chunk, how many entries touch
-//      each of the cell's 64 tiles; one wave per cell turns the counts into prefixes within the cell and per-tile totals; a
-//      scan over the tiles (in global row-major order) gives every tile's range -- `ranges` falls out, no key array, no
-//      range-finding pass;
-//   4. a second kernel walks each chunk in order and writes the Gaussian ids to their final slots: for tile t the lanes whose
-//      mask has bit t form a ballot; slot = start of the tile + prefix of the chunk + number of earlier lanes in the ballot.
-//      Entry order inside a tile = order inside the cell = depth order, ties by Gaussian index.
+//   1. coarse cells of 8 x 8 tiles: a Gaussian has ONE coarse entry per cell that holds at least one of its surviving tiles --
+//      (Gaussian id, 64-bit mask of its tiles inside the cell).  C3: 2.6 M entries instead of 12.4 M;
+//   2. the entries are PLACED, cell by cell and in depth order inside a cell, by a counting sort over the cells whose digits are
+//      recomputed from the Gaussian's rectangle and tile mask (count per block of depth ranks -> scan per cell -> place; below);
+//   3. each cell is cut into chunks of 256 entries (one wave each, 4 rounds of 64).  A round is a 64 x 64 bit matrix, row =
+//      entry, column = tile of the cell; the wave TRANSPOSES it in registers (wave_bits.h) so that lane t holds which entries
+//      go to tile t.  A first kernel counts those bits per chunk; one wave per cell turns the counts into prefixes within the
+//      cell and per-tile totals; a scan over the tiles (in global row-major order) gives every tile's range -- `ranges` falls
+//      out, no key array, no range-finding pass;
+//   4. a second kernel walks each chunk in order and writes the Gaussian ids to their final slots: an entry lane walks the set
+//      bits of its mask; slot = start of the tile + prefix of the chunk + entries of earlier rounds + number of earlier lanes
+//      in the tile's column.  Entry order inside a tile = order inside the cell = depth order, ties by Gaussian index
+//      (SURVEY.md Q9).
 //
 // The lists are bit-identical to the ones a stable sort of (tile, depth-rank) keys produces (= the reference's lists, restricted
 // to the tiles the exact cull keeps); tests compare them with the oracle entry by entry.
 #include "common.h"
+#include "wave_bits.h"
 
 namespace ibgs {
 
 constexpr int CB = BIN_CELL;            // tiles per cell edge (8)
 constexpr int XCHUNK = BIN_XCHUNK;      // coarse entries per expansion chunk = 4 rounds of one wave
 
-// up to 8 bits of a <= 256-bit row-major tile mask, starting at bit `start`
-__device__ __forceinline__ uint32_t mask_bits(const uint64_t* __restrict__ mw, uint32_t start, uint32_t len)
+// A Gaussian's rectangle and tile mask, loaded once into registers (the mask words beyond the first only exist for rectangles of
+// more than 64 tiles, preprocess.hip)
+struct RectU { uint32_t x0, x1, y0, y1; };
+struct Footprint { RectU r; uint64_t m[IBGS_CULL_WORDS]; bool masked; };
+__device__ __forceinline__ Footprint make_footprint(const uint4 rr, const uint64_t* __restrict__ tmask_hi, uint32_t id)
+{
+    Footprint f;
+    f.r = RectU{rr.x & 0xFFFFu, rr.x >> 16, rr.y & 0xFFFFu, rr.y >> 16};
+    const uint32_t area = (f.r.x1 - f.r.x0) * (f.r.y1 - f.r.y0);
+    f.masked = area <= (uint32_t)IBGS_CULL_MAX_TILES;            // larger rectangles keep every tile (preprocess.hip)
+    f.m[0] = ((uint64_t)rr.w << 32) | rr.z;
+    const uint64_t* mw = tmask_hi + (size_t)id * (IBGS_CULL_WORDS - 1);
+#pragma unroll
+    for (int k = 1; k < IBGS_CULL_WORDS; k++) f.m[k] = (f.masked && area > 64u * (uint32_t)k) ? mw[k - 1] : 0ull;
+    return f;
+}
+
+// up to 8 bits of the row-major tile mask, starting at bit `start`
+__device__ __forceinline__ uint32_t mask_bits(const Footprint& f, uint32_t start, uint32_t len)
 {
     const uint32_t w = start >> 6, o = start & 63u;
-    uint64_t v = mw[w] >> o;
-    if (o + len > 64u) v |= mw[w + 1] << (64u - o);        // only reached for masks of more than one word
+    static_assert(IBGS_CULL_WORDS == 4, "word select below");
+    const uint64_t lo = w == 0 ? f.m[0] : (w == 1 ? f.m[1] : (w == 2 ? f.m[2] : f.m[3]));
+    const uint64_t hi = w == 0 ? f.m[1] : (w == 1 ? f.m[2] : f.m[3]);          // (only used when the run crosses into the next word)
+    uint64_t v = lo >> o;
+    if (o + len > 64u) v |= hi << (64u - o);
     return (uint32_t)v & ((1u << len) - 1u);
 }
 
-struct RectU { uint32_t x0, x1, y0, y1; };
-__device__ __forceinline__ RectU load_rect(const uint32_t* __restrict__ rect, uint32_t id)
-{
-    const uint32_t rx = rect[2 * id], ry = rect[2 * id + 1];
-    return RectU{rx & 0xFFFFu, rx >> 16, ry & 0xFFFFu, ry >> 16};
-}
-
 // surviving tiles of one Gaussian inside cell (ccx, ccy): bit ly * 8 + lx for tile (8 ccx + lx, 8 ccy + ly)
-__device__ __forceinline__ uint64_t cell_mask(const RectU& r, const uint64_t* __restrict__ mw, uint32_t ccx, uint32_t ccy)
+__device__ __forceinline__ uint64_t cell_mask(const Footprint& f, uint32_t ccx, uint32_t ccy)
 {
+    const RectU& r = f.r;
     const uint32_t cx0 = ccx * CB, cy0 = ccy * CB;
     const uint32_t xa = max(r.x0, cx0), xb = min(r.x1, cx0 + CB), ya = max(r.y0, cy0), yb = min(r.y1, cy0 + CB);
     if (xa >= xb || ya >= yb) return 0ull;
     const uint32_t w = r.x1 - r.x0;
-    const bool masked = w * (r.y1 - r.y0) <= (uint32_t)IBGS_CULL_MAX_TILES;       // larger rectangles keep every tile (preprocess.hip)
     const uint32_t len = xb - xa;
     uint64_t m = 0ull;
     for (uint32_t ty = ya; ty < yb; ty++) {
-        const uint32_t bits = masked ? mask_bits(mw, (ty - r.y0) * w + (xa - r.x0), len) : ((1u << len) - 1u);
+        const uint32_t bits = f.masked ? mask_bits(f, (ty - r.y0) * w + (xa - r.x0), len) : ((1u << len) - 1u);
         m |= (uint64_t)bits << ((ty - cy0) * CB + (xa - cx0));
     }
     return m;
 }
 
-// Per depth rank j: tiles touched (for R, only when the host needs it before the binning) and the number of coarse slots the
-// Gaussian gets: min(cells of its rectangle, surviving tiles) >= its non-empty cells, so C <= R always holds (arena sizing).
-__global__ void __launch_bounds__(256) gather_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tc,
-                                                           uint32_t* __restrict__ out_tiles /* may be null */, uint32_t* __restrict__ out_cells)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P) return;
-    const uint32_t v = tc[order[j]];
-    const uint32_t nt = v & 0x3FFFFu, nc = v >> 18;
-    if (out_tiles) out_tiles[j] = nt;
-    out_cells[j] = min(nt, nc);
-}
+// ---- cells in depth order by DIRECT PLACEMENT ------------------------------------------------------------------------------------
+// What a stable sort of (cell, depth rank) keys would produce, without materialising keys: a counting sort whose digits (the cells
+// a Gaussian reaches) are recomputed from the Gaussian's rectangle and tile mask instead of being read from an array.
+//   cell_count_kernel   one workgroup per block of G consecutive depth ranks: entries per cell (LDS histogram) -> cnt[cell][block]
+//   cell_colscan_kernel one workgroup per cell: exclusive scan over the blocks, in place; the cell's total
+//   cell_setup_kernel   one workgroup: first entry of every cell, chunk bookkeeping, C (the number of coarse entries)
+//   cell_place_kernel   same traversal as the count; an entry's slot = first entry of its cell + entries of earlier blocks + entries
+//                       of earlier ranks in its own block.  The last term: per batch of 64 ranks (a wave, lane = rank) every cell
+//                       collects the lanes that reach it as a 64-bit word in LDS (ds_or); rank inside the batch = set bits below
+//                       the own lane, plus the words of the block's earlier waves.
+// Cells are handled in slices of at most PLACE_MAX_CELLS (LDS tables); one slice covers a 4K frame.
+constexpr int PLACE_THREADS = 256;       // four waves, one batch of 64 consecutive depth ranks each per round
+constexpr int PLACE_MAX_CELLS = 1024;
 
-int launch_gather_tiles(hipStream_t s, int P, const GeomState& g, bool want_tiles)
-{
-    hipLaunchKernelGGL(gather_tiles_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.sort_val[0], g.tc, want_tiles ? g.offsets : nullptr, g.coffs);
-    IBGS_HIP(hipGetLastError());
-    return 0;
-}
+struct PlaceGeom { int P, G, nblk, cgx; int c0, nc; };            // G = depth ranks per block (a multiple of 256); cells [c0, c0 + nc) in this launch
 
-// Four lanes per depth rank: lane c looks at cells c, c + 4, ... of the Gaussian's rectangle (row-major); the cells that hold a
-// surviving tile are packed into the Gaussian's slots [coffs[j], coffs[j + 1]) (rank inside the group of four from a ballot), the
-// slots that stay free become NULL entries (key = ncells: sorted behind every real cell and ignored).
-__global__ void __launch_bounds__(256) coarse_emit_kernel(int P, uint32_t ccap, int cgx, uint32_t null_key, const uint32_t* __restrict__ order,
-                                                          const uint32_t* __restrict__ coffs, const uint32_t* __restrict__ rect,
-                                                          const uint64_t* __restrict__ tmask,
-                                                          uint32_t* __restrict__ ckeys, uint32_t* __restrict__ cvals,
-                                                          uint32_t* __restrict__ cid, uint64_t* __restrict__ cmask)
+// calls f(cell, mask) for every cell of the slice that holds a surviving tile of the Gaussian
+template <typename F>
+__device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& fp, F f)
 {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = min(gid >> 2, P - 1);               // every lane stays in the ballots below
-    const bool live = (gid >> 2) < P;
-    const uint32_t e0 = coffs[j], e1 = coffs[j + 1];
-    // e1 > ccap: the arena was carved for a too small hint and the call is redone (api.hip); until then every slot below the
-    // capacity must still hold a well-formed (null) entry, the sort reads them all
-    const bool fits = e1 <= ccap;
-    const bool work = live && e1 != e0 && fits;
-    const uint32_t id = order[j];
-    const RectU r = load_rect(rect, id);
-    const uint64_t* mw = tmask + (size_t)id * IBGS_CULL_WORDS;
-    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, ncx = work ? (r.x1 - 1) / CB - c0x + 1 : 1u;
-    const uint32_t ncell = work ? ncx * ((r.y1 - 1) / CB - c0y + 1) : 0u;
-    const int c = gid & 3, qshift = (int)(threadIdx.x & 63) & ~3;
-    uint32_t filled = 0;
-    // the four lanes of a Gaussian run the same number of rounds; the wave runs the maximum
-    uint32_t nr = (ncell + 3) / 4;
-    for (int d = 32; d >= 1; d >>= 1) nr = max(nr, (uint32_t)__shfl_xor((int)nr, d, 64));
-    for (uint32_t rd = 0; rd < nr; rd++) {
-        const uint32_t k = rd * 4 + (uint32_t)c;
-        uint64_t m = 0ull; uint32_t cell = 0;
-        if (k < ncell) {
-            const uint32_t row = k / ncx, cx = c0x + (k - row * ncx), cy = c0y + row;
-            m = cell_mask(r, mw, cx, cy);
-            cell = cy * (uint32_t)cgx + cx;
-        }
-        const uint32_t qb = (uint32_t)(__builtin_amdgcn_ballot_w64(m != 0ull) >> qshift) & 0xFu;
-        if (m != 0ull) {
-            const uint32_t e = e0 + filled + (uint32_t)__popc(qb & ((1u << c) - 1u));
-            ckeys[e] = cell; cvals[e] = e; cid[e] = id; cmask[e] = m;
-        }
-        filled += (uint32_t)__popc(qb);
+    const RectU& r = fp.r;
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return;                 // culled: no tiles
+    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
+    const uint32_t w = r.x1 - r.x0, h = r.y1 - r.y0;
+    if (w <= (uint32_t)CB && h <= (uint32_t)CB) {
+        // the common case, a rectangle of at most 8 x 8 tiles (its whole mask is word 0): spread the rows to a stride of 8 once; the
+        // part inside a cell is then that image shifted by the rectangle's offset from the cell, columns that wrap masked off
+        uint64_t img = 0ull;
+        const uint64_t rowm = (1ull << w) - 1ull;
+        for (uint32_t i = 0; i < h; i++) img |= ((fp.m[0] >> (i * w)) & rowm) << (8u * i);
+        for (uint32_t cy = c0y; cy <= c1y; cy++)
+            for (uint32_t cx = c0x; cx <= c1x; cx++) {
+                const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+                if (cell < 0 || cell >= pg.nc) continue;
+                const int dx = (int)r.x0 - (int)(cx * CB), dy = (int)r.y0 - (int)(cy * CB);          // both in (-8, 8)
+                uint64_t m = dx >= 0 ? (img << dx) & (0x0101010101010101ull * (uint64_t)((0xFFu << dx) & 0xFFu))
+                                     : (img >> (-dx)) & (0x0101010101010101ull * (uint64_t)(0xFFu >> (-dx)));
+                m = dy >= 0 ? m << (8 * dy) : m >> (8 * (-dy));
+                if (m != 0ull) f(cell, m);
+            }
+        return;
     }
-    if (live)
-        for (uint32_t e = e0 + filled + (uint32_t)c; e < min(e1, ccap); e += 4) { ckeys[e] = null_key; cvals[e] = e; cid[e] = id; cmask[e] = 0ull; }
+    for (uint32_t cy = c0y; cy <= c1y; cy++)
+        for (uint32_t cx = c0x; cx <= c1x; cx++) {
+            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+            if (cell < 0 || cell >= pg.nc) continue;
+            const uint64_t m = cell_mask(fp, cx, cy);
+            if (m != 0ull) f(cell, m);
+        }
 }
 
-// First sorted entry of every cell + chunk bookkeeping, ONE workgroup (ncells <= a few thousand).  After a ONE-pass sort the
-// scanned radix histogram already holds the answer: hist[digit * nblocks] = number of keys with a smaller digit.
-__global__ void __launch_bounds__(256) cell_setup_kernel(const uint32_t* __restrict__ C_dev, uint32_t ccap, const uint32_t* __restrict__ sorted_cells,
-                                                         const uint32_t* __restrict__ hist, unsigned hist_stride /* 0: search instead */,
-                                                         int ncells, uint32_t* __restrict__ cell_start /* ncells + 1 */,
-                                                         uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */)
+__global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys,
+                                                                   const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi,
+                                                                   uint4* __restrict__ fp_sorted /* the footprints in depth order, for the place kernel */,
+                                                                   uint32_t* __restrict__ cnt /* ncells x nblk */)
 {
-    __shared__ uint32_t s_part[256];
-    const uint32_t C = min(*C_dev, ccap);
-    for (int c = threadIdx.x; c <= ncells; c += 256) {
-        uint32_t lo = 0;
-        if (hist_stride) lo = min(hist[(size_t)c * hist_stride], C);
-        else {      // first sorted entry with cell id >= c (the list is sorted by cell id, null entries last)
-            uint32_t hi = C;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_cells[mid] < (uint32_t)c) lo = mid + 1; else hi = mid; }
-        }
-        cell_start[c] = lo;
+    extern __shared__ uint32_t s_cnt[];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    for (int c = tid; c < pg.nc; c += PLACE_THREADS) s_cnt[c] = 0u;
+    __syncthreads();
+    const int j1 = min(pg.P, (blk + 1) * pg.G);
+    for (int j = blk * pg.G + tid; j < j1; j += PLACE_THREADS) {
+        if (keys[j] == 0xFFFFFFFFu) continue;                  // no tiles (culled): these sort last, whole blocks of them cost one load
+        const uint32_t id = order[j];
+        const uint4 rec = fpr[id];                             // the one random 16-byte gather per Gaussian of the binning stage
+        if (pg.c0 == 0) fp_sorted[j] = rec;
+        const Footprint fp = make_footprint(rec, tmask_hi, id);
+        for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
     }
     __syncthreads();
-    // exclusive scan of chunks per cell (sequential per thread over a strip, then over the 256 strip sums)
+    for (int c = tid; c < pg.nc; c += PLACE_THREADS) cnt[(size_t)(pg.c0 + c) * pg.nblk + blk] = s_cnt[c];
+}
+
+__global__ void __launch_bounds__(256) cell_colscan_kernel(int nblk, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cell_total)
+{
+    __shared__ uint32_t s_part[256];
+    uint32_t* row = cnt + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + 255) / 256;
+    const int b0 = min(nblk, (int)threadIdx.x * per), b1 = min(nblk, b0 + per);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; b++) sum += row[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    // inclusive scan of the 256 strip sums (Hillis-Steele in LDS)
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; b++) { const uint32_t v = row[b]; row[b] = run; run += v; }
+    if (threadIdx.x == 255) cell_total[blockIdx.x] = s_part[255];
+}
+
+// First entry of every cell + chunk bookkeeping + C, ONE workgroup (ncells <= a few thousand)
+__global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const uint32_t* __restrict__ cell_total, int ncells,
+                                                         uint32_t* __restrict__ cell_start /* ncells + 1 */,
+                                                         uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */, uint32_t* __restrict__ C_out)
+{
+    __shared__ uint32_t s_part[256], s_chunks[256];
+    // exclusive scans over the cells (sequential per thread over a strip, then over the 256 strip sums), entries first
     const int per = (ncells + 255) / 256;
     const int c0 = min(ncells, (int)threadIdx.x * per), c1 = min(ncells, c0 + per);
     uint32_t sum = 0;
-    for (int c = c0; c < c1; c++) sum += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK;
+    for (int c = c0; c < c1; c++) sum += cell_total[c];
     s_part[threadIdx.x] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int t = 0; t < 256; t++) { const uint32_t v = s_part[t]; s_part[t] = run; run += v; } cell_chunk0[ncells] = run; }
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; t++) { const uint32_t v = s_part[t]; s_part[t] = run; run += v; }
+        *C_out = run;                                       // entries the frame needs; > ccap: the arena was carved for a too small hint
+        cell_start[ncells] = min(run, ccap);
+    }
     __syncthreads();
+    // clamped to the capacity: the place kernel drops what does not fit, nobody reads past it, the call is redone (api.hip)
     uint32_t run = s_part[threadIdx.x];
+    for (int c = c0; c < c1; c++) { cell_start[c] = min(run, ccap); run += cell_total[c]; }
+    __syncthreads();
+    sum = 0;
+    for (int c = c0; c < c1; c++) sum += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK;
+    s_chunks[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t r2 = 0; for (int t = 0; t < 256; t++) { const uint32_t v = s_chunks[t]; s_chunks[t] = r2; r2 += v; } cell_chunk0[ncells] = r2; }
+    __syncthreads();
+    run = s_chunks[threadIdx.x];
     for (int c = c0; c < c1; c++) { cell_chunk0[c] = run; run += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK; }
+}
+
+__global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys,
+                                                                   const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi,
+                                                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
+                                                                   uint4* __restrict__ cent)
+{
+    extern __shared__ unsigned long long s_place[];        // 4 x nc lane words (one table per wave), then nc next-free slots
+    const int nc = pg.nc;
+    unsigned long long* s_touch = s_place;
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + 4 * nc);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start[pg.c0 + c] + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int j1 = min(pg.P, (blk + 1) * pg.G);
+    for (int j0 = blk * pg.G; j0 < j1; j0 += PLACE_THREADS) {          // uniform over the workgroup
+        for (int c = tid; c < 4 * nc; c += PLACE_THREADS) s_touch[c] = 0ull;
+        __syncthreads();
+        const int j = j0 + tid;
+        const bool have = j < j1 && keys[j] != 0xFFFFFFFFu;
+        const uint32_t id = have ? order[j] : 0u;
+        unsigned long long* mine = s_touch + wave * nc;
+        Footprint fp;
+        if (have) { fp = make_footprint(fp_sorted[j], tmask_hi, id); for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); }); }
+        __syncthreads();
+        if (have)
+            for_cells(pg, fp, [&](int cell, uint64_t m) {
+                uint32_t pos = s_base[cell] + (uint32_t)__popcll(mine[cell] & below);
+                for (int w = 0; w < wave; w++) pos += (uint32_t)__popcll(s_touch[w * nc + cell]);       // earlier waves = earlier ranks
+                if (pos < ccap) cent[pos] = make_uint4(id, 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
+            });
+        __syncthreads();
+        for (int c = tid; c < nc; c += PLACE_THREADS)
+            s_base[c] += (uint32_t)(__popcll(s_touch[c]) + __popcll(s_touch[nc + c]) + __popcll(s_touch[2 * nc + c]) + __popcll(s_touch[3 * nc + c]));
+    }
 }
 
 // which cell owns chunk `ch` (cell_chunk0 is non-decreasing, cell_chunk0[ncells] = number of chunks)
@@ -165,10 +246,11 @@ __device__ __forceinline__ int cell_of_chunk(const uint32_t* __restrict__ cell_c
     return lo;
 }
 
-// One wave per chunk: counts of entries touching each of the cell's 64 tiles (lane = tile).  The chunk's four rounds of masks sit
-// in registers; for each tile the four ballots are counted on the scalar unit and the sum lands in lane t with one v_writelane.
+// One wave per chunk: counts of entries touching each of the cell's 64 tiles (lane = tile).  A round of 64 entries is a 64 x 64 bit
+// matrix (row = entry, column = tile of the cell) with one row per lane; the wave transposes it (wave_bits.h, 31 instructions) so
+// that lane t holds column t, and counts its bits -- instead of 64 ballots.
 __global__ void __launch_bounds__(64) expand_count_kernel(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_chunk0, int ncells,
-                                                          const uint32_t* __restrict__ sorted_e, const uint64_t* __restrict__ cmask,
+                                                          const uint4* __restrict__ cent,
                                                           uint32_t* __restrict__ chunk_cnt /* nchunks x 64 */)
 {
     const uint32_t ch = blockIdx.x;
@@ -180,20 +262,18 @@ __global__ void __launch_bounds__(64) expand_count_kernel(const uint32_t* __rest
 #pragma unroll
     for (int rd = 0; rd < XCHUNK / 64; rd++) {
         const uint32_t i = i0 + (uint32_t)rd * 64 + lane;
-        const uint64_t m = (i < i1) ? cmask[sorted_e[i]] : 0ull;
-        mlo[rd] = (uint32_t)m; mhi[rd] = (uint32_t)(m >> 32);
+        const uint4 e = (i < i1) ? cent[i] : make_uint4(0u, 0u, 0u, 0u);
+        mlo[rd] = e.z; mhi[rd] = e.w;
     }
-    int cnt = 0;                       // lane t: entries of this chunk whose mask has bit t
+    const BitTransposeConsts btc = bit_transpose_consts(lane);
+    uint32_t cnt = 0;                  // lane t: entries of this chunk whose mask has bit t
 #pragma unroll
-    for (int t = 0; t < 64; t++) {
-        int c = 0;
-#pragma unroll
-        for (int rd = 0; rd < XCHUNK / 64; rd++)
-            c += __popcll(__builtin_amdgcn_ballot_w64(((t < 32 ? mlo[rd] : mhi[rd]) & (1u << (t & 31))) != 0u));
-        // v_writelane_b32: lane t of cnt <- c (uniform).  Inline asm: this hipcc has no builtin for it; one instruction, no hazard inside
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(cnt) : "s"(__builtin_amdgcn_readfirstlane(c)), "n"(t));
+    for (int rd = 0; rd < XCHUNK / 64; rd++) {
+        if (i0 + (uint32_t)rd * 64 >= i1) break;          // wave-uniform
+        wave_bit_transpose64(mlo[rd], mhi[rd], btc);
+        cnt += (uint32_t)__popc(mlo[rd]) + (uint32_t)__popc(mhi[rd]);
     }
-    chunk_cnt[(size_t)ch * 64 + lane] = (uint32_t)cnt;
+    chunk_cnt[(size_t)ch * 64 + lane] = cnt;
 }
 
 // One wave per cell (lane = tile of the cell): counts -> exclusive prefixes over the cell's chunks, per-tile totals
@@ -217,24 +297,31 @@ __global__ void __launch_bounds__(64) cell_scan_kernel(const uint32_t* __restric
 // tile_start (exclusive scan of the totals, in place) -> ranges; empty tiles keep (0, 0) like identifyTileRanges
 // (rasterizer_impl.cu:233-255 after its memset)
 __global__ void __launch_bounds__(256) write_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_start /* ntiles + 1 */, uint32_t* __restrict__ ranges,
-                                                           const uint32_t* __restrict__ C_dev, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
+                                                           uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) { counters[0] = tile_start[ntiles]; counters[2] = *C_dev; }      // what the host reads back in ONE copy (api.hip)
+    if (t == 0) counters[0] = tile_start[ntiles];              // R as the binning counted it
     if (t >= ntiles) return;
     // clamped to the capacity of point_list: after a too small hint the render kernels must not walk past it (the call is redone)
     const uint32_t a = min(tile_start[t], cap), b = min(tile_start[t + 1], cap);
     ranges[2 * t] = (b > a) ? a : 0u; ranges[2 * t + 1] = (b > a) ? b : 0u;
 }
 
-// One wave per chunk: ids to their final slots, in order.  Tile by tile: the lanes whose mask has the bit form a ballot per round;
-// slot = first slot of the tile for this chunk (scalar, from lane t) + entries of earlier rounds + earlier lanes of the ballot.
+// One wave per chunk: ids to their final slots, in order.  Per round of 64 entries the wave transposes the bit matrix (row = entry,
+// column = tile; wave_bits.h); lane t then holds WHICH entries go to tile t and walks the set bits of that word in ascending order
+// (= entry order), round after round, picking each entry's id out of LDS.  The walk takes as many steps as the fullest tile of
+// the round has entries (a walk over the ROWS -- every entry lane placing its own id into its tiles -- would take 64 steps whenever
+// one large Gaussian covers the cell).  The ids are first gathered in LDS, tile after tile, and then written out with consecutive
+// lanes on consecutive slots of one tile's list: a store per (entry, tile) straight from the walk is one partial-line write request
+// each and costs 45 us of the kernel's 68 at C3.  A chunk with more than SCAT_STAGE ids (rare: 16 per entry) stores directly.
+constexpr int SCAT_STAGE = 4096;
 __global__ void __launch_bounds__(64) expand_scatter_kernel(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_chunk0, int ncells,
-                                                            int cgx, int gx, int gy, const uint32_t* __restrict__ sorted_e,
-                                                            const uint32_t* __restrict__ cid, const uint64_t* __restrict__ cmask,
+                                                            int cgx, int gx, int gy, const uint4* __restrict__ cent,
                                                             const uint32_t* __restrict__ chunk_pref, const uint32_t* __restrict__ tile_start,
                                                             uint32_t cap, uint32_t* __restrict__ point_list)
 {
+    __shared__ uint32_t s_id[XCHUNK / 64][64];
+    __shared__ uint8_t s_out[SCAT_STAGE];              // which entry of the chunk (round << 6 | lane): one byte per id, the id itself stays in s_id
     const uint32_t ch = blockIdx.x;
     if (ch >= cell_chunk0[ncells]) return;
     const int lane = threadIdx.x;
@@ -242,32 +329,67 @@ __global__ void __launch_bounds__(64) expand_scatter_kernel(const uint32_t* __re
     const uint32_t i0 = cell_start[cell] + (ch - cell_chunk0[cell]) * XCHUNK, i1 = min(cell_start[cell + 1], i0 + XCHUNK);
     // lane t: first slot of tile t for this chunk
     const int tx = (cell % cgx) * CB + (lane & 7), ty = (cell / cgx) * CB + (lane >> 3);
-    const int slot = (tx < gx && ty < gy) ? (int)(tile_start[ty * gx + tx] + chunk_pref[(size_t)ch * 64 + lane]) : 0;
-    uint32_t mlo[XCHUNK / 64], mhi[XCHUNK / 64], id[XCHUNK / 64];
+    const uint32_t slot0 = (tx < gx && ty < gy) ? tile_start[ty * gx + tx] + chunk_pref[(size_t)ch * 64 + lane] : 0u;
+    uint32_t mlo[XCHUNK / 64], mhi[XCHUNK / 64];
 #pragma unroll
     for (int rd = 0; rd < XCHUNK / 64; rd++) {
         const uint32_t i = i0 + (uint32_t)rd * 64 + lane;
-        uint64_t m = 0ull; id[rd] = 0u;
-        if (i < i1) { const uint32_t e = sorted_e[i]; m = cmask[e]; id[rd] = cid[e]; }
-        mlo[rd] = (uint32_t)m; mhi[rd] = (uint32_t)(m >> 32);
+        const uint4 e = (i < i1) ? cent[i] : make_uint4(0u, 0u, 0u, 0u);
+        mlo[rd] = e.z; mhi[rd] = e.w;
+        s_id[rd][lane] = e.x;
     }
+    const BitTransposeConsts btc = bit_transpose_consts(lane);
+    uint32_t n = 0;                                        // lane t: ids of this chunk for tile t
 #pragma unroll
-    for (int t = 0; t < 64; t++) {
-        uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane(slot, t);
+    for (int rd = 0; rd < XCHUNK / 64; rd++) {
+        if (i0 + (uint32_t)rd * 64 < i1) wave_bit_transpose64(mlo[rd], mhi[rd], btc);          // (wave-uniform; rounds past the end hold zeros)
+        n += (uint32_t)__popc(mlo[rd]) + (uint32_t)__popc(mhi[rd]);
+    }
+    uint32_t inc = n;                                      // inclusive scan over the tiles: the chunk's ids, tile after tile
 #pragma unroll
-        for (int rd = 0; rd < XCHUNK / 64; rd++) {
-            const bool mine = ((t < 32 ? mlo[rd] : mhi[rd]) & (1u << (t & 31))) != 0u;
-            const uint64_t b = __builtin_amdgcn_ballot_w64(mine);
-            const uint32_t n = (uint32_t)__popcll(b);
-            if (n != 0u) {                                                           // wave-uniform
-                const uint32_t dst = s0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                // dst < cap: after a too small hint every slot below the capacity still gets its entry -- the render kernels walk the
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const bool staged = total <= (uint32_t)SCAT_STAGE;      // wave-uniform
+    const uint32_t base = inc - n;
+    __syncthreads();                                       // one wave: orders the LDS writes of s_id before the reads below
+    uint32_t k = staged ? base : slot0;
+#pragma unroll
+    for (int rd = 0; rd < XCHUNK / 64; rd++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t bits = half ? mhi[rd] : mlo[rd];
+            while (bits != 0u) {
+                const int l = __builtin_ctz(bits) + 32 * half;
+                bits &= bits - 1u;
+                // < cap: after a too small hint every slot below the capacity still gets its entry -- the render kernels walk the
                 // (clamped) ranges before the call is redone
-                if (mine && dst < cap) point_list[dst] = id[rd];
+                if (staged) s_out[k] = (uint8_t)(rd * 64 + l);
+                else if (k < cap) point_list[k] = s_id[rd][l];
+                k++;
             }
-            s0 += n;
         }
     }
+    if (!staged) return;
+    __syncthreads();
+    // write-out, four tiles per step: 16 lanes per tile walk its ids
+    const int sub = lane & 15, grp = lane >> 4;
+    for (int t0 = 0; t0 < 64; t0 += 4) {
+        const int t = t0 + grp;
+        const uint32_t nt = (uint32_t)__shfl((int)n, t, 64), bt = (uint32_t)__shfl((int)base, t, 64), st = (uint32_t)__shfl((int)slot0, t, 64);
+        for (uint32_t q = (uint32_t)sub; q < nt; q += 16u)
+            if (st + q < cap) point_list[st + q] = (&s_id[0][0])[s_out[bt + q]];
+    }
+}
+
+// depth ranks per block of the placement kernels: 256, or more when the count matrix (ncells x blocks) would not fit its share
+// of the arena (BinState::carve)
+static int place_block_ranks(int P, size_t cnt_elems, int ncells)
+{
+    const size_t max_blocks = cnt_elems / (size_t)(ncells > 0 ? ncells : 1);
+    size_t G = 256;
+    if (max_blocks == 0) return -1;
+    if (((size_t)P + G - 1) / G > max_blocks) G = (((size_t)P + max_blocks - 1) / max_blocks + 255) / 256 * 256;
+    return (int)G;
 }
 
 // Part 1: everything up to the tile ranges and the counters the host reads back (R, C); part 2 (launch_binning_scatter) writes the
@@ -275,44 +397,49 @@ __global__ void __launch_bounds__(64) expand_scatter_kernel(const uint32_t* __re
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges)
 {
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy, ntiles = gx * gy;
-    const uint32_t* C_dev = g.coffs + P;              // coarse slots in use (null entries included)
+    uint32_t* counters = g.offsets + P;               // R, depth sort error flag, C: what the host reads back in ONE copy (api.hip)
     if (cap <= 0) { IBGS_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles, s)); return 0; }      // R = 0 (synchronous sizing)
     const uint32_t ccap = (uint32_t)b.ccap;
-    hipLaunchKernelGGL(coarse_emit_kernel, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, s, P, ccap, cgx, (uint32_t)ncells, g.sort_val[0],
-                       g.coffs, g.rect, g.tmask, b.ckeys[0], b.cvals[0], b.cid, b.cmask);
+    PlaceGeom pg;
+    pg.P = P; pg.cgx = cgx;
+    pg.G = place_block_ranks(P, b.cnt_elems, ncells);
+    if (pg.G <= 0) { set_error("binning arena too small for the cell count matrix"); return -IBGS_ERR_ALLOC; }
+    pg.nblk = (P + pg.G - 1) / pg.G;
+    const uint32_t* order = g.sort_val[0];
+    for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
+        pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_key[0], g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
+        IBGS_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total);
     IBGS_HIP(hipGetLastError());
-    int bits = 1;
-    while ((1 << bits) <= ncells) bits++;             // cell ids 0 .. ncells (ncells = the null key)
-    uint32_t* keys[2] = {b.ckeys[0], b.ckeys[1]};
-    uint32_t* vals[2] = {b.cvals[0], b.cvals[1]};
-    int cur = 0;                                  // which ping-pong buffer holds the sorted entries (no copy back after an odd pass count)
-    int rc = radix_sort_pairs(s, keys, vals, (size_t)ccap, bits, b.hist, b.hist_elems, C_dev, false, nullptr, &cur);
-    if (rc) return rc;
-    const uint32_t* sorted_cells = b.ckeys[cur];
-    const uint32_t* sorted_e = b.cvals[cur];
-    const unsigned sort_blocks = (unsigned)(((size_t)ccap + 4095) / 4096);          // RS_CHUNK of scan_sort.hip: the histogram's column stride
-    hipLaunchKernelGGL(cell_setup_kernel, dim3(1), dim3(256), 0, s, C_dev, ccap, sorted_cells, b.hist, bits <= 8 ? sort_blocks : 0u, ncells,
-                       b.cell_start, b.cell_chunk0);
+    hipLaunchKernelGGL(cell_setup_kernel, dim3(1), dim3(256), 0, s, ccap, b.cell_total, ncells, b.cell_start, b.cell_chunk0, counters + 2);
     IBGS_HIP(hipGetLastError());
+    for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
+        pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
+        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.sort_key[0], g.fp_sorted, g.tmask_hi,
+                           b.cnt, b.cell_start, b.cent);
+        IBGS_HIP(hipGetLastError());
+    }
+    int rc;
     const unsigned nchunks_max = (unsigned)(ccap / XCHUNK + (size_t)ncells + 1);
-    hipLaunchKernelGGL(expand_count_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, sorted_e, b.cmask, b.chunk_cnt);
+    hipLaunchKernelGGL(expand_count_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, b.cent, b.chunk_cnt);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
     if ((rc = exclusive_scan_u32(s, b.tile_total, b.tile_total, (size_t)ntiles, b.scan_scratch, b.scan_elems, true))) return rc;
-    hipLaunchKernelGGL(write_ranges_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, b.tile_total, ranges, C_dev, g.offsets + P,
+    hipLaunchKernelGGL(write_ranges_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, b.tile_total, ranges, counters,
                        (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll));
     IBGS_HIP(hipGetLastError());
-    return cur;                                   // >= 0: the buffer that holds the sorted coarse entries (for part 2)
+    return 0;
 }
 
-int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, int cur)
+int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b)
 {
     if (cap <= 0) return 0;
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy;
-    const uint32_t* sorted_e = b.cvals[cur];
     const unsigned nchunks_max = (unsigned)(b.ccap / XCHUNK + (size_t)ncells + 1);
-    hipLaunchKernelGGL(expand_scatter_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, cgx, gx, gy, sorted_e, b.cid, b.cmask,
+    hipLaunchKernelGGL(expand_scatter_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, cgx, gx, gy, b.cent,
                        b.chunk_cnt, b.tile_total, (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), b.point_list);
     IBGS_HIP(hipGetLastError());
     return 0;

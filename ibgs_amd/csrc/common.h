@@ -42,14 +42,14 @@ struct GeomState {
     float* depths;         // P
     float* cov3D;          // P x 6
     uint32_t* tiles;       // P   tiles touched
-    uint32_t* tc;          // P   tiles | (coarse cells of the rectangle) << 18, what the binning stage gathers
-    uint32_t* rect;        // P x 2  (x0 | x1<<16, y0 | y1<<16), tightened by the tile cull
-    uint64_t* tmask;       // P x IBGS_CULL_WORDS  surviving tiles inside rect (row-major bit mask, rects of <= IBGS_CULL_MAX_TILES tiles)
+    uint4* fp;             // P   footprint: (x0 | x1<<16, y0 | y1<<16) = the tile rectangle, tightened by the tile cull, and the first 64 bits of the
+                           //     row-major mask of its surviving tiles -- ONE 16-byte gather per Gaussian for the binning stage
+    uint64_t* tmask_hi;    // P x (IBGS_CULL_WORDS - 1)  mask bits 64.. (rectangles of 65..IBGS_CULL_MAX_TILES tiles only)
+    uint4* fp_sorted;      // P   the footprints in depth order (written by the binning's count pass, read by its place pass)
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered
-    uint32_t* offsets;     // P+3: exclusive scan of tiles in depth order (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back together
-    uint32_t* coffs;       // P+1: exclusive scan of coarse cells touched, in depth order; [P] = C (binning.hip)
+    uint32_t* offsets;     // P+3: exclusive scan of the tiles touched (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back together
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
     static GeomState carve(char* base, size_t P, size_t* total);
@@ -73,17 +73,16 @@ constexpr int BIN_XCHUNK = 256;    // coarse entries per expansion chunk (one wa
 
 struct BinState {
     uint32_t* point_list;  // R     sorted Gaussian ids (final); FIRST in the arena so that its offset does not depend on the capacity
-    uint32_t* cid;         // ccap  coarse entry e (emission = depth order): Gaussian id
-    uint64_t* cmask;       // ccap  ... its surviving tiles inside the cell, bit ly * 8 + lx
-    uint32_t* ckeys[2];    // ccap  cell ids (ping-pong of the coarse sort)
-    uint32_t* cvals[2];    // ccap  coarse entry indices (ping-pong)
-    uint32_t* cell_start;  // ncells + 1   first sorted coarse entry of every cell
+    uint4* cent;           // ccap  coarse entries, cell by cell, depth order inside a cell: {Gaussian id, -, its surviving tiles inside the cell as a
+                           //       64-bit mask (lo, hi), bit ly * 8 + lx}
+    uint32_t* cnt;         // cnt_elems >= ncells x blocks   entries per (cell, block of depth ranks), scanned over the blocks in place
+    size_t cnt_elems;
+    uint32_t* cell_total;  // ncells   entries per cell
+    uint32_t* cell_start;  // ncells + 1   first coarse entry of every cell
     uint32_t* cell_chunk0; // ncells + 1   first expansion chunk of every cell ([ncells] = number of chunks)
     uint32_t* chunk_cnt;   // nchunks_max x 64   per chunk and tile of its cell: count, then prefix within the cell
     uint32_t* tile_total;  // ntiles + 1   entries per tile, scanned in place to the tile starts
     uint32_t* scan_scratch; size_t scan_elems;
-    uint32_t* hist;        // radix histogram + scan scratch
-    size_t hist_elems;
     size_t ccap;           // capacity of the coarse arrays (= the capacity the arena was carved for: C <= R always)
     static BinState carve(char* base, size_t R, int W, int H, size_t* total);       // H = height of the (stacked) tile grid in pixels
 };
@@ -194,11 +193,10 @@ int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t 
 size_t scan_scratch_elems(size_t n);
 void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatter launches per pass
 
-int launch_gather_tiles(hipStream_t s, int P, const GeomState& g, bool want_tiles);   // tiles / coarse slots in depth order -> scan inputs
 // per-tile lists + tile ranges from the depth-ordered Gaussians (two-level binning, binning.hip); `cap` = capacity of point_list
 // part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges);
-int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, int cur);
+int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
 // geo backward: per-pixel table of the median / warp terms of every buffered contributor (render_bwd.hip), 6 words per slot

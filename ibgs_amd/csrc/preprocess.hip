@@ -33,7 +33,7 @@ struct PreParams {
     float scale_modifier;
     int depth_only;
     int32_t* radii;
-    float* rec; float* depths; float* cov3D; uint32_t* tiles; uint32_t* tc; uint32_t* rect; uint64_t* tmask; uint8_t* clamped;
+    float* rec; float* depths; float* cov3D; uint32_t* tiles; uint4* fp; uint64_t* tmask_hi; uint8_t* clamped;
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
 };
@@ -339,17 +339,11 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     const int o = p.inst0 + i;            // instance slot (= i for a single view)
     p.radii[o] = radius;
     p.tiles[o] = ntiles;
-    {   // tiles | (coarse cells of the rectangle) << 18: ONE gather per Gaussian for the binning stage (binning.hip)
-        const uint32_t bx0 = rx & 0xFFFFu, bx1 = rx >> 16, by0 = ry & 0xFFFFu, by1 = ry >> 16;
-        const uint32_t nc = ntiles ? ((bx1 - 1) / BIN_CELL - bx0 / BIN_CELL + 1) * ((by1 - 1) / BIN_CELL - by0 / BIN_CELL + 1) : 0u;
-        p.tc[o] = ntiles | (nc << 18);
-    }
-    p.rect[2 * o] = rx; p.rect[2 * o + 1] = ry;
-    // word 0 always; words 1..3 only matter (and are only read by emit) for rectangles of more than 64 tiles
-    p.tmask[(size_t)o * IBGS_CULL_WORDS] = tmask[0];
+    // rectangle + mask word 0: one 16-byte record; words 1..3 only matter (and are only read by the binning) for rectangles of more than 64 tiles
+    p.fp[o] = make_uint4(rx, ry, (uint32_t)tmask[0], (uint32_t)(tmask[0] >> 32));
     if (big_rect) {
 #pragma unroll
-        for (int k = 1; k < IBGS_CULL_WORDS; k++) p.tmask[(size_t)o * IBGS_CULL_WORDS + k] = tmask[k];
+        for (int k = 1; k < IBGS_CULL_WORDS; k++) p.tmask_hi[(size_t)o * (IBGS_CULL_WORDS - 1) + (k - 1)] = tmask[k];
     }
     p.depths[o] = depth;
     p.clamped[o] = clampbits;
@@ -384,8 +378,8 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     p.shs = a.shs; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
     p.plane_normal = a.plane_normal; p.plane_offset = a.plane_offset; p.plane_mode = a.plane_mode;
     p.scale_modifier = a.scale_modifier; p.depth_only = a.render_depth_only;
-    p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.tc = g.tc; p.rect = g.rect;
-    p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0]; p.tmask = g.tmask;
+    p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.fp = g.fp; p.tmask_hi = g.tmask_hi;
+    p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0];
     // depth-only with a 1-slot buffer depends on list positions (the per-round 'break' of forward.cu:484-488)
     p.cull = !(a.flags & IBGS_FLAG_NO_TILE_CULL) && !(a.render_depth_only && a.buffer_length == 1);
     const int blocks = (a.P + 255) / 256;

@@ -229,7 +229,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                         dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);          // ... - T_final (bg . g) / (1 - alpha)
                         const float qv = oG * dL_dalpha;                          // dL/dG * G
                         Q[q] = qv;
-                        aX += fabsf(qv * lxq[q]); aY += fabsf(qv * lyq[q]);
+                        aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);      // |a b| = |a| |b|: one v_fma with source modifiers
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
@@ -520,7 +520,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                         dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);
                         const float qv = oG * dL_dalpha;
                         Q[q] = qv;
-                        aX += fabsf(qv * lxq[q]); aY += fabsf(qv * lyq[q]);
+                        aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);      // |a b| = |a| |b|: one v_fma with source modifiers
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
