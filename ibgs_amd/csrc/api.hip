@@ -48,7 +48,7 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.clamped = c.take<uint8_t>(P);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
-    g.offsets = c.take<uint32_t>(P + 3);
+    g.offsets = c.take<uint32_t>(P + 4);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -265,8 +265,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     { StageTimer t(s, IBGS_STAGE_PREPROCESS); if ((rc = launch_preprocess(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess"))) return rc;
     { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
-      IBGS_HIP(hipMemsetAsync(g.offsets + Pn + 1, 0, sizeof(uint32_t), s));          // look-back error flag, travels back with R
-      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, nullptr, false, g.offsets + Pn + 1))) return rc; }
+      // (the preprocess kernel has zeroed the sort's scratch, the look-back error flag [Pn + 1] that travels back with R, and [Pn + 3])
+      // Gaussians without tiles (key 0xFFFFFFFF) are not carried through the sort; [Pn + 3] = how many others there are
+      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.offsets + Pn + 1, g.offsets + Pn + 3, true))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
     // R = total number of (Gaussian, tile) pairs.  The binning arena is sized from it, and it is only known on the device.
     //  * no hint (first call of a shape, or debug): the tiles-touched counts are scanned, R travels to the host through a pinned

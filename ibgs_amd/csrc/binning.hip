@@ -125,7 +125,7 @@ __device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& 
         }
 }
 
-__global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys,
+__global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi,
                                                                    uint4* __restrict__ fp_sorted /* the footprints in depth order, for the place kernel */,
                                                                    uint32_t* __restrict__ cnt /* ncells x nblk */)
@@ -134,9 +134,8 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg,
     const int tid = threadIdx.x, blk = blockIdx.x;
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) s_cnt[c] = 0u;
     __syncthreads();
-    const int j1 = min(pg.P, (blk + 1) * pg.G);
+    const int j1 = min((int)min((uint32_t)pg.P, *n_kept), (blk + 1) * pg.G);          // ranks past the Gaussians with tiles hold nothing
     for (int j = blk * pg.G + tid; j < j1; j += PLACE_THREADS) {
-        if (keys[j] == 0xFFFFFFFFu) continue;                  // no tiles (culled): these sort last, whole blocks of them cost one load
         const uint32_t id = order[j];
         const uint4 rec = fpr[id];                             // the one random 16-byte gather per Gaussian of the binning stage
         if (pg.c0 == 0) fp_sorted[j] = rec;
@@ -203,7 +202,7 @@ __global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const ui
     for (int c = c0; c < c1; c++) { cell_chunk0[c] = run; run += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK; }
 }
 
-__global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys,
+__global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi,
                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
                                                                    uint4* __restrict__ cent)
@@ -215,12 +214,12 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
     for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start[pg.c0 + c] + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int j1 = min(pg.P, (blk + 1) * pg.G);
+    const int j1 = min((int)min((uint32_t)pg.P, *n_kept), (blk + 1) * pg.G);
     for (int j0 = blk * pg.G; j0 < j1; j0 += PLACE_THREADS) {          // uniform over the workgroup
         for (int c = tid; c < 4 * nc; c += PLACE_THREADS) s_touch[c] = 0ull;
         __syncthreads();
         const int j = j0 + tid;
-        const bool have = j < j1 && keys[j] != 0xFFFFFFFFu;
+        const bool have = j < j1;
         const uint32_t id = have ? order[j] : 0u;
         unsigned long long* mine = s_touch + wave * nc;
         Footprint fp;
@@ -294,17 +293,47 @@ __global__ void __launch_bounds__(64) cell_scan_kernel(const uint32_t* __restric
     if (tx < gx && ty < gy) tile_total[ty * gx + tx] = run;
 }
 
-// tile_start (exclusive scan of the totals, in place) -> ranges; empty tiles keep (0, 0) like identifyTileRanges
-// (rasterizer_impl.cu:233-255 after its memset)
-__global__ void __launch_bounds__(256) write_ranges_kernel(int ntiles, const uint32_t* __restrict__ tile_start /* ntiles + 1 */, uint32_t* __restrict__ ranges,
-                                                           uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
+// Per-tile totals -> tile starts (exclusive scan, in place; [ntiles] = R) -> ranges, ONE workgroup: a strip of consecutive tiles per
+// thread, the 1024 strip sums scanned through LDS.  Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after
+// its memset).
+__global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) counters[0] = tile_start[ntiles];              // R as the binning counted it
-    if (t >= ntiles) return;
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (ntiles + 1023) / 1024;
+    const int t0 = min(ntiles, tid * per), t1 = min(ntiles, t0 + per);
+    constexpr int KEEP = 16;                               // strips up to this length stay in registers (frames up to 2048 x 2048 tiles ... 16 K tiles)
+    uint32_t v[KEEP];
+    uint32_t sum = 0;
+    if (per <= KEEP) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k++) { v[k] = (t0 + k < t1) ? tile_start[t0 + k] : 0u; sum += v[k]; }
+    } else {
+        for (int t = t0; t < t1; t++) sum += tile_start[t];
+    }
+    uint32_t inc = sum;                                    // inclusive scan of the strip sums: within the wave, then over the 16 waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    uint32_t run = before + inc - sum;
     // clamped to the capacity of point_list: after a too small hint the render kernels must not walk past it (the call is redone)
-    const uint32_t a = min(tile_start[t], cap), b = min(tile_start[t + 1], cap);
-    ranges[2 * t] = (b > a) ? a : 0u; ranges[2 * t + 1] = (b > a) ? b : 0u;
+    auto put = [&](int t, uint32_t n) {
+        tile_start[t] = run;
+        const uint32_t a = min(run, cap), b = min(run + n, cap);
+        *reinterpret_cast<uint2*>(ranges + 2 * (size_t)t) = (b > a) ? make_uint2(a, b) : make_uint2(0u, 0u);
+        run += n;
+    };
+    if (per <= KEEP) {
+#pragma unroll
+        for (int k = 0; k < KEEP; k++) if (t0 + k < t1) put(t0 + k, v[k]);
+    } else {
+        for (int t = t0; t < t1; t++) put(t, tile_start[t]);
+    }
+    if (tid == 1023) { tile_start[ntiles] = run; counters[0] = run; }      // R as the binning counted it (the last strip ends at ntiles)
 }
 
 // One wave per chunk: ids to their final slots, in order.  Per round of 64 entries the wave transposes the bit matrix (row = entry,
@@ -408,7 +437,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     const uint32_t* order = g.sort_val[0];
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
-        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_key[0], g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.offsets + P + 3, g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
         IBGS_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total);
@@ -417,18 +446,16 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     IBGS_HIP(hipGetLastError());
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
-        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.sort_key[0], g.fp_sorted, g.tmask_hi,
+        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
                            b.cnt, b.cell_start, b.cent);
         IBGS_HIP(hipGetLastError());
     }
-    int rc;
     const unsigned nchunks_max = (unsigned)(ccap / XCHUNK + (size_t)ncells + 1);
     hipLaunchKernelGGL(expand_count_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, b.cent, b.chunk_cnt);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
-    if ((rc = exclusive_scan_u32(s, b.tile_total, b.tile_total, (size_t)ntiles, b.scan_scratch, b.scan_elems, true))) return rc;
-    hipLaunchKernelGGL(write_ranges_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, ntiles, b.tile_total, ranges, counters,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
                        (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll));
     IBGS_HIP(hipGetLastError());
     return 0;

@@ -49,7 +49,8 @@ struct GeomState {
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered
-    uint32_t* offsets;     // P+3: exclusive scan of the tiles touched (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back together
+    uint32_t* offsets;     // P+4: exclusive scan of the tiles touched (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back
+                           //      together; [P+3] = Gaussians with tiles (what the depth sort keeps)
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
     static GeomState carve(char* base, size_t P, size_t* total);
@@ -181,12 +182,13 @@ int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float*
 size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by radix_sort_pairs on n items
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev = nullptr, bool key16 = false, uint32_t* err_dev = nullptr,
-                     int* result_buf = nullptr);
-// result_buf: when given, an odd number of passes is NOT copied back to buffer 0; *result_buf says which buffer holds the result
-// key16: keys[] hold uint16_t values (tile ids of frames with <= 65536 tiles)
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false);
+size_t radix_zero_elems(size_t n, int nbits);      // leading words of `hist` the sort needs zeroed (see scratch_is_zero)
 // err_dev: device word (zeroed by the caller) that the single-launch look-back passes set to 1 when their bounded spin gives up --
 //          the pass has then scattered with a partial prefix; the caller must read it back and fail the call
+// kept_dev: device word (zeroed by the caller).  When given, pairs whose key is 0xFFFFFFFF need not be carried: *kept_dev receives the
+//          number K of other pairs, the result holds those K pairs sorted in [0, K) and unspecified pairs behind them
+// scratch_is_zero: the caller has zeroed hist[0, radix_zero_elems(n, nbits)) on the stream already
 // Exclusive scan of `n` uint32 (in place allowed); out[n] receives the total when with_total.
 int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* scratch,
                        size_t scratch_elems, bool with_total);

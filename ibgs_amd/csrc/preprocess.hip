@@ -36,6 +36,7 @@ struct PreParams {
     float* rec; float* depths; float* cov3D; uint32_t* tiles; uint4* fp; uint64_t* tmask_hi; uint8_t* clamped;
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
+    uint32_t* zero_a; uint32_t zero_a_n; uint32_t* zero_b; uint32_t zero_b_n;      // words the next stages want zeroed (the depth sort's scratch, its counters)
 };
 
 __device__ __forceinline__ float ndc_to_pix(float v, int S)
@@ -111,7 +112,11 @@ __device__ __forceinline__ bool tile_keep(const CullJob& j, int tx, int ty)
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
 __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam)
 {
+    __shared__ float4 s_stage_all[4][64 * 5];                 // 64 records at a stride of 5 quads (conflict-free 16-byte LDS accesses)
+    float4* s_stage = s_stage_all[threadIdx.x >> 6];          // private to the wave: LDS operations of one wave execute in order, no barrier needed
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t z = (uint32_t)gi; z < p.zero_a_n; z += gridDim.x * blockDim.x) p.zero_a[z] = 0u;      // instead of two fill launches
+    if ((uint32_t)gi < p.zero_b_n) p.zero_b[gi] = 0u;
     const bool valid = gi < p.P;          // lanes past the end stay in the wave: the cooperative tile test below needs all 64
     const int i = valid ? gi : p.P - 1;   // (they recompute the last Gaussian and store nothing)
 
@@ -334,6 +339,20 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
             }
         }
     }
+    {   // the 64-byte records leave through LDS: a lane storing its own record spreads every store instruction over 64 lines; transposed, the
+        // wave writes its 4 KB as four fully coalesced 1 KB stores
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_stage[lane * 5 + k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+        const int first = blockIdx.x * blockDim.x + (threadIdx.x & ~63);          // this wave's Gaussians are [first, first + 64) cut at P
+        const int nrow = min(64, p.P - first);
+        float4* out = reinterpret_cast<float4*>(p.rec) + ((size_t)p.inst0 + first) * 4;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int q = it * 64 + lane, row = q >> 2;
+            if (row < nrow) out[q] = s_stage[row * 5 + (q & 3)];
+        }
+    }
     if (!valid) return;
 
     const int o = p.inst0 + i;            // instance slot (= i for a single view)
@@ -351,11 +370,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
 #pragma unroll
         for (int k = 0; k < 6; k++) p.cov3D[6 * o + k] = c6loc[k];   // computed for every Gaussian past the near cull
     }
-    float4* out = reinterpret_cast<float4*>(p.rec + (size_t)o * REC_FLOATS);
-    out[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
-    out[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
-    out[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
-    out[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
     // depth sort input: positive float bits order like the floats; culled Gaussians sort last
     // Gaussians without any tile (culled, or fully tile-culled) sort last and emit nothing
     p.sort_key[o] = (alive && ntiles > 0) ? __float_as_uint(depth) : 0xFFFFFFFFu;
@@ -385,6 +399,8 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     const int blocks = (a.P + 255) / 256;
     const int nv = a.n_views > 1 ? a.n_views : 1;
     const int gy = (a.H + TILE - 1) / TILE;
+    p.zero_a = g.hist; p.zero_a_n = (uint32_t)radix_zero_elems((size_t)nv * a.P, 32);
+    p.zero_b = g.offsets + (size_t)nv * a.P + 1; p.zero_b_n = 3;
     for (int v = 0; v < nv; v++) {       // batched depth passes: one launch per camera, outputs land in that view's slice
         p.inst0 = v * a.P; p.tile_row0 = v * gy;
         const Cam cam = make_cam(a.viewmatrix + 16 * v, a.projmatrix + 16 * v, a.campos + 3 * v, a.bg,

@@ -291,18 +291,26 @@ constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_INC = 2u << 30, OS_VAL_MASK =
 constexpr int OS_MAX_PASS = 4;
 
 __global__ void __launch_bounds__(RS_THREADS) onesweep_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npass, int dbits,
-                                                                   uint32_t* __restrict__ ghist /* npass x 256 */)
+                                                                   uint32_t* __restrict__ ghist /* npass x 256 */,
+                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept)
 {
     __shared__ uint32_t h[OS_MAX_PASS][RS_MAX_BINS];
+    __shared__ uint32_t s_kept;
     for (int k = threadIdx.x; k < OS_MAX_PASS * RS_MAX_BINS; k += RS_THREADS) (&h[0][0])[k] = 0;
+    if (threadIdx.x == 0) s_kept = 0;
     __syncthreads();
     const uint32_t mask = (1u << dbits) - 1u;
     const size_t stride = (size_t)gridDim.x * RS_THREADS;
+    uint32_t kept = 0;
     for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += stride) {
         const uint32_t k = keys[i];
+        if (drop_max && k == 0xFFFFFFFFu) continue;
+        kept++;
         for (int p = 0; p < npass; p++) atomicAdd(&h[p][(k >> (p * dbits)) & mask], 1u);
     }
+    if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
+    if (threadIdx.x == 0 && s_kept) atomicAdd(n_kept, s_kept);
     for (int k = threadIdx.x; k < npass * RS_MAX_BINS; k += RS_THREADS) {
         const uint32_t c = (&h[0][0])[k];
         if (c) atomicAdd(&ghist[k], c);
@@ -314,7 +322,9 @@ __global__ void __launch_bounds__(RS_THREADS) onesweep_pass_kernel(const uint32_
                                                                    size_t n, int shift, int nbits, int nbins,
                                                                    const uint32_t* __restrict__ ghist /* 256, this pass */,
                                                                    uint32_t* __restrict__ status /* nblocks x 256, zeroed */,
-                                                                   uint32_t* __restrict__ ticket, uint32_t* __restrict__ err)
+                                                                   uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                                                                   int drop_here /* first pass of a sort that drops the 0xFFFFFFFF keys */,
+                                                                   const uint32_t* __restrict__ n_kept /* items that take part (device) */)
 {
     __shared__ uint32_t wcnt[4][RS_MAX_BINS];
     __shared__ unsigned long long ptab[4][RS_MAX_BINS];      // match-any slots (wave_rank)
@@ -326,22 +336,40 @@ __global__ void __launch_bounds__(RS_THREADS) onesweep_pass_kernel(const uint32_
     __shared__ uint32_t s_bid;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t kept = *n_kept;
+    const size_t n_in = drop_here ? n : (size_t)kept;         // after the first pass the dropped keys are gone
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
     for (int k = threadIdx.x; k < 4 * RS_MAX_BINS; k += RS_THREADS) { (&wcnt[0][0])[k] = 0; (&ptab[0][0])[k] = 0ull; }
     __syncthreads();
     const uint32_t bid = s_bid;
-
     const size_t base = (size_t)bid * RS_CHUNK;
+    if (base >= n_in) return;                               // (uniform; nobody looks back at a workgroup without items)
+
+    // Every key carries the same digit (e.g. the top byte of depths within [2, 8)): the pass would not move anything.  The decision
+    // comes from the global histogram, so every workgroup takes it alike; a pass that also has to drop keys always runs.
+    const int all_one_bin = __syncthreads_or((int)(threadIdx.x < (unsigned)nbins && kept != 0u && ghist[threadIdx.x] == kept));
+    if (all_one_bin && (!drop_here || (size_t)kept == n)) {
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; k++) {
+            const size_t idx = base + (size_t)k * RS_THREADS + threadIdx.x;
+            if (idx < n_in) { keys_out[idx] = keys_in[idx]; vals_out[idx] = vals_in[idx]; }
+        }
+        return;
+    }
+
     const uint32_t mask = (uint32_t)nbins - 1;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    uint32_t takes = 0;                                    // bit k: item k of this thread takes part
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
         const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
-        const bool valid = idx < n;
-        key[k] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[k] = valid ? vals_in[idx] : 0u;
+        const bool inside = idx < n_in;
+        key[k] = inside ? keys_in[idx] : 0xFFFFFFFFu;
+        val[k] = inside ? vals_in[idx] : 0u;
+        const bool valid = inside && !(drop_here && key[k] == 0xFFFFFFFFu);
+        takes |= valid ? (1u << k) : 0u;
         const uint32_t d = (key[k] >> shift) & mask;
         const uint32_t r = wave_rank(d, valid, lane, lt_mask, &wcnt[wave][0], &ptab[wave][0]);
         rank[k] = r;
@@ -386,12 +414,10 @@ __global__ void __launch_bounds__(RS_THREADS) onesweep_pass_kernel(const uint32_
     }
     __syncthreads();
 
-    const size_t remaining = n - base;
-    const uint32_t count = remaining < (size_t)RS_CHUNK ? (uint32_t)remaining : (uint32_t)RS_CHUNK;
+    const uint32_t count = ltotal;                         // items of this chunk that take part
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; k++) {
-        const size_t idx = base + (size_t)wave * (RS_ITEMS * 64) + (size_t)k * 64 + lane;
-        if (idx < n) {
+        if (takes & (1u << k)) {
             const uint32_t d = (key[k] >> shift) & mask;
             const uint32_t lpos = dstart[d] + wcnt[wave][d] + rank[k];
             skey[lpos] = key[k];
@@ -428,24 +454,24 @@ static size_t onesweep_elems(size_t n)
 }
 
 static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
-                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev)
+                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero)
 {
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int nbins = 1 << dbits;
     const size_t need = (size_t)OS_MAX_PASS * RS_MAX_BINS + 64 + (size_t)npass * nblocks * RS_MAX_BINS;
     if (scratch_elems < need) { set_error("onesweep scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* ghist = scratch;                                  // OS_MAX_PASS x 256
-    uint32_t* tickets = scratch + OS_MAX_PASS * RS_MAX_BINS;      // per pass ticket counters, [32] = error flag
+    uint32_t* tickets = scratch + OS_MAX_PASS * RS_MAX_BINS;      // per pass ticket counters, [32] = error flag, [33] = keys that take part
     uint32_t* status = tickets + 64;
-    IBGS_HIP(hipMemsetAsync(scratch, 0, need * sizeof(uint32_t), s));
+    if (!scratch_is_zero) IBGS_HIP(hipMemsetAsync(scratch, 0, need * sizeof(uint32_t), s));
     const unsigned hblocks = nblocks < 1024u ? nblocks : 1024u;
-    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(RS_THREADS), 0, s, keys[0], n, npass, dbits, ghist);
+    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(RS_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33);
     IBGS_HIP(hipGetLastError());
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
         hipLaunchKernelGGL(onesweep_pass_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
                            n, pass * dbits, dbits, nbins, ghist + pass * RS_MAX_BINS, status + (size_t)pass * nblocks * RS_MAX_BINS,
-                           tickets + pass, err_dev ? err_dev : tickets + 32);
+                           tickets + pass, err_dev ? err_dev : tickets + 32, (kept_dev && pass == 0) ? 1 : 0, kept_dev ? kept_dev : tickets + 33);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
@@ -465,40 +491,59 @@ size_t radix_hist_elems(size_t n)
     return classic > os ? classic : os;
 }
 
-int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, const uint32_t* n_dev, bool key16, uint32_t* err_dev, int* result_buf)
+__global__ void __launch_bounds__(RS_THREADS) count_kept_kernel(const uint32_t* __restrict__ keys, size_t n, uint32_t* __restrict__ kept)
 {
-    if (result_buf) *result_buf = 0;
+    uint32_t c = 0;
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RS_THREADS) c += keys[i] != 0xFFFFFFFFu ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(kept, c);
+}
+
+// how many leading words of the scratch radix_sort_pairs wants zeroed (0: none); a caller that zeroes them itself -- e.g. inside a kernel
+// it runs anyway -- passes scratch_is_zero and saves the fill launch
+size_t radix_zero_elems(size_t n, int nbits_total)
+{
+    if (n == 0 || nbits_total <= 0) return 0;
+    const size_t nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    const int npass = (nbits_total + 7) / 8;
+    const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
+    if (!(want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)) return 0;
+    return (size_t)OS_MAX_PASS * RS_MAX_BINS + 64 + (size_t)npass * nblocks * RS_MAX_BINS;
+}
+
+int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero)
+{
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int npass = (nbits_total + 7) / 8;
     const int dbits = (nbits_total + npass - 1) / npass;
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
-    if (want_os && !n_dev && !key16 && !result_buf && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
-        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev);
+    if (want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;
     const size_t scan_elems = hist_elems - (hist_n + 1 + 63);
+    if (kept_dev) {      // the 0xFFFFFFFF keys sort behind everything else: counting the others is all that "dropping" them takes here
+        hipLaunchKernelGGL(count_kept_kernel, dim3(nblocks < 1024u ? nblocks : 1024u), dim3(RS_THREADS), 0, s, keys[0], n, kept_dev);
+        IBGS_HIP(hipGetLastError());
+    }
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
         const int shift = pass * dbits;
-        if (key16) hipLaunchKernelGGL(radix_hist_kernel<uint16_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, reinterpret_cast<const uint16_t*>(keys[cur]), n, n_dev, shift, nbins, hist, nblocks);
-        else hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, n_dev, shift, nbins, hist, nblocks);
+        hipLaunchKernelGGL(radix_hist_kernel<uint32_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], n, (const uint32_t*)nullptr, shift, nbins, hist, nblocks);
         IBGS_HIP(hipGetLastError());
         int rc = exclusive_scan_u32(s, hist, hist, hist_n, scan_scratch, scan_elems, false);
         if (rc) return rc;
-        if (key16) hipLaunchKernelGGL(radix_scatter_kernel<uint16_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, reinterpret_cast<const uint16_t*>(keys[cur]), vals[cur],
-                                      reinterpret_cast<uint16_t*>(keys[cur ^ 1]), vals[cur ^ 1], n, n_dev, shift, dbits, nbins, hist, nblocks);
-        else hipLaunchKernelGGL(radix_scatter_kernel<uint32_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
-                                n, n_dev, shift, dbits, nbins, hist, nblocks);
+        hipLaunchKernelGGL(radix_scatter_kernel<uint32_t>, dim3(nblocks), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                           n, (const uint32_t*)nullptr, shift, dbits, nbins, hist, nblocks);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
-    if (result_buf) { *result_buf = cur; return 0; }
     if (cur != 0) {   // odd number of passes: bring the result back to buffer 0
-        IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * (key16 ? sizeof(uint16_t) : sizeof(uint32_t)), hipMemcpyDeviceToDevice, s));
+        IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
     return 0;
