@@ -90,32 +90,43 @@ constexpr int PLACE_MAX_CELLS = 1024;
 
 struct PlaceGeom { int P, G, nblk, cgx; int c0, nc; };            // G = depth ranks per block (a multiple of 256); cells [c0, c0 + nc) in this launch
 
-// calls f(cell, mask) for every cell of the slice that holds a surviving tile of the Gaussian
+// The common case: a rectangle of at most 8 x 8 tiles reaches at most 2 x 2 cells and its whole mask is word 0.  The rows are spread
+// to a stride of 8 once; the part inside a cell is that image shifted by the rectangle's offset from the cell, columns that wrap
+// masked off.  Four fixed slots (cell < 0: none), so the callers run straight-line code and keep the masks between their sweeps.
+struct Cells4 { int cell[4]; uint64_t m[4]; };
+__device__ __forceinline__ bool small_cells(const PlaceGeom& pg, const Footprint& fp, Cells4& out)
+{
+    const RectU& r = fp.r;
+    const uint32_t w = r.x1 - r.x0, h = r.y1 - r.y0;          // (unsigned: an empty, culled rectangle fails the test below or yields no cell)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { out.cell[k] = -1; out.m[k] = 0ull; }
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return true;            // culled: no tiles
+    if (w > (uint32_t)CB || h > (uint32_t)CB) return false;
+    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
+    uint64_t img = 0ull;
+    const uint64_t rowm = (1ull << w) - 1ull;
+    for (uint32_t i = 0; i < h; i++) img |= ((fp.m[0] >> (i * w)) & rowm) << (8u * i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t cx = c0x + (uint32_t)(k & 1), cy = c0y + (uint32_t)(k >> 1);
+        if (cx > c1x || cy > c1y) continue;
+        const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+        if (cell < 0 || cell >= pg.nc) continue;
+        const int dx = (int)r.x0 - (int)(cx * CB), dy = (int)r.y0 - (int)(cy * CB);          // both in (-8, 8)
+        uint64_t m = dx >= 0 ? (img << dx) & (0x0101010101010101ull * (uint64_t)((0xFFu << dx) & 0xFFu))
+                             : (img >> (-dx)) & (0x0101010101010101ull * (uint64_t)(0xFFu >> (-dx)));
+        m = dy >= 0 ? m << (8 * dy) : m >> (8 * (-dy));
+        if (m != 0ull) { out.cell[k] = cell; out.m[k] = m; }
+    }
+    return true;
+}
+
+// larger rectangles: calls f(cell, mask) for every cell of the slice that holds a surviving tile of the Gaussian
 template <typename F>
 __device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& fp, F f)
 {
     const RectU& r = fp.r;
-    if (r.x1 <= r.x0 || r.y1 <= r.y0) return;                 // culled: no tiles
     const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
-    const uint32_t w = r.x1 - r.x0, h = r.y1 - r.y0;
-    if (w <= (uint32_t)CB && h <= (uint32_t)CB) {
-        // the common case, a rectangle of at most 8 x 8 tiles (its whole mask is word 0): spread the rows to a stride of 8 once; the
-        // part inside a cell is then that image shifted by the rectangle's offset from the cell, columns that wrap masked off
-        uint64_t img = 0ull;
-        const uint64_t rowm = (1ull << w) - 1ull;
-        for (uint32_t i = 0; i < h; i++) img |= ((fp.m[0] >> (i * w)) & rowm) << (8u * i);
-        for (uint32_t cy = c0y; cy <= c1y; cy++)
-            for (uint32_t cx = c0x; cx <= c1x; cx++) {
-                const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
-                if (cell < 0 || cell >= pg.nc) continue;
-                const int dx = (int)r.x0 - (int)(cx * CB), dy = (int)r.y0 - (int)(cy * CB);          // both in (-8, 8)
-                uint64_t m = dx >= 0 ? (img << dx) & (0x0101010101010101ull * (uint64_t)((0xFFu << dx) & 0xFFu))
-                                     : (img >> (-dx)) & (0x0101010101010101ull * (uint64_t)(0xFFu >> (-dx)));
-                m = dy >= 0 ? m << (8 * dy) : m >> (8 * (-dy));
-                if (m != 0ull) f(cell, m);
-            }
-        return;
-    }
     for (uint32_t cy = c0y; cy <= c1y; cy++)
         for (uint32_t cx = c0x; cx <= c1x; cx++) {
             const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
@@ -140,7 +151,11 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg,
         const uint4 rec = fpr[id];                             // the one random 16-byte gather per Gaussian of the binning stage
         if (pg.c0 == 0) fp_sorted[j] = rec;
         const Footprint fp = make_footprint(rec, tmask_hi, id);
-        for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+        Cells4 c4;
+        if (small_cells(pg, fp, c4)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicAdd(&s_cnt[c4.cell[k]], 1u);
+        } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
     }
     __syncthreads();
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) cnt[(size_t)(pg.c0 + c) * pg.nblk + blk] = s_cnt[c];
@@ -222,15 +237,29 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
         const bool have = j < j1;
         const uint32_t id = have ? order[j] : 0u;
         unsigned long long* mine = s_touch + wave * nc;
-        Footprint fp;
-        if (have) { fp = make_footprint(fp_sorted[j], tmask_hi, id); for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); }); }
+        Footprint fp; Cells4 c4; bool small = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) c4.cell[k] = -1;
+        if (have) {
+            fp = make_footprint(fp_sorted[j], tmask_hi, id);
+            small = small_cells(pg, fp, c4);
+            if (small) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicOr(&mine[c4.cell[k]], 1ull << lane);
+            } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); });
+        }
         __syncthreads();
-        if (have)
-            for_cells(pg, fp, [&](int cell, uint64_t m) {
-                uint32_t pos = s_base[cell] + (uint32_t)__popcll(mine[cell] & below);
-                for (int w = 0; w < wave; w++) pos += (uint32_t)__popcll(s_touch[w * nc + cell]);       // earlier waves = earlier ranks
-                if (pos < ccap) cent[pos] = make_uint4(id, 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
-            });
+        auto place = [&](int cell, uint64_t m) {
+            uint32_t pos = s_base[cell] + (uint32_t)__popcll(mine[cell] & below);
+            for (int w = 0; w < wave; w++) pos += (uint32_t)__popcll(s_touch[w * nc + cell]);       // earlier waves = earlier ranks
+            if (pos < ccap) cent[pos] = make_uint4(id, 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
+        };
+        if (have) {
+            if (small) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) place(c4.cell[k], c4.m[k]);
+            } else for_cells(pg, fp, place);
+        }
         __syncthreads();
         for (int c = tid; c < nc; c += PLACE_THREADS)
             s_base[c] += (uint32_t)(__popcll(s_touch[c]) + __popcll(s_touch[nc + c]) + __popcll(s_touch[2 * nc + c]) + __popcll(s_touch[3 * nc + c]));
