@@ -184,7 +184,7 @@ def load():
     return lib
 
 
-# "binning" = coarse emit + coarse sort + per-tile counts + ranges, "list_scatter" = the ids to their slots (two-level binning,
+# "binning" = coarse entries placed per cell + per-tile counts + ranges, "list_scatter" = the ids to their slots (two-level binning,
 # csrc/binning.hip); "ranges" has no kernel of its own any more (always 0)
 STAGES = ["preprocess", "depth_sort", "scan", "binning", "list_scatter", "ranges", "render_fwd", "render_bwd",
           "preprocess_bwd"]

@@ -306,7 +306,7 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name);
 #define IBGS_STAGE_PREPROCESS 0
 #define IBGS_STAGE_DEPTH_SORT 1
 #define IBGS_STAGE_SCAN 2
-#define IBGS_STAGE_EMIT 3         /* two-level binning, part 1: coarse emit + sort, per-tile counts, ranges */
+#define IBGS_STAGE_EMIT 3         /* two-level binning, part 1: coarse entries placed per cell in depth order, per-tile counts, ranges */
 #define IBGS_STAGE_TILE_SORT 4    /* two-level binning, part 2: Gaussian ids to their list slots */
 #define IBGS_STAGE_RANGES 5       /* (no kernel of its own any more) */
 #define IBGS_STAGE_RENDER_FWD 6
