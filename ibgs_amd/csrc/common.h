@@ -88,6 +88,21 @@ struct BinState {
     static BinState carve(char* base, size_t R, int W, int H, size_t* total);       // H = height of the (stacked) tile grid in pixels
 };
 
+// ---- what the blend kernels stage instead of the record's conic and alpha bound -------------------------------------------------
+// alpha = o exp(-p2 / 2) = o exp2(-(p2 * 0.5 log2 e)).  Staging a record into LDS, the blend kernels multiply its conic (a, b, c) and
+// its bound 2 ln(255 o) by 0.5 log2(e) ONCE per (Gaussian, tile); the quadratic form of the scaled conic is then the negated exponent
+// itself (exp2 with a free source negation) and the skip test compares it with the scaled bound: one multiply less per (pixel,
+// Gaussian) pair in both passes, which take the same decisions because they stage the same numbers.  The record keeps the unscaled
+// conic (bit-identical to the oracle's; preprocess_bwd reads it).
+constexpr float EXP2_SCALE = 0.5f * 1.4426950408889634f;
+constexpr float EXP2_UNSCALE = 1.0f / EXP2_SCALE;
+__device__ __forceinline__ void scale_for_exp2(float4& conic_quad, float& bound_slot)
+{
+    conic_quad.x *= EXP2_SCALE; conic_quad.y *= EXP2_SCALE; conic_quad.z *= EXP2_SCALE;
+    const uint32_t qb = __float_as_uint(bound_slot);          // bits(2 ln(255 o)) + 1, or 0 when nothing can pass (preprocess.hip)
+    bound_slot = qb ? __uint_as_float(__float_as_uint(EXP2_SCALE * __uint_as_float(qb - 1u)) + 1u) : 0.0f;
+}
+
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define IBGS_HIP(expr)                                                                    \

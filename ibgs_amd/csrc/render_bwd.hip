@@ -125,7 +125,6 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
     const size_t HW = (size_t)W * H;
-    const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E, the forward's constant
 
     float T[PPL], S[PPL];
     uint32_t ncontrib[PPL];
@@ -163,7 +162,9 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
             ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
-            s_rec[0][lane] = ra; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2];
+            float4 c1 = r[1], c2 = r[2];
+            scale_for_exp2(c1, c2.w);                          // as the forward stages them (common.h): same numbers, same decisions
+            s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = c2;
         }
         // pixels that take part: k < n_contrib.  k runs from top-1 down to top-count in this chunk and a pixel only ever
         // switches ON (at k = n_contrib - 1), so when the masks at both ends agree they hold for the whole chunk.
@@ -213,7 +214,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                         // unchanged (1 / (1 - 0) = 1 exactly) and every sum receives a zero
                         // (the select sits on o G, not on G: an inline-asm instruction must not be the first reader of a
                         // transcendental's result -- hipcc pads no wait states inside asm, cdna_hip_programming.md 5.7)
-                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(p2q[q] * NHL2E));
+                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(-p2q[q]));
                         const float alpha = min_099(oG);
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T[q] = T[q] * rinv;
@@ -247,7 +248,8 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                         const float qdx = Q[0] * dx0, qdy = Q[0] * dy0;
                         v[0] = qdx; v[1] = qdy; v[4] = qdx * dx0; v[5] = qdx * dy0; v[6] = qdy * dy0; v[7] = Q[0];
                     }
-                    v[2] = aX; v[3] = aY; v[8] = vR; v[9] = vG; v[10] = vB; v[11] = 0.f;
+                    v[2] = aX * EXP2_UNSCALE; v[3] = aY * EXP2_UNSCALE;          // conic * d was formed with the scaled conic
+                    v[8] = vR; v[9] = vG; v[10] = vB; v[11] = 0.f;
                     const float tot = wave_transpose_reduce12(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);
                     if (col >= 0) {
@@ -409,7 +411,6 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
     const size_t HW = (size_t)W * H;
-    const float NHL2E = -0.5f * 1.4426950408889634f;
 
     float T[PPL], S[PPL];
     uint32_t ncontrib[PPL], next_c[PPL], slot[PPL], pixo[PPL];
@@ -452,7 +453,9 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
             ra.w = __uint_as_float(id);
-            s_rec[0][lane] = ra; s_rec[1][lane] = r[1]; s_rec[2][lane] = r[2]; s_rec[3][lane] = r[3];
+            float4 c1 = r[1], c2 = r[2];
+            scale_for_exp2(c1, c2.w);
+            s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = c2; s_rec[3][lane] = r[3];
         }
         uint64_t ncm[PPL];
         bool stable = true;
@@ -493,7 +496,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                     Q[q] = 0.f;
                     if (okm != 0ull) {
                         any = true;
-                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(p2q[q] * NHL2E));
+                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(-p2q[q]));
                         const float alpha = min_099(oG);
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T[q] = T[q] * rinv;
@@ -545,7 +548,8 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                         const float qdx = Q[0] * dx0, qdy = Q[0] * dy0;
                         v[0] = qdx; v[1] = qdy; v[4] = qdx * dx0; v[5] = qdx * dy0; v[6] = qdy * dy0; v[7] = Q[0];
                     }
-                    v[2] = aX; v[3] = aY; v[8] = vR; v[9] = vG; v[10] = vB; v[11] = vNx; v[12] = vNy; v[13] = vNz; v[14] = vD; v[15] = 0.f;
+                    v[2] = aX * EXP2_UNSCALE; v[3] = aY * EXP2_UNSCALE;          // conic * d was formed with the scaled conic
+                    v[8] = vR; v[9] = vG; v[10] = vB; v[11] = vNx; v[12] = vNy; v[13] = vNz; v[14] = vD; v[15] = 0.f;
                     const float tot = wave_transpose_reduce16(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);
                     if (col >= 0) {

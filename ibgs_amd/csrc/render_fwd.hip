@@ -147,7 +147,6 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const float fx = (DEPTH && p.n_views > 1) ? p.fxv[view] : p.cam.fx, fy = (DEPTH && p.n_views > 1) ? p.fyv[view] : p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
     const float eps = 1.0e-8f;
-    const float NHL2E = -0.5f * 1.4426950408889634f;      // power * log2(e) = p2 * NHL2E
 
     // geo / depth-only state (PPL == 1 for GEO; DEPTH keeps running sums only plus the ring)
     float Nacc[PPL][3];
@@ -190,10 +189,11 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 const uint32_t id = p.point_list[r0 + e];
                 const float4* r = p.rec + (size_t)id * 4;
                 s_rec[0][lane] = r[0];
-                s_rec[1][lane] = r[1];
-                if (!DEPTH) s_rec[2][lane] = r[2];
+                float4 c1 = r[1], c2 = DEPTH ? r[3] : r[2];      // quad 2: rgb (colour / geo) or the normal (depth-only), .w = the alpha bound
+                scale_for_exp2(c1, c2.w);                      // conic and bound in units of the exp2 exponent (common.h)
+                s_rec[1][lane] = c1;
+                s_rec[2][lane] = c2;
                 if constexpr (GEO) s_rec[3][lane] = r[3];
-                if (DEPTH) s_rec[2][lane] = r[3];
             }
         }
         __syncthreads();
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     m &= running;
                 }
                 if (m == 0ull) continue;                              // wave-uniform: nobody sees this Gaussian
-                const float G = __builtin_amdgcn_exp2f(p2 * NHL2E);
+                const float G = __builtin_amdgcn_exp2f(-p2);          // p2 is already in exp2 units (staging above)
                 const float alpha = fminf(0.99f, q0.z * G);
                 const float aeff = __builtin_amdgcn_inverse_ballot_w64(m) ? alpha : 0.f;
                 float aT = aeff * T[q];
