@@ -88,19 +88,23 @@ struct BinState {
     static BinState carve(char* base, size_t R, int W, int H, size_t* total);       // H = height of the (stacked) tile grid in pixels
 };
 
-// ---- what the blend kernels stage instead of the record's conic and alpha bound -------------------------------------------------
-// alpha = o exp(-p2 / 2) = o exp2(-(p2 * 0.5 log2 e)).  Staging a record into LDS, the blend kernels multiply its conic (a, b, c) and
-// its bound 2 ln(255 o) by 0.5 log2(e) ONCE per (Gaussian, tile); the quadratic form of the scaled conic is then the negated exponent
-// itself (exp2 with a free source negation) and the skip test compares it with the scaled bound: one multiply less per (pixel,
-// Gaussian) pair in both passes, which take the same decisions because they stage the same numbers.  The record keeps the unscaled
-// conic (bit-identical to the oracle's; preprocess_bwd reads it).
+// ---- what the blend kernels stage instead of the record's conic and opacity ------------------------------------------------------
+// alpha = o exp(-p2 / 2) = exp2(-(p2 * 0.5 log2 e - log2 o)).  Staging a record into LDS, the blend kernels multiply its conic
+// (a, b, c) by 0.5 log2(e) and replace the opacity by -log2(o), ONCE per (Gaussian, tile).  The lane's quadratic form is started from
+// that offset (an fma instead of a mul), so what the inner loop holds per pixel is E = -log2(alpha before the 0.99 clamp):
+//   alpha      = min(0.99, exp2(-E))             (exp2 with a free source negation: no multiply by o, none by log2 e)
+//   skip test  : alpha >= 1/255  <=>  E <= log2(255), ONE compare against a constant (forward.cu:420-425 tests power > 0 and
+//                alpha < 1/255; power <= 0 holds for every positive definite conic up to rounding noise, and where that noise makes the
+//                reference's own formula positive it skips a pixel at the very centre line of a needle-shaped Gaussian -- not reproduced)
+// Two multiplies less per (pixel, Gaussian) pair in both passes, which take the same decisions because they stage the same numbers.
+// The record keeps the unscaled conic and the opacity (bit-identical to the oracle's; preprocess_bwd reads them).
 constexpr float EXP2_SCALE = 0.5f * 1.4426950408889634f;
 constexpr float EXP2_UNSCALE = 1.0f / EXP2_SCALE;
-__device__ __forceinline__ void scale_for_exp2(float4& conic_quad, float& bound_slot)
+constexpr float ALPHA_SKIP_E = 7.9943533f;                    // log2(255): E above this = alpha below 1/255
+__device__ __forceinline__ void stage_for_exp2(float4& pos_opacity_quad, float4& conic_quad)
 {
     conic_quad.x *= EXP2_SCALE; conic_quad.y *= EXP2_SCALE; conic_quad.z *= EXP2_SCALE;
-    const uint32_t qb = __float_as_uint(bound_slot);          // bits(2 ln(255 o)) + 1, or 0 when nothing can pass (preprocess.hip)
-    bound_slot = qb ? __uint_as_float(__float_as_uint(EXP2_SCALE * __uint_as_float(qb - 1u)) + 1u) : 0.0f;
+    pos_opacity_quad.z = -__builtin_amdgcn_logf(pos_opacity_quad.z);          // v_log_f32 = log2; o = 0 -> +inf -> never passes
 }
 
 // ---- error plumbing -------------------------------------------------------------------------

@@ -223,13 +223,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
                 rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
                 depth = zview;
                 rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
-                {   // alpha = o exp(-p2/2) >= 1/255  <=>  p2 <= 2 ln(255 o): the blend kernels test the quadratic form against
-                    // this bound (as an unsigned compare of the float bits, "bits(p2) < bound") before they spend an exp on it.
-                    // Stored as bits(2 ln(255 o)) + 1, or 0 when no pixel can pass (255 o < 1).
-                    const float qm = 2.0f * logf(255.0f * p.opacities[i]);
-                    const float qb = __uint_as_float((qm >= 0.0f) ? __float_as_uint(qm) + 1u : 0u);
-                    rec[R_PAD1] = qb; rec[R_PAD2] = qb;      // quad 2 (colour / geo passes) and quad 3 (depth-only pass stages the normal quad)
-                }
                 rec[R_CA] = cc * det_inv; rec[R_CB] = -cb * det_inv; rec[R_CC] = ca * det_inv;
                 if (p.colors_precomp) {
                     rec[R_R] = p.colors_precomp[3 * i]; rec[R_G] = p.colors_precomp[3 * i + 1]; rec[R_B] = p.colors_precomp[3 * i + 2];

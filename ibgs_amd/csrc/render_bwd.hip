@@ -26,8 +26,8 @@
 //   * geo: the median / warp block (B2) runs as a pixel-parallel pre-pass that leaves a per-pixel table; the blend loop only
 //     looks entries up (geo_window_kernel below).
 //
-// Deviations (documented in DESIGN.md): the skip tests are the forward's single compare of p2 against the per-Gaussian
-// bound 2 ln(255 o) (render_fwd.hip), so both passes visit exactly the same (pixel, Gaussian) pairs; alpha is recomputed with the
+// Deviations (documented in DESIGN.md): the skip test is the forward's single compare E <= log2(255) on the same staged numbers
+// (render_fwd.hip, common.h), so both passes visit exactly the same (pixel, Gaussian) pairs; alpha is recomputed with the
 // same fast exp2 as the forward (the reference uses __expf forward / exp backward); 1/(1-alpha) is the hardware
 // reciprocal (1 ulp) instead of an IEEE division.
 #include "common.h"
@@ -162,9 +162,9 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
             ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
-            float4 c1 = r[1], c2 = r[2];
-            scale_for_exp2(c1, c2.w);                          // as the forward stages them (common.h): same numbers, same decisions
-            s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = c2;
+            float4 c1 = r[1];
+            stage_for_exp2(ra, c1);                            // as the forward stages them (common.h): same numbers, same decisions
+            s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = r[2];
         }
         // pixels that take part: k < n_contrib.  k runs from top-1 down to top-count in this chunk and a pixel only ever
         // switches ON (at k = n_contrib - 1), so when the masks at both ends agree they hold for the whole chunk.
@@ -181,13 +181,12 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
             for (int j = 0; j < count; j++) {
                 const uint32_t k = (uint32_t)(top - 1 - j);          // 0-based position in the tile list
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
-                const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
-                const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
+                const float ca = q1.x, cb = q1.y, cc = q1.z, nlo = q0.z;          // scaled conic, -log2(opacity)
                 // same evaluation of p2 = d^T conic d as the forward (render_fwd.hip): once per lane, shifted to the
                 // other three quadrants, so both passes take identical alpha decisions
                 const float dx0 = q0.x - pxf0, dy0 = q0.y - pyf0;
                 const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
-                const float P0 = dx0 * lx0 + dy0 * ly0;
+                const float P0 = fmaf(dx0, lx0, fmaf(dy0, ly0, nlo));          // the forward's E (render_fwd.hip)
                 float p2q[PPL], lxq[PPL], lyq[PPL];
                 p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
                 if constexpr (PPL >= 2) {
@@ -204,17 +203,17 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                 bool any = false;
 #pragma unroll
                 for (int q = 0; q < PPL; q++) {
-                    // the forward's test: 0 <= p2 <= 2 ln(255 o) as one unsigned compare of the float bits (render_fwd.hip)
+                    // the forward's test: E <= log2(255) (render_fwd.hip, common.h)
                     const uint64_t live = STABLE ? ncm[q] : __builtin_amdgcn_ballot_w64(k < ncontrib[q]);
-                    const uint64_t okm = live & __builtin_amdgcn_ballot_w64(__float_as_uint(p2q[q]) < qbound);
+                    const uint64_t okm = live & __builtin_amdgcn_ballot_w64(p2q[q] <= ALPHA_SKIP_E);
                     Q[q] = 0.f;
                     if (okm != 0ull) {
                         any = true;
                         // lanes that fail the test run the same instructions with G = 0: alpha = 0 leaves T and S
                         // unchanged (1 / (1 - 0) = 1 exactly) and every sum receives a zero
-                        // (the select sits on o G, not on G: an inline-asm instruction must not be the first reader of a
-                        // transcendental's result -- hipcc pads no wait states inside asm, cdna_hip_programming.md 5.7)
-                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(-p2q[q]));
+                        // (exp2(-E) = o G.  The select is inline asm and the first reader of the transcendental's result: it carries its own
+                        // wait state -- hipcc pads none inside asm, cdna_hip_programming.md 5.7)
+                        const float oG = select_or_zero_after_trans(okm, __builtin_amdgcn_exp2f(-p2q[q]));
                         const float alpha = min_099(oG);
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T[q] = T[q] * rinv;
@@ -453,9 +452,9 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
             ra.w = __uint_as_float(id);
-            float4 c1 = r[1], c2 = r[2];
-            scale_for_exp2(c1, c2.w);
-            s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = c2; s_rec[3][lane] = r[3];
+            float4 c1 = r[1];
+            stage_for_exp2(ra, c1);
+            s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = r[2]; s_rec[3][lane] = r[3];
         }
         uint64_t ncm[PPL];
         bool stable = true;
@@ -470,11 +469,10 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
             for (int j = 0; j < count; j++) {
                 const uint32_t k = (uint32_t)(top - 1 - j);
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j];
-                const float ca = q1.x, cb = q1.y, cc = q1.z, op = q0.z;
-                const uint32_t qbound = __float_as_uint(q2.w);
+                const float ca = q1.x, cb = q1.y, cc = q1.z, nlo = q0.z;          // scaled conic, -log2(opacity)
                 const float dx0 = q0.x - pxf0, dy0 = q0.y - pyf0;
                 const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
-                const float P0 = dx0 * lx0 + dy0 * ly0;
+                const float P0 = fmaf(dx0, lx0, fmaf(dy0, ly0, nlo));          // the forward's E (render_fwd.hip)
                 float p2q[PPL], lxq[PPL], lyq[PPL];
                 p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
                 if constexpr (PPL >= 2) {
@@ -492,11 +490,11 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
 #pragma unroll
                 for (int q = 0; q < PPL; q++) {
                     const uint64_t live = STABLE ? ncm[q] : __builtin_amdgcn_ballot_w64(k < ncontrib[q]);
-                    const uint64_t okm = live & __builtin_amdgcn_ballot_w64(__float_as_uint(p2q[q]) < qbound);
+                    const uint64_t okm = live & __builtin_amdgcn_ballot_w64(p2q[q] <= ALPHA_SKIP_E);
                     Q[q] = 0.f;
                     if (okm != 0ull) {
                         any = true;
-                        const float oG = select_or_zero(okm, op * __builtin_amdgcn_exp2f(-p2q[q]));
+                        const float oG = select_or_zero_after_trans(okm, __builtin_amdgcn_exp2f(-p2q[q]));
                         const float alpha = min_099(oG);
                         const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T[q] = T[q] * rinv;

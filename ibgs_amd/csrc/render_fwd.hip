@@ -12,8 +12,9 @@
 //     per-lane loads and read back as wave-uniform broadcasts (ds_read_b128), i.e. 3 LDS reads per
 //     Gaussian per 256 pixels.
 //   * Each quadrant is skipped with a wave-uniform branch when no lane passes the alpha test (ballot), which
-//     recovers 8x8 sub-tile culling.  The test itself is one unsigned compare of the quadratic form's float bits
-//     against a per-Gaussian bound (0 <= p2 <= 2 ln(255 o), from preprocess): no exp for pairs that fail.  "Pixel still blending" is a
+//     recovers 8x8 sub-tile culling.  What a lane holds per pixel is E = -log2(o G) (conic staged in exp2 units, the quadratic form
+//     started from -log2 o, common.h); the test is the one compare E <= log2(255): no exp for pairs that fail, and alpha is
+//     min(0.99, exp2(-E)) without a multiply.  "Pixel still blending" is a
 //     64-bit lane mask kept in SGPRs (one per quadrant): masks are combined on the scalar unit and
 //     turned back into predicates with inverse_ballot, so the blend itself is branch-free VALU code and
 //     a finished quadrant costs one scalar compare per Gaussian.
@@ -188,11 +189,11 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             if (e < n) {
                 const uint32_t id = p.point_list[r0 + e];
                 const float4* r = p.rec + (size_t)id * 4;
-                s_rec[0][lane] = r[0];
-                float4 c1 = r[1], c2 = DEPTH ? r[3] : r[2];      // quad 2: rgb (colour / geo) or the normal (depth-only), .w = the alpha bound
-                scale_for_exp2(c1, c2.w);                      // conic and bound in units of the exp2 exponent (common.h)
+                float4 c0 = r[0], c1 = r[1];
+                stage_for_exp2(c0, c1);                        // conic in units of the exp2 exponent, opacity as -log2 (common.h)
+                s_rec[0][lane] = c0;
                 s_rec[1][lane] = c1;
-                s_rec[2][lane] = c2;
+                s_rec[2][lane] = DEPTH ? r[3] : r[2];          // rgb (colour / geo) or the normal (depth-only)
                 if constexpr (GEO) s_rec[3][lane] = r[3];
             }
         }
@@ -205,7 +206,6 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];          // normal
             const int e = base + j;
-            const uint32_t qbound = __float_as_uint(q2.w);          // bits(2 ln(255 o)) + 1, see preprocess.hip
             // 1-based list position as ONE vector register per Gaussian (opaque to the optimiser, which otherwise re-materialises
             // the scalar -> vector move inside every quadrant's branch)
             uint32_t e1v = (uint32_t)(e + 1);
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             // p2(d - s) = p2(d) - 2 s^T conic d + s^T conic s -- 14 VALU ops for four pixels instead of 32.
             const float dx0 = q0.x - pxf[0], dy0 = q0.y - pyf[0];
             const float lx0 = q1.x * dx0 + q1.y * dy0, ly0 = q1.y * dx0 + q1.z * dy0;
-            const float P0 = dx0 * lx0 + dy0 * ly0;
+            const float P0 = fmaf(dx0, lx0, fmaf(dy0, ly0, q0.z));          // E = -log2(o G) of the lane's quadrant-0 pixel (common.h)
             float p2q[PPL];
             p2q[0] = P0;
             if (PPL >= 2) p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * q1.x);
@@ -227,18 +227,15 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             for (int q = 0; q < PPL; q++) {
                 if (live[q] == 0ull) continue;                        // wave-uniform: quadrant finished
                 const float p2 = p2q[q];                              // = -2 * power
-                // "power > 0" (p2 < 0) and "alpha < 1/255" (p2 > 2 ln(255 o)) in ONE unsigned compare of the float bits against
-                // the per-Gaussian bound from preprocess: a negative p2 has the sign bit set and compares as huge.  No exp, no
-                // multiply for quadrants that nobody passes.
-                uint64_t m = __builtin_amdgcn_ballot_w64(__float_as_uint(p2) < qbound) & live[q];
+                // "alpha < 1/255" as ONE compare of E against log2(255) (common.h).  No exp for quadrants that nobody passes.
+                uint64_t m = __builtin_amdgcn_ballot_w64(p2 <= ALPHA_SKIP_E) & live[q];
                 if (DEPTH) {
                     const uint64_t running = __builtin_amdgcn_ballot_w64(e >= resume[q]) & live[q];
                     if (__builtin_amdgcn_inverse_ballot_w64(running)) cnt[q]++;
                     m &= running;
                 }
                 if (m == 0ull) continue;                              // wave-uniform: nobody sees this Gaussian
-                const float G = __builtin_amdgcn_exp2f(-p2);          // p2 is already in exp2 units (staging above)
-                const float alpha = fminf(0.99f, q0.z * G);
+                const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-p2));
                 const float aeff = __builtin_amdgcn_inverse_ballot_w64(m) ? alpha : 0.f;
                 float aT = aeff * T[q];
                 float test_T = T[q] * (1.0f - aeff);

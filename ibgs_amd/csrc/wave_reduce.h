@@ -19,6 +19,15 @@ __device__ __forceinline__ float select_or_zero(unsigned long long mask, float x
     return r;
 }
 
+// The same, for an x that comes straight out of a transcendental (v_exp_f32 ...): hipcc pads no wait states inside inline asm, and a
+// non-transcendental reader of a transcendental's result needs one (cdna_hip_programming.md 5.7) -- the s_nop supplies it.
+__device__ __forceinline__ float select_or_zero_after_trans(unsigned long long mask, float x)
+{
+    float r;
+    asm("s_nop 0\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+
 // min(0.99, x) as one instruction: across a basic-block boundary hipcc puts a canonicalising v_max_f32 x, x in front
 // of fminf (MI355X_MICROARCH.md, "canonicalising v_max").  NaN in -> 0.99 out, like fminf.
 __device__ __forceinline__ float min_099(float x)
