@@ -127,6 +127,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
     const size_t HW = (size_t)W * H;
 
     float T[PPL], S[PPL];
+    const bool bg0 = p.cam.bg[0] == 0.f && p.cam.bg[1] == 0.f && p.cam.bg[2] == 0.f;      // wave-uniform (scalar loads)
     uint32_t ncontrib[PPL];
     uint32_t nmax = 0;
     const float pxf0 = (float)(tx0 + (quad0 & 1) * 8 + (lane & 7)), pyf0 = (float)(ty0 + (quad0 >> 1) * 8 + (lane >> 3));
@@ -176,8 +177,9 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
             stable = stable && (ncm[q] == __builtin_amdgcn_ballot_w64((uint32_t)(top - 1) < ncontrib[q]));
         }
         __syncthreads();
-        auto chunk = [&](auto stable_tag) {
+        auto chunk = [&](auto stable_tag, auto bg0_tag) {
             constexpr bool STABLE = decltype(stable_tag)::value;
+            constexpr bool BG0 = decltype(bg0_tag)::value;          // black background: the -T_final (bg . g) / (1 - alpha) term is zero
             for (int j = 0; j < count; j++) {
                 const uint32_t k = (uint32_t)(top - 1 - j);          // 0-based position in the tile list
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j];
@@ -226,7 +228,8 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                         float dL_dalpha = cg - S[q];
                         S[q] = fmaf(alpha, dL_dalpha, S[q]);
                         vR = fmaf(w, gp.x, vR); vG = fmaf(w, gp.y, vG); vB = fmaf(w, gp.z, vB);
-                        dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);          // ... - T_final (bg . g) / (1 - alpha)
+                        if constexpr (BG0) dL_dalpha = dL_dalpha * T[q];
+                        else dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);      // ... - T_final (bg . g) / (1 - alpha)
                         const float qv = oG * dL_dalpha;                          // dL/dG * G
                         Q[q] = qv;
                         aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);      // |a b| = |a| |b|: one v_fma with source modifiers
@@ -258,7 +261,8 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                 }
             }
         };
-        if (stable) chunk(std::true_type{}); else chunk(std::false_type{});
+        if (bg0) { if (stable) chunk(std::true_type{}, std::true_type{}); else chunk(std::false_type{}, std::true_type{}); }
+        else { if (stable) chunk(std::true_type{}, std::false_type{}); else chunk(std::false_type{}, std::false_type{}); }
         __syncthreads();
         top -= count;
     }
