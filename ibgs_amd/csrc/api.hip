@@ -346,10 +346,12 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     if (a.P <= 0) return 0;                                       // rasterize_points.cu:221
     if (!a.geom || !a.img || (!a.binning && a.R > 0)) { set_error("backward needs the forward's arenas"); return -IBGS_ERR_INVALID; }
     if (!a.grad_acc) { set_error("grad_acc scratch required"); return -IBGS_ERR_INVALID; }
-    if (!a.dL_dmean2D || !a.dL_dmean2D_abs || !a.dL_dopacity || !a.dL_dcolors || !a.dL_dmean3D || !a.dL_dcov3D) {
+    if (!a.dL_dmean2D || !a.dL_dmean2D_abs || !a.dL_dopacity || !a.dL_dmean3D) {
         set_error("missing gradient output"); return -IBGS_ERR_INVALID;
     }
     if (a.shs && !a.dL_dsh && !(a.flags & IBGS_FLAG_SH_FACTORED)) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
+    if (!a.dL_dcolors && (!a.shs || (a.flags & IBGS_FLAG_SH_FACTORED))) { set_error("dL_dcolors required (precomputed colours, or IBGS_FLAG_SH_FACTORED)"); return -IBGS_ERR_INVALID; }
+    if (!a.dL_dcov3D && a.cov3D_precomp) { set_error("dL_dcov3D required with cov3D_precomp"); return -IBGS_ERR_INVALID; }
     if (a.scales && (!a.dL_dscale || !a.dL_drot)) { set_error("dL_dscale / dL_drot required"); return -IBGS_ERR_INVALID; }
     if (a.render_geo) {
         if (a.plane_mode == IBGS_PLANE_NONE ? (!a.all_map || !a.dL_dall_map)

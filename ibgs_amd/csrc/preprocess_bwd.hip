@@ -95,12 +95,12 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         p.dL_dmean2D_abs[3 * i] = 0.f; p.dL_dmean2D_abs[3 * i + 1] = 0.f; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
         if (p.dL_dconic) { p.dL_dconic[4 * i] = 0.f; p.dL_dconic[4 * i + 1] = 0.f; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = 0.f; }
         p.dL_dopacity[i] = 0.f;
-        p.dL_dcolors[3 * i] = 0.f; p.dL_dcolors[3 * i + 1] = 0.f; p.dL_dcolors[3 * i + 2] = 0.f;
+        if (p.dL_dcolors) { p.dL_dcolors[3 * i] = 0.f; p.dL_dcolors[3 * i + 1] = 0.f; p.dL_dcolors[3 * i + 2] = 0.f; }
         if (p.dL_dall_map) for (int k = 0; k < 5; k++) p.dL_dall_map[5 * i + k] = 0.f;
         if (p.dL_dplane_normal) { p.dL_dplane_normal[3 * i] = 0.f; p.dL_dplane_normal[3 * i + 1] = 0.f; p.dL_dplane_normal[3 * i + 2] = 0.f; }
         if (p.dL_dplane_offset) p.dL_dplane_offset[i] = 0.f;
         p.dL_dmean3D[3 * i] = 0.f; p.dL_dmean3D[3 * i + 1] = 0.f; p.dL_dmean3D[3 * i + 2] = 0.f;
-        for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
+        if (p.dL_dcov3D) for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
         if (!FAST16 && WRITE_SH && p.shs) { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
         if (p.scales) {
             p.dL_dscale[3 * i] = 0.f; p.dL_dscale[3 * i + 1] = 0.f; p.dL_dscale[3 * i + 2] = 0.f;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     p.dL_dmean2D_abs[3 * i] = ddelx_dx * g0.z; p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * g0.w; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
     if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }
     p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
-    if (WRITE_SH || !p.shs) { p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2]; }
+    if ((WRITE_SH || !p.shs) && p.dL_dcolors) { p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2]; }
     if (p.dL_dall_map) {
         p.dL_dall_map[5 * i] = g2.w; p.dL_dall_map[5 * i + 1] = g3.x; p.dL_dall_map[5 * i + 2] = g3.y;
         p.dL_dall_map[5 * i + 3] = 0.f; p.dL_dall_map[5 * i + 4] = g3.z;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         gS[4] = 2 * A[0][2] * A[0][1] * da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * db + 2 * A[1][1] * A[1][2] * dc;
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = gS[k];
+    for (int k = 0; k < 6; k++) if (p.dL_dcov3D) p.dL_dcov3D[6 * i + k] = gS[k];
     float dA[2][3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {

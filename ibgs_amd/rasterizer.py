@@ -323,7 +323,7 @@ class _CModule:
                                      src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
                                      dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None):
+                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False):
         """The reference's 34 positional arguments and 10 results; with `plane` (see rasterize_gaussians) two more
         results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1)."""
         lib = _lib.load()
@@ -340,7 +340,7 @@ class _CModule:
             have_sr = scales is not None and scales.numel() != 0
             new = torch.empty if P != 0 else torch.zeros
             dL_dmeans3D = new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
-            dL_dmeans2D_abs = new(P, 3, **opts); dL_dcolors = new(P, NUM_CHANNELS, **opts)
+            dL_dmeans2D_abs = new(P, 3, **opts)
             # gradients of inputs the mode does not use: zeros without a fill (the reference memsets them, rasterize_points.cu:196-206)
             fused = plane is not None and bool(plane[2])
             dL_dall_map = new(P, NUM_PLANE_PARAMS, **opts) if (render_geo and all_maps.numel() != 0 and P != 0 and not fused) else _zeros_view((P, NUM_PLANE_PARAMS), device)
@@ -350,8 +350,14 @@ class _CModule:
                 want = render_geo and P != 0
                 dL_dplane_normal = (new(P, 3, **opts) if want else _zeros_view((P, 3), device)) if (learnt and plane[0] is not None) else None
                 dL_dplane_offset = (new(P, 1, **opts) if want else _zeros_view((P, 1), device)) if (learnt and plane[1] is not None) else None
-            dL_dopacity = new(P, 1, **opts); dL_dcov3D = new(P, 6, **opts)
+            dL_dopacity = new(P, 1, **opts)
             factored = _sh_factor_sink is not None and M != 0 and P != 0
+            # skip_unused (the autograd node sets it): dL/dcolors and dL/dcov3D are the gradients of colors_precomp / cov3D_precomp -- with
+            # SH coefficients and scales + rotations as inputs nobody reads them (the reference writes them regardless, 36 B per Gaussian)
+            want_colors = not skip_unused or factored or M == 0 or (colors is not None and colors.numel() != 0)
+            want_cov = not skip_unused or not have_sr
+            dL_dcolors = new(P, NUM_CHANNELS, **opts) if want_colors else _zeros_view((P, NUM_CHANNELS), device)
+            dL_dcov3D = new(P, 6, **opts) if want_cov else _zeros_view((P, 6), device)
             dL_dsh = None if factored else new(P, M, 3, **opts)
             dL_dscales = new(P, 3, **opts) if (have_sr and P != 0) else _zeros_view((P, 3), device)
             dL_drotations = new(P, 4, **opts) if (have_sr and P != 0) else _zeros_view((P, 4), device)
@@ -402,8 +408,8 @@ class _CModule:
                 a.grad_acc = grad_acc.data_ptr()
                 a.dL_dmean2D = dL_dmeans2D.data_ptr(); a.dL_dmean2D_abs = dL_dmeans2D_abs.data_ptr()
                 a.dL_dconic = None
-                a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr()
-                a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr()
+                a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr() if want_colors else None
+                a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr() if want_cov else None
                 a.dL_dsh = dL_dsh.data_ptr() if (M and not factored) else None
                 a.dL_dscale = dL_dscales.data_ptr() if have_sr else None; a.dL_drot = dL_drotations.data_ptr() if have_sr else None
                 a.dL_dall_map = dL_dall_map.data_ptr() if (render_geo and all_maps.numel() != 0 and not fused) else None
@@ -586,6 +592,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             kw["plane"] = (plane_normal if plane_normal.numel() else None, plane_offset if plane_offset.numel() else None, ctx.plane_mode)
         if getattr(ctx, "packed_tex", None) is not None:
             kw["packed_tex"] = ctx.packed_tex
+        kw["skip_unused"] = True
 
         # argument order of the reference's _C.rasterize_gaussians_backward (reference __init__.py:182-221)
         args = (raster_settings.bg, normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels,

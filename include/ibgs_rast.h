@@ -206,9 +206,9 @@ typedef struct ibgs_backward_args {
     float* dL_dmean2D_abs; /* P x 3 */
     float* dL_dconic;      /* P x 4 (x,y,w used) */
     float* dL_dopacity;    /* P */
-    float* dL_dcolors;     /* P x 3 */
+    float* dL_dcolors;     /* P x 3; may be NULL when shs is given without IBGS_FLAG_SH_FACTORED (it is the gradient of colors_precomp) */
     float* dL_dmean3D;     /* P x 3 */
-    float* dL_dcov3D;      /* P x 6 */
+    float* dL_dcov3D;      /* P x 6; may be NULL when scales + rotations are given (it is the gradient of cov3D_precomp) */
     float* dL_dsh;         /* P x M x 3 */
     float* dL_dscale;      /* P x 3 */
     float* dL_drot;        /* P x 4 */
