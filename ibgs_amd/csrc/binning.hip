@@ -263,6 +263,7 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
         __syncthreads();
         for (int c = tid; c < nc; c += PLACE_THREADS)
             s_base[c] += (uint32_t)(__popcll(s_touch[c]) + __popcll(s_touch[nc + c]) + __popcll(s_touch[2 * nc + c]) + __popcll(s_touch[3 * nc + c]));
+        __syncthreads();                                   // (blocks of more than 256 ranks: the next round clears the lane words)
     }
 }
 

@@ -174,6 +174,19 @@ def test_mid_size_rectangles_are_culled_by_the_whole_wave():
     assert np.array_equal(ist["tiles"], ref["tiles_touched"])
 
 
+def test_many_small_gaussians_on_a_large_frame():
+    """P / 256 blocks of depth ranks do not fit the placement's count matrix when R is small and the frame has many cells (its share of
+    the binning arena follows R): the blocks then span 512 or more ranks and the place kernel runs several rounds per block.  Lists
+    must equal the oracle's bit for bit."""
+    from ibgs_amd import _lib
+    inp = scene(P=200000, W=1920, H=1088, deg=0, seed=61, opacity="trained", scale_mul=0.08)
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, 1088, 1920), 5)}, cull=True)
+    R = int(ref["num_rendered"])
+    ncells = ((1920 // 16 + 7) // 8) * ((1088 // 16 + 7) // 8)
+    assert (200000 + 255) // 256 > (max(R // 4, 65536) + ncells) // ncells, ("the case must force blocks of more than 256 ranks", R)
+    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
 def test_precomputed_colour_and_covariance_inputs():
     inp = scene(P=1500, deg=0, seed=4, opacity="trained")
     f0 = oracle.forward(inp)
