@@ -83,10 +83,14 @@ def profile_counters(kernel_substr, workload_tag):
 
 class Workload:
     """One view of one BASELINE config resident on `dev`: leaves, settings, the step closure."""
+    CLUSTER = 0.0
 
     def __init__(self, cfg, view, dev, opacity, geo, forward_only, target_seed):
         c = syn.CONFIGS[cfg]
         inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"], view=view, opacity=opacity)
+        if Workload.CLUSTER > 0:
+            k = int(Workload.CLUSTER * c["P"])
+            inp["means3D"] = inp["means3D"].copy(); inp["means3D"][:k] = inp["means3D"][:k] * 0.3 + np.array([0.5, 0.25, 0.0], np.float32)
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
         P, H, W = c["P"], c["H"], c["W"]
         self.c, self.cfg, self.inp, self.geo, self.forward_only, self.dev = c, cfg, inp, geo, forward_only, dev
@@ -169,7 +173,8 @@ class Workload:
         c = self.c
         return "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, opacity=%s%s, one view per GPU%s" % (
             self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target",
-            opacity, ", render_geo n_src=4 L=4" if self.geo else "", (", RCCL gradient exchange (%s)" % exchange) if world > 1 else "")
+            opacity + ((", %g of the Gaussians in one blob" % Workload.CLUSTER) if Workload.CLUSTER > 0 else ""),
+            ", render_geo n_src=4 L=4" if self.geo else "", (", RCCL gradient exchange (%s)" % exchange) if world > 1 else "")
 
 
 def fence(world):
@@ -323,6 +328,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3", choices=list(syn.CONFIGS))
     ap.add_argument("--opacity", default="init", choices=["init", "trained"])
+    ap.add_argument("--cluster", type=float, default=0.0,
+                    help="NOT the BASELINE workload: move this fraction of the Gaussians into one blob (a non-uniform image: what the tile -> XCD "
+                         "mapping and the binning must cope with in real scenes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="factored", choices=["factored", "dense"],
                     help="N > 1: factored = all-gather 3-float dL/dRGB per view + local SH expansion (default); dense = all-reduce of every gradient")
@@ -354,6 +362,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     _lib.load()
 
+    Workload.CLUSTER = a.cluster
     wl = Workload(a.config, rank % 8, dev, a.opacity, a.geo, a.forward_only, 1234 + rank)
     reducer = None
     if world > 1:
@@ -409,7 +418,8 @@ def main():
         del gwl
 
     if rank == 0:
-        tag = "%s%s%s opacity=%s" % (a.config, " geo" if a.geo else "", " forward-only" if a.forward_only else "", a.opacity)
+        tag = "%s%s%s opacity=%s%s" % (a.config, " geo" if a.geo else "", " forward-only" if a.forward_only else "", a.opacity,
+                                       (" cluster=%g" % a.cluster) if a.cluster > 0 else "")
         rf = roofline(wl, m, tag)
         out = {
             "metric": ("forward render fps " + a.config) if a.forward_only else

@@ -78,11 +78,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-__device__ __forceinline__ int xcd_band_map_b(int b, int n)
-{
-    const int per = (n + 7) >> 3;
-    return (b & 7) * per + (b >> 3);
-}
+__device__ __forceinline__ int tile_of_block_b(int b, int n) { (void)n; return b; }          // round-robin over the XCDs, see render_fwd.hip
 
 __device__ __forceinline__ float fast_rcp(float x)
 {   // v_rcp_f32 (1 ulp) + one Newton step
@@ -118,7 +114,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
     if (col >= 11) col = -1;
     constexpr int IPT = 4 / PPL;
     const int nitems = p.ntiles * IPT;
-    const int item = xcd_band_map_b(blockIdx.x, nitems);
+    const int item = tile_of_block_b(blockIdx.x, nitems);
     if (item >= nitems) return;
     const int tile = item / IPT;
     const int quad0 = (item % IPT) * PPL;
@@ -407,7 +403,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
     if (col >= 15) col = -1;
     constexpr int IPT = 4 / PPL;
     const int nitems = p.ntiles * IPT;
-    const int item = xcd_band_map_b(blockIdx.x, nitems);
+    const int item = tile_of_block_b(blockIdx.x, nitems);
     if (item >= nitems) return;
     const int tile = item / IPT;
     const int quad0 = (item % IPT) * PPL;

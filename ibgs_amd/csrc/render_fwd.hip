@@ -95,13 +95,11 @@ __device__ __forceinline__ float tex_depth(const float* __restrict__ img, int W,
     return (1.f - a) * (1.f - b) * t00 + a * (1.f - b) * t10 + (1.f - a) * b * t01 + a * b * t11;
 }
 
-// XCD-aware block -> work item map: consecutive block ids are dealt round-robin to the 8 XCDs, so
-// give every XCD one contiguous band of tiles (neighbouring tiles share Gaussian records in L2).
-__device__ __forceinline__ int xcd_band_map(int b, int n)
-{
-    const int per = (n + 7) >> 3;
-    return (b & 7) * per + (b >> 3);
-}
+// Block -> work item: the identity.  Consecutive workgroups are dealt round-robin to the 8 XCDs, so neighbouring tiles land on
+// different XCDs and a dense region of the image is spread over the whole chip.  (Round 1 gave every XCD a contiguous band of tiles so
+// that neighbours share Gaussian records in one L2: no faster on the uniform C3 scene -- the blend is VALU-bound -- and 5 % (forward) /
+// 9 % (backward) slower when half of the Gaussians sit in one blob, `bench.py --cluster 0.5`: the XCDs that own the blob finish last.)
+__device__ __forceinline__ int tile_of_block(int b, int n) { (void)n; return b; }
 
 // MAXL = compile-time capacity of the per-pixel median buffer (4 covers the reference's default
 // buffer_length = 4 with half the select chains of 8).
@@ -116,7 +114,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const int lane = threadIdx.x;
     constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
     const int nitems = p.ntiles * IPT;
-    const int item = xcd_band_map(blockIdx.x, nitems);
+    const int item = tile_of_block(blockIdx.x, nitems);
     if (item >= nitems) return;
     const int tile = item / IPT;
     const int quad0 = (item % IPT) * PPL;
