@@ -281,3 +281,36 @@ def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, gro
         gn, gna, cnt = packed[:, 0:1], packed[:, 1:2], packed[:, 2:3]
         dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
     return gn, gna, cnt, rmax
+
+
+# ---- densification on replicated parameters ---------------------------------------------------------------------------
+# Every rank runs densify_and_prune itself on its replica.  The decisions (which points to clone / split / prune) are functions of the
+# reduced statistics above, so they agree; what does NOT agree by itself are the random samples of densify_and_split
+# (`torch.normal(mean=means, std=stds)`, scene/gaussian_model.py:498-502, 562-566) -- every process has its own generator state.
+def seed_for_densification(iteration, base_seed=0, devices=None):
+    """Give every rank the SAME generator state before a densification step: seeds torch's CPU generator and the generators of
+    `devices` (default: the current HIP device, if any) with a value that depends only on (base_seed, iteration).  Call it on every rank
+    right before `gaussians.densify_and_prune(...)`; the replicas then draw identical samples and stay bit-identical."""
+    seed = (int(base_seed) * 1000003 + int(iteration)) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        for d in (devices if devices is not None else [torch.cuda.current_device()]):
+            torch.cuda.manual_seed(seed) if d == torch.cuda.current_device() else torch.cuda.default_generators[d].manual_seed(seed)
+    return seed
+
+
+def assert_replicas_identical(tensors, group=None, what="parameters"):
+    """Cheap guard for the replicated-parameter invariant: one all-reduce (MIN and MAX) of a float64 checksum and the element count per
+    tensor.  Raises on EVERY rank when any replica differs (e.g. a densification that ran with unsynchronised generators)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    vals = []
+    for t in _resolve(tensors):
+        vals += [t.detach().double().sum().reshape(1), torch.tensor([float(t.numel())], dtype=torch.float64, device=t.device)]
+    cs = torch.cat([v.to(vals[0].device) for v in vals])
+    lo, hi = cs.clone(), cs.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        bad = [i // 2 for i in range(0, cs.numel(), 2) if not (lo[i] == hi[i] and lo[i + 1] == hi[i + 1])]
+        raise RuntimeError("view-parallel replicas diverged: %s %s differ between ranks (unsynchronised densification?)" % (what, bad))

@@ -215,3 +215,32 @@ def test_reducer_never_diverges_or_hangs(tmp_path):
         assert "ranks disagree" in r["d"], r["d"]
         assert "no tensor in `params` has a gradient" in r["e"], r["e"]
     assert torch.equal(res[0]["b"]["sh"], res[1]["b"]["sh"])
+
+
+# ---- densification on replicas: identical random samples on every rank, and a guard that notices when they are not ----------------
+def _densify_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init_from_env(backend="gloo")
+    torch.manual_seed(1000 + rank)                      # ranks arrive with different generator states, as in a real run
+    _ = torch.rand(3 + rank)
+    base = torch.arange(12, dtype=torch.float32).reshape(4, 3)
+    vdist.seed_for_densification(iteration=700, base_seed=5)
+    split = torch.normal(mean=torch.zeros(4, 3), std=torch.ones(4, 3))          # densify_and_split's sampling (gaussian_model.py:498-502)
+    params = [base + split]
+    vdist.assert_replicas_identical(params)              # passes: same samples everywhere
+    other = torch.normal(mean=torch.zeros(4, 3), std=torch.ones(4, 3), generator=torch.Generator().manual_seed(rank))
+    err = None
+    try:
+        vdist.assert_replicas_identical([base + other], what="split samples")
+    except RuntimeError as ex:
+        err = str(ex)
+    torch.save({"split": split, "err": err}, os.path.join(out_dir, "d%d.pt" % rank))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_densification_samples_agree_across_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_densify_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "d0.pt"), torch.load(tmp_path / "d1.pt")
+    assert torch.equal(r0["split"], r1["split"])
+    assert r0["err"] and r1["err"] and "diverged" in r0["err"] and "diverged" in r1["err"]      # the guard fires on both ranks
