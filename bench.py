@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 from ibgs_amd import _lib, synthetic as syn  # noqa: E402
 from ibgs_amd._build import csrc_sha  # noqa: E402
 from ibgs_amd import dist as vdist  # noqa: E402
+from ibgs_amd.losses import l1_loss  # noqa: E402
 from ibgs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 
 HBM_PEAK = 8.0e12   # bytes/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
@@ -153,7 +154,7 @@ class Workload:
         for v in self.leaves.values():
             v.grad = None
         outs = self._call()
-        loss = torch.nn.functional.l1_loss(outs[0], self.target)
+        loss = l1_loss(outs[0], self.target)          # the reference's l1_loss (utils/loss_utils.py:23-24) as one pass: value + gradient
         if self.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
             loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
         self.R = outs[0].grad_fn.num_rendered
@@ -172,7 +173,7 @@ class Workload:
     def describe(self, opacity, world, exchange):
         c = self.c
         return "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, opacity=%s%s, one view per GPU%s" % (
-            self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target",
+            self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target (ibgs_amd.losses.l1_loss: value + gradient in one pass)",
             opacity + ((", %g of the Gaussians in one blob" % Workload.CLUSTER) if Workload.CLUSTER > 0 else ""),
             ", render_geo n_src=4 L=4" if self.geo else "", (", RCCL gradient exchange (%s)" % exchange) if world > 1 else "")
 

@@ -18,6 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ibgs_amd import dist as vdist, renderer, simple_scene, synthetic as syn  # noqa: E402
+from ibgs_amd.losses import l1_loss  # noqa: E402
 from ibgs_amd.optim import FusedAdam  # noqa: E402
 
 
@@ -74,7 +75,7 @@ def main():
         def fwd_bwd():
             out = renderer.render(cam, pc, scene, pipe, args, bg, learnt_normal=False, nb_src_frames=3, buffer_length=4,
                                   render_geo=geo, return_depth_normal=False)
-            loss = torch.nn.functional.l1_loss(out["render"], targets[vid])
+            loss = l1_loss(out["render"], targets[vid])
             if geo:   # multi-view term in the spirit of train.py:319-338: the first source's warped colours should match the image
                 m = (out["cam_feat"][3:4] != 0).float()
                 loss = loss + 0.05 * ((out["warped_image"][0:3] - targets[vid]).abs() * m).mean()

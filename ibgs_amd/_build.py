@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libibgs_rast.so")
-SOURCES = ["api", "preprocess", "scan_sort", "binning", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "adam", "compact", "deterministic"]
+SOURCES = ["api", "preprocess", "scan_sort", "binning", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "adam", "compact", "deterministic", "loss"]
 EXTRA = {
     "preprocess": ["-ffp-contract=off"],           # bit-identical to the oracle (see preprocess.hip)
     # no SLP packing: v_pk_*_f32 is not faster than two scalar VALU ops on gfx950 and costs v_mov / s_nop glue

@@ -265,6 +265,13 @@ typedef struct ibgs_adam_tensor {
 } ibgs_adam_tensor;
 int32_t ibgs_adam_step(void* stream, int32_t n_tensors, const ibgs_adam_tensor* tensors);
 
+/* The photometric L1 term of the trainer's loss, l1_loss(image, gt) = |image - gt|.mean() (utils/loss_utils.py:23-24, train.py:302),
+ * value and gradient in ONE pass over the image: *loss = mean |x - y|, grad[i] = sign(x[i] - y[i]) / n (grad may be NULL: value only).
+ * x, y, grad: n floats each on the device; loss: one device float; `scratch` >= ibgs_required_l1() bytes, caller-owned, transient.
+ * No float atomics: the partial sums are added in a fixed order. */
+size_t ibgs_required_l1(void);
+int32_t ibgs_l1_loss(void* stream, int64_t n, const float* x, const float* y, float* grad, float* loss, char* scratch, size_t scratch_bytes);
+
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other
  * points (exact).  `scratch` >= ibgs_required_knn(P) bytes, caller-owned, transient. */
