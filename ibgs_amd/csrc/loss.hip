@@ -37,6 +37,21 @@ __global__ void __launch_bounds__(L1_THREADS) l1_partial_kernel(const float* __r
     if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < L1_THREADS / 64; w++) t += s_w[w]; partial[blockIdx.x] = t; }
 }
 
+// the gradient on its own, scaled by a DEVICE scalar (autograd's incoming gradient): grad = sign(x - y) * (*scale) / n, one pass
+__global__ void __launch_bounds__(L1_THREADS) l1_grad_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t n, float inv_n,
+                                                             const float* __restrict__ scale, float* __restrict__ grad)
+{
+    const float k = inv_n * (scale ? *scale : 1.0f);
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(grad)) & 15u) == 0;
+    auto one = [&](float a, float b) -> float { const float d = a - b; return d > 0.f ? k : (d < 0.f ? -k : 0.f * k); };
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * L1_THREADS) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(grad)[i] = make_float4(one(a.x, b.x), one(a.y, b.y), one(a.z, b.z), one(a.w, b.w));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * L1_THREADS) grad[i] = one(x[i], y[i]);
+}
+
 __global__ void __launch_bounds__(64) l1_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n, float* __restrict__ loss)
 {
     double v = 0.0;
@@ -64,6 +79,18 @@ extern "C" int32_t ibgs_l1_loss(void* stream, int64_t n, const float* x, const f
     hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)nb), dim3(L1_THREADS), 0, s, x, y, (size_t)n, (float)inv_n, grad, partial);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, partial, (int)nb, inv_n, loss);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int32_t ibgs_l1_grad(void* stream, int64_t n, const float* x, const float* y, const float* scale_dev, float* grad)
+{
+    if (n <= 0 || !x || !y || !grad) { set_error("ibgs_l1_grad: n > 0 and x, y, grad required"); return -IBGS_ERR_INVALID; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t per_block = (size_t)L1_THREADS * 4 * 4;
+    size_t nb = ((size_t)n + per_block - 1) / per_block;
+    if (nb > (size_t)L1_MAX_BLOCKS * 4) nb = (size_t)L1_MAX_BLOCKS * 4;
+    hipLaunchKernelGGL(l1_grad_kernel, dim3((unsigned)nb), dim3(L1_THREADS), 0, s, x, y, (size_t)n, (float)(1.0 / (double)n), scale_dev, grad);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

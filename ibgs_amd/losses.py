@@ -20,8 +20,6 @@ class _L1(torch.autograd.Function):
         lib = _lib.load()
         x = image.detach().float().contiguous()
         y = target.detach().to(x.device).float().contiguous()
-        need_grad = ctx.needs_input_grad[0]
-        grad = torch.empty_like(x) if need_grad else None
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -31,20 +29,27 @@ class _L1(torch.autograd.Function):
                 if len(_scratch) > 8:
                     _scratch.clear()
                 sc = _scratch[key] = torch.empty(lib.ibgs_required_l1(), dtype=torch.uint8, device=x.device)
-            rc = lib.ibgs_l1_loss(stream, x.numel(), x.data_ptr(), y.data_ptr(), grad.data_ptr() if need_grad else None, loss.data_ptr(),
-                                  sc.data_ptr(), sc.numel())
+            rc = lib.ibgs_l1_loss(stream, x.numel(), x.data_ptr(), y.data_ptr(), None, loss.data_ptr(), sc.data_ptr(), sc.numel())
         if rc < 0:
             raise RuntimeError("ibgs_l1_loss failed (%d): %s" % (rc, _lib.last_error()))
-        ctx.grad = grad
+        ctx.save_for_backward(x, y)
         ctx.shape = image.shape
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        g = ctx.grad
-        if g is None:
+        if not ctx.needs_input_grad[0]:
             return None, None
-        return (g * grad_out).view(ctx.shape), None      # (the target's gradient is never asked for by the trainer)
+        x, y = ctx.saved_tensors
+        lib = _lib.load()
+        go = grad_out.detach().to(x.device).float().contiguous()
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            # sign(x - y) * grad_out / N in ONE pass: the incoming gradient is read on the device (no host sync, no separate multiply)
+            rc = lib.ibgs_l1_grad(torch.cuda.current_stream(x.device).cuda_stream, x.numel(), x.data_ptr(), y.data_ptr(), go.data_ptr(), grad.data_ptr())
+        if rc < 0:
+            raise RuntimeError("ibgs_l1_grad failed (%d): %s" % (rc, _lib.last_error()))
+        return grad.view(ctx.shape), None      # (the target's gradient is never asked for by the trainer)
 
 
 def l1_loss(network_output, gt):

@@ -271,6 +271,8 @@ int32_t ibgs_adam_step(void* stream, int32_t n_tensors, const ibgs_adam_tensor* 
  * No float atomics: the partial sums are added in a fixed order. */
 size_t ibgs_required_l1(void);
 int32_t ibgs_l1_loss(void* stream, int64_t n, const float* x, const float* y, float* grad, float* loss, char* scratch, size_t scratch_bytes);
+/* The gradient alone, scaled by a DEVICE scalar (autograd's incoming gradient; NULL = 1): grad[i] = sign(x[i] - y[i]) * (*scale_dev) / n. */
+int32_t ibgs_l1_grad(void* stream, int64_t n, const float* x, const float* y, const float* scale_dev, float* grad);
 
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other
