@@ -134,6 +134,8 @@ class Workload:
         self.rast = GaussianRasterizer(st)
         self.target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(target_seed))
         self.params = [lv[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        # geo line: L1 terms on the normal map (target 0), the median depth (0) and the warped source colours (0.5)
+        self.geo_targets = (torch.zeros(3, H, W, device=dev), torch.zeros(1, H, W, device=dev), torch.full((15, H, W), 0.5, device=dev)) if geo else None
         self.R = 0
 
     def _call(self):
@@ -156,7 +158,7 @@ class Workload:
         outs = self._call()
         loss = l1_loss(outs[0], self.target)          # the reference's l1_loss (utils/loss_utils.py:23-24) as one pass: value + gradient
         if self.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
-            loss = loss + outs[2].abs().mean() + outs[3].abs().mean() + (outs[5] - 0.5).abs().mean()
+            loss = loss + l1_loss(outs[2], self.geo_targets[0]) + l1_loss(outs[3], self.geo_targets[1]) + l1_loss(outs[5], self.geo_targets[2])
         self.R = outs[0].grad_fn.num_rendered
         if backward is None:
             loss.backward()
