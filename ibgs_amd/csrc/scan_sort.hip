@@ -127,8 +127,9 @@ int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t 
 // ------------------------------------------------------------------------------------------------
 // radix pass
 // ------------------------------------------------------------------------------------------------
-// `n_dev` (may be NULL): the element count lives in device memory (written by an earlier kernel of the same stream);
-// the launch is then sized for the upper bound `n` and workgroups past the real count find nothing to do.
+// (The classic hist + scan + scatter passes below stay generic over the key width and accept a device-side element count `n_dev`: round 1's
+// R-sized tile sort used both; since the two-level binning of round 2 only the depth sort of more than 2 M Gaussians, the knn codes and
+// the deterministic backward's ids come through here, all with 32-bit keys and a host-side count.)
 // Rank of an element among the elements of its wave that carry the same digit, in lane order (what makes the pass
 // stable), plus the running per-wave digit counter.  The set of lanes with the same digit ("match-any") comes from
 // the LDS: every lane ORs its lane bit into the digit's 64-bit slot, then reads the slot back -- LDS operations of
@@ -151,7 +152,7 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t d, bool valid, int lane, 
     return r;
 }
 
-// K = uint32_t, or uint16_t for the tile sort of frames with <= 65536 tiles (a third less traffic per pass).
+// K = uint32_t (uint16_t was round 1's tile sort of frames with <= 65536 tiles).
 template <typename K>
 __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(const K* __restrict__ keys, size_t n, const uint32_t* __restrict__ n_dev,
                                                                 int shift, int nbins, uint32_t* __restrict__ hist, unsigned nblocks)
