@@ -37,16 +37,25 @@ def _newest_dep():
     return max(os.path.getmtime(d) for d in deps)
 
 
+def _code_only(text):
+    """C / HIP source without comments and blank lines (string literals in these sources never hold comment markers)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return "\n".join(l.rstrip() for l in text.split("\n") if l.strip())
+
+
 def csrc_sha():
-    """Fingerprint of the kernel sources (csrc/*.hip, csrc/*.h, include/ibgs_rast.h).  profiles/summarize.py stamps it into the
-    committed rocprofv3 summaries and bench.py quotes profile-derived numbers only when the stamp matches this tree."""
+    """Fingerprint of the kernel sources (csrc/*.hip, csrc/*.h, include/ibgs_rast.h), comments and blank lines excluded.
+    profiles/summarize.py stamps it into the committed rocprofv3 summaries and bench.py quotes profile-derived numbers only when the
+    stamp matches this tree."""
     import hashlib
     h = hashlib.sha1()
     for f in sorted(os.listdir(CSRC)):
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
-            h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(open(os.path.join(HERE, "..", "include", "ibgs_rast.h"), "rb").read())
+            h.update(_code_only(open(os.path.join(CSRC, f), "r").read()).encode())
+    h.update(_code_only(open(os.path.join(HERE, "..", "include", "ibgs_rast.h"), "r").read()).encode())
     return h.hexdigest()[:12]
 
 
