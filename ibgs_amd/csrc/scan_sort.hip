@@ -463,7 +463,8 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
 // IBGS_RADIX_ONESWEEP=1 / =0 forces it on / off for experiments.
 static int g_use_onesweep = getenv("IBGS_RADIX_ONESWEEP") ? atoi(getenv("IBGS_RADIX_ONESWEEP")) : -1;   // -1 = by size
 void radix_set_onesweep(bool on) { g_use_onesweep = on ? 1 : 0; }
-constexpr size_t OS_AUTO_MAX_CHUNKS = 512;
+constexpr size_t OS_AUTO_MAX_CHUNKS = 4096;          // (round 1: 512 -- with 256-thread chunks the look-back of ~3000 workgroups lost against hist + scan + scatter; with 512-thread chunks and
+                                                     // eight predecessors per look-back round trip the single-launch passes win up to at least 5 M keys: 0.178 vs 0.296 ms)
 
 static size_t onesweep_elems(size_t n)
 {
