@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     const float gcol[3] = {g2.x, g2.y, g2.z};
 
     p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y; p.dL_dmean2D[3 * i + 2] = 0.f;
-    p.dL_dmean2D_abs[3 * i] = ddelx_dx * g0.z; p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * g0.w; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
+    // (the blend kernels form sum |q (conic d)| with the conic in exp2 units, common.h: undone here, once per Gaussian)
+    p.dL_dmean2D_abs[3 * i] = ddelx_dx * (g0.z * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * (g0.w * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 2] = 0.f;
     if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }
     p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
     if ((WRITE_SH || !p.shs) && p.dL_dcolors) { p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2]; }

@@ -193,7 +193,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                 }
                 if constexpr (PPL == 4) {
                     p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
-                    p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
+                    p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));          // E3 = E2 + (E1 - E0) + 128 b: three instructions, as the forward
                     lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
                     lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
                 }
@@ -246,7 +246,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                         const float qdx = Q[0] * dx0, qdy = Q[0] * dy0;
                         v[0] = qdx; v[1] = qdy; v[4] = qdx * dx0; v[5] = qdx * dy0; v[6] = qdy * dy0; v[7] = Q[0];
                     }
-                    v[2] = aX * EXP2_UNSCALE; v[3] = aY * EXP2_UNSCALE;          // conic * d was formed with the scaled conic
+                    v[2] = aX; v[3] = aY;          // (conic * d was formed with the scaled conic: preprocess_bwd multiplies these two sums by EXP2_UNSCALE)
                     v[8] = vR; v[9] = vG; v[10] = vB; v[11] = 0.f;
                     const float tot = wave_transpose_reduce12(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);
@@ -481,7 +481,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                 }
                 if constexpr (PPL == 4) {
                     p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
-                    p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * cb + 64.0f * cc));
+                    p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));          // E3 = E2 + (E1 - E0) + 128 b: three instructions, as the forward
                     lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
                     lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
                 }
@@ -546,7 +546,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                         const float qdx = Q[0] * dx0, qdy = Q[0] * dy0;
                         v[0] = qdx; v[1] = qdy; v[4] = qdx * dx0; v[5] = qdx * dy0; v[6] = qdy * dy0; v[7] = Q[0];
                     }
-                    v[2] = aX * EXP2_UNSCALE; v[3] = aY * EXP2_UNSCALE;          // conic * d was formed with the scaled conic
+                    v[2] = aX; v[3] = aY;          // (conic * d was formed with the scaled conic: preprocess_bwd multiplies these two sums by EXP2_UNSCALE)
                     v[8] = vR; v[9] = vG; v[10] = vB; v[11] = vNx; v[12] = vNy; v[13] = vNz; v[14] = vD; v[15] = 0.f;
                     const float tot = wave_transpose_reduce16(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             if (PPL >= 2) p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * q1.x);
             if (PPL == 4) {
                 p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
-                p2q[3] = fmaf(-16.0f, ly0, p2q[1] + (128.0f * q1.y + 64.0f * q1.z));
+                p2q[3] = fmaf(128.0f, q1.y, p2q[2] + (p2q[1] - P0));          // E(d - (8,8)) = E2 + (E1 - E0) + 128 b: three instructions instead of four
             }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
