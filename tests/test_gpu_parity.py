@@ -187,6 +187,27 @@ def test_many_small_gaussians_on_a_large_frame():
     check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
 
 
+def test_dense_cells_and_a_crowded_corner():
+    """Binning corner cases of the expansion kernels (binning.hip): (i) Gaussians that each cover most of a cell put more than 4096 ids
+    into one chunk of 256 coarse entries -- the list scatter then stores directly instead of staging in LDS; (ii) a third of the
+    Gaussians in one corner gives one cell many times the chunks of the others (cell_scan splits them over its waves).  Lists, colours
+    and gradients must equal the oracle's."""
+    inp = scene(P=1500, W=256, H=256, deg=1, seed=71, opacity="trained", scale_mul=22.0)
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, 256, 256), 6)}, cull=True)
+    # cell 0 = tiles (0..7, 0..7) of the 16 x 16 grid: ids per coarse entry there = its list entries / the Gaussians that reach it
+    rg = ref["ranges"].reshape(16, 16, 2)
+    ids = np.concatenate([ref["point_list"][rg[ty, tx, 0]:rg[ty, tx, 1]] for ty in range(8) for tx in range(8)])
+    per_entry = ids.size / max(1, np.unique(ids).size)
+    assert np.unique(ids).size > 300 and per_entry > 20, (np.unique(ids).size, per_entry)      # chunks of 256 entries hold > 4096 ids
+    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+    inp = scene(P=12000, W=640, H=384, deg=1, seed=72, opacity="trained", scale_mul=0.8)
+    inp["means3D"] = inp["means3D"].copy()
+    inp["means3D"][:4000] = inp["means3D"][:4000] * 0.15 + np.array([0.55, 0.3, 0.0], np.float32)
+    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, 384, 640), 7)}, cull=True)
+    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
 def test_precomputed_colour_and_covariance_inputs():
     inp = scene(P=1500, deg=0, seed=4, opacity="trained")
     f0 = oracle.forward(inp)
