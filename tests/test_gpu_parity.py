@@ -208,6 +208,27 @@ def test_dense_cells_and_a_crowded_corner():
     check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
 
 
+def test_depth_keys_that_differ_in_every_byte():
+    """The depth sort copies instead of sorting in a pass whose keys all share one digit (the top byte of depths within [2, 8)) and drops
+    the Gaussians without tiles in its first pass.  Here the depths span 0.3 .. 40 (every pass is a real one), once with culled Gaussians in
+    between and once with every Gaussian on screen (nothing to drop)."""
+    for P, keep_all in ((5000, False), (300, True)):
+        inp = scene(P=P, W=320, H=208, deg=1, seed=81 + P, opacity="trained", scale_mul=0.6)
+        cam = np.asarray(inp["campos"], np.float32)
+        f = np.random.default_rng(3).choice(np.array([0.08, 0.4, 1.0, 3.0, 9.0], np.float32), size=P)[:, None]
+        pos = inp["means3D"] * (0.25 if keep_all else 1.0)              # keep_all: a small cloud on the optical axis, visible at every distance
+        inp["means3D"] = (cam + (pos - cam) * f).astype(np.float32)
+        inp["scales"] = (inp["scales"] * f).astype(np.float32)            # keep the screen-space size
+        ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, 208, 320), 8)}, cull=True)
+        d = ref["depths"][ref["radii"] > 0]
+        assert d.min() < 0.5 and d.max() > 16.0, (d.min(), d.max())
+        if keep_all:
+            assert (ref["tiles_touched"] > 0).all()
+        else:
+            assert (ref["tiles_touched"] == 0).sum() > 100
+        check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+
+
 def test_precomputed_colour_and_covariance_inputs():
     inp = scene(P=1500, deg=0, seed=4, opacity="trained")
     f0 = oracle.forward(inp)
