@@ -4,6 +4,8 @@ Everything goes through the product path: GaussianRasterizer -> autograd.Functio
 libibgs_rast.so.  Bars: integer / index results bit-exact (radii, tiles touched, sorted lists, tile
 ranges, clamp flags, preprocess records); blended floats within the north-star tolerance (mean L1 per
 pixel <= 1e-4, PSNR delta <= 0.05 dB -- asserted far tighter); gradients relative L2 <= 1e-3."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -351,3 +353,23 @@ def test_idempotent_forward_and_linear_backward():
     for k in res[0][1]:
         assert rel_l2(res[1][1][k], res[0][1][k]) < 1e-5                                # float atomics: order noise only
         assert rel_l2(res[2][1][k], 2.0 * res[0][1][k]) < 1e-5                          # backward is linear in dL/dC
+
+
+def test_classic_radix_passes_still_sort():
+    """The hist + scan + scatter passes (scan_sort.hip) only run for sorts of more than 4096 chunks (16.7 M keys) since the single-launch
+    passes took over; IBGS_RADIX_ONESWEEP=0 forces them.  The library reads the switch when it is loaded: a child process."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, oracle
+        from tests import hipref
+        from tests.scenes import scene
+        inp = scene(P=6000, W=320, H=208, deg=1, seed=91, opacity="trained")
+        ref = oracle.forward(inp, cull=True)
+        outs, lv, _ = hipref.run_forward(inp, debug=True)
+        ist = hipref.internal_state(outs, inp)
+        assert ist["R"] == ref["num_rendered"] and np.array_equal(ist["point_list"], ref["point_list"]) and np.array_equal(ist["ranges"], ref["ranges"])
+        print("classic ok", ist["R"])
+    ''')
+    env = dict(os.environ, IBGS_RADIX_ONESWEEP="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "classic ok" in r.stdout, r.stdout + r.stderr
