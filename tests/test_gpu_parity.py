@@ -373,3 +373,19 @@ def test_classic_radix_passes_still_sort():
     env = dict(os.environ, IBGS_RADIX_ONESWEEP="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "classic ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_frame_with_more_cells_than_one_placement_slice(wave_shape):
+    """8208 x 2064 pixels = 513 x 129 tiles = 65 x 17 = 1105 coarse cells: the placement kernels (binning.hip) keep per-cell tables in LDS
+    and handle at most 1024 cells per launch, so this frame takes two slices.  Sparse and forward only on purpose (the oracle walks
+    17 M pixels), and once -- the binning does not depend on the wave shape of the blend kernels."""
+    if wave_shape != "tile":
+        pytest.skip("binning is independent of the blend kernels' wave shape")
+    W, H = 8208, 2064
+    inp = scene(P=4000, W=W, H=H, deg=0, seed=95, opacity="trained", scale_mul=0.5)
+    ref, o, ist, leaves, gb = run(inp, None, cull=True)
+    assert ((W + 15) // 16 + 7) // 8 * (((H + 15) // 16 + 7) // 8) > 1024
+    rg = ref["ranges"].reshape(-1, 2)
+    used = np.flatnonzero(rg[:, 1] > rg[:, 0])
+    assert used.size > 2000 and (used // (((W + 15) // 16))).max() > 100           # tiles in use down to the last rows: cells of both slices
+    check_stages(ist, o, ref); check_color(o, ist, ref)
