@@ -20,6 +20,7 @@ FLAG_TILE_WAVES = 32
 FLAG_QUADRANT_WAVES = 64
 FLAG_DETERMINISTIC = 128
 FLAG_TEX_PACKED = 256
+FLAG_NO_REF_POWER_SKIP = 512
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 MAX_VIEWS = 8
 

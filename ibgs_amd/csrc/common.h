@@ -107,6 +107,26 @@ __device__ __forceinline__ void stage_for_exp2(float4& pos_opacity_quad, float4&
     pos_opacity_quad.z = -__builtin_amdgcn_logf(pos_opacity_quad.z);          // v_log_f32 = log2; o = 0 -> +inf -> never passes
 }
 
+// ---- the reference's `power > 0` skip (forward.cu:420, backward.cu:645) -------------------------------------------------------------
+// `power` = -0.5 (a dx^2 + c dy^2) - b dx dy is <= 0 for a positive definite conic; the reference's fp32 evaluation can come out
+// positive only through rounding: |rounding| <= ~4 ulp of S = a dx^2 + c dy^2, while -power >= S (1 - |b| / sqrt(a c)) / 2, so a pair can
+// be dropped by that test only when b^2 > (1 - 1e-6) a c -- needles hundreds of pixels long and half a pixel wide, up to conics that
+// the fp32 inversion of cov2D has left INDEFINITE (then `power > 0` holds on a whole sector of the image and the test is what keeps
+// exp(power) from exploding).  conic_is_risky() keeps a decade of margin; it is the same expression as oracle/ibgs_oracle.c's.
+// For those Gaussians (a wave-uniform, rare branch: one scalar bit test per staged record otherwise) the blend kernels evaluate
+// the reference's own expression per pixel, without contraction -- as the oracle does; nvcc's fma contraction of it is not knowable
+// here -- drop the pairs with power > 0 and take E from it, so that they follow the reference's rounding instead of the shifted
+// quadratic form's.  They are also exempt from the tile cull (preprocess.hip).  IBGS_FLAG_NO_REF_POWER_SKIP switches the branch off.
+constexpr float POWER_RISK = 0.99999f;
+constexpr float LOG2_E = 1.4426950408889634f;
+__device__ __forceinline__ bool conic_is_risky(float a, float b, float c) { return b * b > POWER_RISK * (a * c); }
+__device__ __forceinline__ float ref_power_E(float dx, float dy, float a, float b, float c, float neg_log2_opacity)
+{
+#pragma clang fp contract(off)
+    const float power = -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy;
+    return power > 0.0f ? __builtin_inff() : fmaf(-power, LOG2_E, neg_log2_opacity);          // +inf fails every E <= log2(255) test
+}
+
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define IBGS_HIP(expr)                                                                    \

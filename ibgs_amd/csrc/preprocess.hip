@@ -78,6 +78,7 @@ enum { CULL_NONE = 0, CULL_AABB = 1, CULL_LANE = 2, CULL_WAVE = 3 };
 __device__ __forceinline__ int cull_setup(float px, float py, float sxx, float syy, float A, float B, float C, float o,
                                           int& x0, int& y0, int& x1, int& y1, CullJob& j)
 {
+    if (conic_is_risky(A, B, C)) return CULL_AABB;          // near-singular conic: the margin below is not sized for its rounding (common.h); keep the reference rectangle
     const float x255 = 255.0f * o;
     if (!(x255 >= 1.0f)) { x1 = x0; y1 = y0; return CULL_NONE; }
     const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;

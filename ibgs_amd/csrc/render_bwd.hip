@@ -41,6 +41,7 @@ struct BwdParams {
     Cam cam;
     int ntiles;
     int n_src; int tex_quant;
+    int power_skip;       // as the forward (render_fwd.hip, common.h)
     const float* ref_to_src; const float4* src_rgba;
     const float* final_T; const uint32_t* n_contrib; const float* sum_w; const uint32_t* low_high;
     const int32_t* valid_idx; const float* valid_w;
@@ -154,15 +155,18 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
 
     while (top > 0) {
         const int count = min(CHUNK, top);
+        bool risky = false;
         if (lane < count) {   // stage in processing order: slot l holds entry top-1-l
             const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
             ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
             float4 c1 = r[1];
+            risky = conic_is_risky(c1.x, c1.y, c1.z);
             stage_for_exp2(ra, c1);                            // as the forward stages them (common.h): same numbers, same decisions
             s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = r[2];
         }
+        const uint64_t riskm = p.power_skip ? __builtin_amdgcn_ballot_w64(risky) : 0ull;      // near-singular conics: the forward's rare branch
         // pixels that take part: k < n_contrib.  k runs from top-1 down to top-count in this chunk and a pixel only ever
         // switches ON (at k = n_contrib - 1), so when the masks at both ends agree they hold for the whole chunk.
         uint64_t ncm[PPL];
@@ -196,6 +200,15 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
                     p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));          // E3 = E2 + (E1 - E0) + 128 b: three instructions, as the forward
                     lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
                     lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                }
+                if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h)
+                    const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+                    const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
+#pragma unroll
+                    for (int q = 0; q < PPL; q++) {
+                        const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+                        p2q[q] = ref_power_E(g0.x - (pxf0 + ox), g0.y - (pyf0 + oy), g1.x, g1.y, g1.z, nlo);
+                    }
                 }
                 float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f;
                 bool any = false;
@@ -447,15 +460,18 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
 
     while (top > 0) {
         const int count = min(CHUNK, top);
+        bool risky = false;
         if (lane < count) {
             const uint32_t id = p.point_list[r0 + (uint32_t)(top - 1 - lane)];
             const float4* r = p.rec + (size_t)id * 4;
             float4 ra = r[0];
             ra.w = __uint_as_float(id);
             float4 c1 = r[1];
+            risky = conic_is_risky(c1.x, c1.y, c1.z);
             stage_for_exp2(ra, c1);
             s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = r[2]; s_rec[3][lane] = r[3];
         }
+        const uint64_t riskm = p.power_skip ? __builtin_amdgcn_ballot_w64(risky) : 0ull;
         uint64_t ncm[PPL];
         bool stable = true;
 #pragma unroll
@@ -484,6 +500,15 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                     p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));          // E3 = E2 + (E1 - E0) + 128 b: three instructions, as the forward
                     lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
                     lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                }
+                if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h)
+                    const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+                    const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
+#pragma unroll
+                    for (int q = 0; q < PPL; q++) {
+                        const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+                        p2q[q] = ref_power_E(g0.x - (pxf0 + ox), g0.y - (pyf0 + oy), g1.x, g1.y, g1.z, nlo);
+                    }
                 }
                 float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f;
                 bool any = false;
@@ -586,6 +611,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     p.ntiles = p.cam.gx * p.cam.gy;
     p.n_src = a.n_src; p.tex_quant = (a.flags & IBGS_FLAG_TEX_QUANT) ? 1 : 0;
+    p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
     p.ref_to_src = a.ref_to_src; p.src_rgba = src_rgba;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;

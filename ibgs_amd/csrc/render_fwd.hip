@@ -34,6 +34,7 @@ struct FwdParams {
     int n_views, gyv; float fxv[IBGS_MAX_VIEWS], fyv[IBGS_MAX_VIEWS];
     // geo
     int n_src; int L; float thr; int tex_quant;
+    int power_skip;      // reproduce the reference's `power > 0` skip for near-singular conics (common.h)
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta;
@@ -182,18 +183,22 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const int n = (int)(r1 - r0);
 
     for (int base = 0; base < n; base += WAVE) {
+        uint64_t riskm = 0ull;          // staged records whose conic is near-singular: the reference's power expression decides for them (common.h)
         {   // stage up to 64 records: lane e loads the quads of entry base+e
             const int e = base + lane;
+            bool risky = false;
             if (e < n) {
                 const uint32_t id = p.point_list[r0 + e];
                 const float4* r = p.rec + (size_t)id * 4;
                 float4 c0 = r[0], c1 = r[1];
+                risky = conic_is_risky(c1.x, c1.y, c1.z);
                 stage_for_exp2(c0, c1);                        // conic in units of the exp2 exponent, opacity as -log2 (common.h)
                 s_rec[0][lane] = c0;
                 s_rec[1][lane] = c1;
                 s_rec[2][lane] = DEPTH ? r[3] : r[2];          // rgb (colour / geo) or the normal (depth-only)
                 if constexpr (GEO) s_rec[3][lane] = r[3];
             }
+            if (p.power_skip) riskm = __builtin_amdgcn_ballot_w64(risky);
         }
         __syncthreads();
         const int count = min(WAVE, n - base);
@@ -220,6 +225,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             if (PPL == 4) {
                 p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
                 p2q[3] = fmaf(128.0f, q1.y, p2q[2] + (p2q[1] - P0));          // E(d - (8,8)) = E2 + (E1 - E0) + 128 b: three instructions instead of four
+            }
+            if ((riskm >> j) & 1ull) {          // wave-uniform and rare: the record as preprocess wrote it, the reference's expression per pixel
+                const uint32_t gid = p.point_list[r0 + e];
+                const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
+#pragma unroll
+                for (int q = 0; q < PPL; q++) p2q[q] = ref_power_E(g0.x - pxf[q], g0.y - pyf[q], g1.x, g1.y, g1.z, q0.z);
             }
 #pragma unroll
             for (int q = 0; q < PPL; q++) {
@@ -431,6 +442,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.ntiles = p.cam.gx * p.cam.gy;
     p.n_src = a.n_src; p.L = a.buffer_length; p.thr = a.depth_error_threshold;
     p.tex_quant = (a.flags & IBGS_FLAG_TEX_QUANT) ? 1 : 0;
+    p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
     p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta;

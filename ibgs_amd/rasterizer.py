@@ -32,6 +32,10 @@ TEX_QUANT = False
 # Exact tile culling (shorter per-tile lists, identical outputs).  False reproduces the reference's AABB lists.
 TILE_CULL = True
 
+# The reference's `if (power > 0.0f) continue;` (forward.cu:420, backward.cu:645): reproduced for the Gaussians whose conic is close enough
+# to singular for it to fire (csrc/common.h); False = IBGS_FLAG_NO_REF_POWER_SKIP, every Gaussian takes the fast path.
+REF_POWER_SKIP = True
+
 # Deterministic backward (IBGS_FLAG_DETERMINISTIC): no float atomics, gradients bit-identical from run to run (CI mode, slower).
 DETERMINISTIC = False
 
@@ -41,7 +45,8 @@ WAVE_SHAPE = None
 
 
 def _shape_flag():
-    return {None: 0, "tile": _lib.FLAG_TILE_WAVES, "quadrant": _lib.FLAG_QUADRANT_WAVES}[WAVE_SHAPE]
+    return ({None: 0, "tile": _lib.FLAG_TILE_WAVES, "quadrant": _lib.FLAG_QUADRANT_WAVES}[WAVE_SHAPE]
+            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP))
 
 
 # View-parallel training (ibgs_amd/dist.py): while a `capture_sh_factors()` block is active the backward leaves
@@ -511,7 +516,7 @@ def rasterize_depth_batch(means3D, opacities, scales, rotations, cov3D_precomp, 
         a.tanfovx = float(tanfovxs[0]); a.tanfovy = float(tanfovys[0])
         a.n_src = 1; a.buffer_length = int(buffer_length); a.depth_error_threshold = 0.0
         a.render_geo = 0; a.render_depth_only = 1
-        a.flags = (_lib.FLAG_DEBUG if debug else 0) | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL)
+        a.flags = (_lib.FLAG_DEBUG if debug else 0) | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL) | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP)
         a.geom = geom.data_ptr(); a.geom_bytes = geom.numel(); a.img = img.data_ptr(); a.img_bytes = img.numel()
         a.binning_alloc = cb; a.binning_user = None
         a.radii = radii.data_ptr(); a.out_depth = depths.data_ptr()

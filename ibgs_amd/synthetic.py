@@ -79,9 +79,17 @@ def quat_to_rotmat(q):
     return Rm
 
 
-def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1.3):
+def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1.3, anisotropy=None):
     """Random-init Gaussians.  Returns fp32 arrays: xyz (P,3), shs (P,Mc,3), scales (P,3) [activated],
-    rotations (P,4) [normalised], opacities (P,1) [activated]."""
+    rotations (P,4) [normalised], opacities (P,1) [activated].
+
+    anisotropy: None = the near-isotropic random init above (axis ratios <= ~2.5);
+      "plane"  = the shape IBGS / PGSR Gaussians are trained towards (scene/gaussian_model.py:156-173 takes the smallest-scale axis
+                 as the plane normal): one random axis shrunk to 10^-2 .. 10^-3 of the others, the disc 1.6x larger so that the
+                 footprints stay comparable -- seen edge-on these project to ellipses of aspect up to ~100:1;
+      "needle" = one random axis stretched 30x, the other two shrunk 3x (long thin splats);
+      "mixed"  = a third of each.
+    The extra draws come from their own generator, so the other arrays do not depend on the mode."""
     rng = np.random.default_rng(seed)
     xyz = rng.uniform(-extent, extent, size=(P, 3)).astype(np.float32)
     rgb = rng.uniform(0.0, 1.0, size=(P, 3)).astype(np.float32)
@@ -91,6 +99,17 @@ def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1
         shs[:, 1:, :] = rng.normal(0.0, 0.05, size=(P, max_coeffs - 1, 3)).astype(np.float32)
     sbar = 0.65 * ((2 * extent) ** 3 / P) ** (1.0 / 3.0)
     scales = (sbar * np.exp(rng.normal(0.0, 0.3, size=(P, 3)))).astype(np.float32)
+    if anisotropy is not None:
+        arng = np.random.default_rng(1_000_003 + seed)
+        axis = arng.integers(0, 3, size=P)
+        mode = {"plane": np.zeros(P, int), "needle": np.ones(P, int), "mixed": arng.integers(0, 3, size=P)}[anisotropy]
+        flat = 10.0 ** arng.uniform(-3.0, -2.0, size=P)
+        f = np.ones((P, 3))
+        rows = np.arange(P)
+        pl, nd = mode == 0, mode == 1
+        f[pl] = 1.6; f[rows[pl], axis[pl]] = flat[pl]
+        f[nd] = 1.0 / 3.0; f[rows[nd], axis[nd]] = 30.0
+        scales = (scales * f).astype(np.float32)
     q = rng.normal(0.0, 1.0, size=(P, 4))
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
     if opacity == "init":
@@ -147,9 +166,9 @@ CONFIGS = {
 }
 
 
-def make_scene(P, W, H, sh_degree=3, seed=1, view=0, opacity="init", with_planes=False):
+def make_scene(P, W, H, sh_degree=3, seed=1, view=0, opacity="init", with_planes=False, anisotropy=None):
     """Oracle-style input dict for one view (colour path; see make_geo_inputs for the geo path)."""
-    g = make_gaussians(P, seed, sh_degree=sh_degree, opacity=opacity)
+    g = make_gaussians(P, seed, sh_degree=sh_degree, opacity=opacity, anisotropy=anisotropy)
     cam = make_camera(W, H, azimuth_deg=45.0 * view)
     inp = dict(g)
     inp.update({

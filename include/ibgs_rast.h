@@ -79,6 +79,12 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                      write the clamp-masked dL/dRGB (P x 3) to dL_dcolors; after the ranks exchanged those
                                      3 floats instead of 3 M, ibgs_sh_grad_from_views rebuilds the summed dL/dsh */
 
+#define IBGS_FLAG_NO_REF_POWER_SKIP 512u /* both passes: do NOT reproduce the reference's `if (power > 0.0f) continue;` (forward.cu:420,
+                                           backward.cu:645).  By default the blend kernels evaluate the reference's expression for the
+                                           Gaussians whose conic is within 1e-5 of singular (the only ones for which that test can fire,
+                                           csrc/common.h: conic_is_risky) and drop the pairs it drops; with this flag every Gaussian
+                                           takes the fast path and such pairs are blended with alpha ~= opacity */
+
 typedef struct ibgs_forward_args {
     void* stream;
     /* problem size */

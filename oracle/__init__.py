@@ -225,6 +225,14 @@ def backward(inp, fwd, dL_dcolor, dL_dnormal=None, dL_ddepth=None, dL_dwarped=No
     return res
 
 
+def power_skips():
+    """(forward, backward) counts of (pixel, Gaussian) pairs that the LAST forward / backward call dropped through the
+    reference's `power > 0` test (forward.cu:420, backward.cu:645) -- it can only fire through rounding, on needle-shaped conics."""
+    out = (ctypes.c_longlong * 2)()
+    lib().orc_power_skips(out)
+    return int(out[0]), int(out[1])
+
+
 def eval_sh(deg, shs, dirs):
     """shs (N,M,3), dirs (N,3) unit -> (N,3) SH colour before the +0.5 / clamp."""
     shs = _f32(shs); dirs = _f32(dirs)

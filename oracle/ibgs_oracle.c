@@ -179,6 +179,17 @@ static float ln_portable(float x)           /* |error| < 2e-6 for x >= 1; basic 
 
 static inline float clampf_(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* Is the conic so close to singular that the reference's fp32 evaluation of `power` (forward.cu:419, backward.cu:644) can come out
+ * POSITIVE through rounding?  |rounding| <= ~4 ulp of S = a dx^2 + c dy^2 while -power >= S (1 - |b| / sqrt(a c)) / 2, so that needs
+ * b^2 > (1 - 1e-6) a c; the test below keeps a decade of margin.  Such Gaussians (needles hundreds of pixels long and half a pixel
+ * wide) are exempt from the tile cull -- its margin is sized for well-conditioned conics -- and the HIP blend kernels evaluate them
+ * with the reference's own expression, `power > 0` skip included (ibgs_amd/csrc/common.h: conic_is_risky). */
+static inline int conic_is_risky(float A, float B, float C) { return B * B > 0.99999f * (A * C); }
+
+/* statistics of the last orc_render_forward / orc_render_backward call: (pixel, Gaussian) pairs dropped by `power > 0` */
+static long long g_power_skips[2] = {0, 0};
+void orc_power_skips(long long* out) { out[0] = g_power_skips[0]; out[1] = g_power_skips[1]; }
+
 /* In: pixel centre, cov2D diagonal (with the 0.3), conic, opacity, reference rectangle.
  * Out: tightened rectangle, bit mask of surviving tiles (row-major inside the tightened rectangle,
  * CULL_WORDS x 64 bits, only when it has <= CULL_MAX_TILES tiles; otherwise every tile of it survives). Returns the tile count. */
@@ -188,6 +199,7 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
                           int* x0, int* y0, int* x1, int* y1, uint64_t* mask /* [CULL_WORDS] */)
 {
     for (int k = 0; k < CULL_WORDS; k++) mask[k] = ~0ull;
+    if (conic_is_risky(A, B, C)) return (uint32_t)((*x1 - *x0) * (*y1 - *y0));      /* keeps the reference rectangle, every tile of it */
     const float x255 = 255.0f * o;
     if (!(x255 >= 1.0f)) { *x1 = *x0; *y1 = *y0; for (int k = 0; k < CULL_WORDS; k++) mask[k] = 0; return 0; }
     const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
@@ -440,7 +452,8 @@ void orc_render_forward(
     const int before_cap = (L % 2 == 0) ? (L / 2) : ((L + 1) / 2);
     const int below_cap = L - before_cap;
 
-#pragma omp parallel for schedule(dynamic, 8)
+    long long nskip = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : nskip)
     for (int py = 0; py < H; py++) for (int px = 0; px < W; px++) {
         const size_t pix = (size_t)py * W + px;
         const int tile = (py / TILE) * gx + (px / TILE);
@@ -463,7 +476,7 @@ void orc_render_forward(
             const float dx = means2D[2 * id] - pixx, dy = means2D[2 * id + 1] - pixy;
             const float* co = conic_opacity + 4 * id;
             const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-            if (power > 0.0f) continue;
+            if (power > 0.0f) { nskip++; continue; }
             const float alpha = fminf_(0.99f, co[3] * expf(power));   /* reference: __expf (Q1) */
             if (alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1.0f - alpha);
@@ -592,6 +605,7 @@ void orc_render_forward(
             for (int ch = 0; ch < 3; ch++) out_normal[ch * HW + pix] = N[ch];
         }
     }
+    g_power_skips[0] = nskip;
 }
 
 /* Q3: derivative of the warped colour w.r.t. (u,v) as the reference computes it
@@ -646,7 +660,8 @@ void orc_render_backward(
 
     /* rows in parallel; the double accumulators are updated atomically (sum order is then
      * nondeterministic at the 1e-16 level, far below the fp32 results being checked) */
-#pragma omp parallel for schedule(dynamic, 4)
+    long long nskip = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : nskip)
     for (int py = 0; py < H; py++) for (int px = 0; px < W; px++) {
         const size_t pix = (size_t)py * W + px;
         const int tile = (py / TILE) * gx + (px / TILE);
@@ -680,7 +695,7 @@ void orc_render_backward(
             const float dx = means2D[2 * id] - pixx, dy = means2D[2 * id + 1] - pixy;
             const float* co = conic_opacity + 4 * id;
             const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-            if (power > 0.0f) continue;
+            if (power > 0.0f) { nskip++; continue; }
             const float G = expf(power);
             const float alpha = fminf_(0.99f, co[3] * G);
             if (alpha < 1.0f / 255.0f) continue;
@@ -786,6 +801,7 @@ void orc_render_backward(
             acc_opacity[id] += (double)(G * dL_dalpha);
         }
     }
+    g_power_skips[1] = nskip;
 }
 
 /* ------------------------------------------------------------------------------------------

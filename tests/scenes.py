@@ -5,12 +5,25 @@ import oracle
 from ibgs_amd import synthetic as syn
 
 
-def scene(P=4000, W=208, H=144, deg=3, seed=1, opacity="init", planes=False, scale_mul=1.0):
-    inp = syn.make_scene(P, W, H, sh_degree=deg, seed=seed, opacity=opacity, with_planes=planes)
+def scene(P=4000, W=208, H=144, deg=3, seed=1, opacity="init", planes=False, scale_mul=1.0, anisotropy=None):
+    inp = syn.make_scene(P, W, H, sh_degree=deg, seed=seed, opacity=opacity, with_planes=planes, anisotropy=anisotropy)
     if scale_mul != 1.0:
         inp["scales"] = (inp["scales"] * scale_mul).astype(np.float32)
         if planes:
             inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
+    return inp
+
+
+def giant_needles(P=300, W=208, H=144, seed=5, stretch=4.0, thin=0.05, deg=1, opacity="trained"):
+    """Needles far longer than the frame and thinner than a pixel: the fp32 inversion of cov2D leaves conics within rounding of singular
+    (some indefinite), the regime in which the reference's `power > 0` test (forward.cu:420, backward.cu:645) decides which pairs blend.
+    The longest axis of every "needle" Gaussian is stretched again, the other two shrunk."""
+    inp = scene(P=P, W=W, H=H, deg=deg, seed=seed, opacity=opacity, anisotropy="needle")
+    s0 = inp["scales"]
+    k = np.argmax(s0, axis=1); rows = np.arange(P)
+    s = s0 * thin
+    s[rows, k] = s0[rows, k] * stretch
+    inp["scales"] = s.astype(np.float32)
     return inp
 
 
