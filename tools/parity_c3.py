@@ -1,5 +1,9 @@
 """Full-size parity datapoint (not in the test suite: the oracle needs ~10 s on the box's host cores): HIP vs oracle on the
-C3 bench workload -- image L1 / max / PSNR difference, per-pixel counter agreement, gradient relative L2."""
+C3 bench workload -- image L1 / max / PSNR difference, per-pixel counter agreement, gradient relative L2.
+
+python tools/parity_c3.py                 the near-isotropic bench scene, init and trained-like opacities (profiles/r02_parity_c3.txt)
+python tools/parity_c3.py plane needle    anisotropic variants of the same scene (synthetic.make_gaussians), with the oracle's own
+                                          fma / no-fma difference beside every number and its count of `power > 0` skips"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,9 +13,13 @@ from tests import hipref
 from tests.metrics import l1, psnr, rel_l2
 
 c = syn.CONFIGS["C3"]
-for opacity in ("init", "trained"):
-    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity)
+modes = sys.argv[1:]
+cases = [(None, "init"), (None, "trained")] if not modes else [(m, "trained") for m in modes]
+names = {"dL_dmeans3D": "means3D", "dL_dsh": "shs", "dL_dopacity": "opacities", "dL_dscales": "scales", "dL_drotations": "rotations", "dL_dmeans2D": "means2D"}
+for aniso, opacity in cases:
+    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity, anisotropy=aniso)
     t0 = time.time(); ref = oracle.forward(inp, cull=True); t1 = time.time()
+    skips_f = oracle.power_skips()[0]
     g = np.random.default_rng(1).standard_normal((3, c["H"], c["W"])).astype(np.float32)
     rb = oracle.backward(inp, ref, g); t2 = time.time()
     outs, lv, _ = hipref.run_forward(inp)
@@ -19,10 +27,22 @@ for opacity in ("init", "trained"):
     col = outs["color"].detach().cpu().numpy()
     (outs["color"] * torch.as_tensor(g, device="cuda")).sum().backward()
     tgt = np.random.default_rng(2).random(col.shape).astype(np.float32)
-    print("C3 opacity=%s: oracle fwd %.1f s bwd %.1f s | R %d == %d: %s | lists equal: %s" % (opacity, t1 - t0, t2 - t1, ist["R"], ref["num_rendered"],
+    co = ref["conic_opacity"][ref["radii"] > 0]
+    asp = (co[:, 0] * co[:, 2]) / np.maximum(co[:, 0] * co[:, 2] - co[:, 1] ** 2, 1e-30)
+    print("C3 anisotropy=%s opacity=%s: oracle fwd %.1f s bwd %.1f s | R %d == %d: %s | lists equal: %s" % (aniso, opacity, t1 - t0, t2 - t1, ist["R"], ref["num_rendered"],
           ist["R"] == ref["num_rendered"], np.array_equal(ist["point_list"], ref["point_list"])))
+    print("   footprints with a c / det > 25 (2D aspect beyond ~10:1): %.2f %%, > 1e3: %.3f %%; near-singular (reference-expression branch): %d; oracle `power > 0` skips fwd %d bwd %d"
+          % (100 * (asp > 25).mean(), 100 * (asp > 1e3).mean(), int((co[:, 1] ** 2 > np.float32(0.99999) * co[:, 0] * co[:, 2]).sum()), skips_f, oracle.power_skips()[1]))
     print("   image: mean L1 %.3e  max |d| %.3e  PSNR(vs common target) HIP %.4f dB oracle %.4f dB | n_contrib equal on %.5f of pixels"
           % (l1(col, ref["color"]), np.abs(col - ref["color"]).max(), psnr(col, tgt)[0], psnr(ref["color"], tgt)[0],
              (ist["n_contrib"] == ref["n_contrib"]).mean()))
-    names = {"dL_dmeans3D": "means3D", "dL_dsh": "shs", "dL_dopacity": "opacities", "dL_dscales": "scales", "dL_drotations": "rotations", "dL_dmeans2D": "means2D"}
     print("   grads rel L2:", {k: float("%.2e" % rel_l2(lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape), rb[k])) for k, v in names.items()})
+    if aniso is not None:
+        with oracle.variant("fma"):
+            r1 = oracle.forward(inp, cull=True); b1 = oracle.backward(inp, r1, g)
+        print("   the oracle against its own fma-contracted build: image mean L1 %.3e max %.3e, n_contrib equal on %.5f, lists equal: %s"
+              % (l1(r1["color"], ref["color"]), np.abs(r1["color"] - ref["color"]).max(), (r1["n_contrib"] == ref["n_contrib"]).mean(),
+                 r1["num_rendered"] == ref["num_rendered"] and np.array_equal(r1["point_list"], ref["point_list"])))
+        print("   ... grads rel L2:", {k: float("%.2e" % rel_l2(b1[k], rb[k])) for k in names})
+    del outs, lv
+    torch.cuda.empty_cache()
