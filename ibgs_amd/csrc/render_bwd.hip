@@ -292,6 +292,9 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
 // Table layout: tab[(slot * 6 + field) * HW + pixel], fields = {contributor number (uint bits), E, Kx, Ky, Kz, Kd}.
 __global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
 {
+    // no fused multiply-adds: the in-bounds test of backward.cu:722 is a decision on a projected coordinate, which is then the oracle's
+    // bit for bit (the depth it starts from is evaluated in double by both); the pass is bound by its gathers
+#pragma clang fp contract(off)
     const int W = p.cam.W, H = p.cam.H;
     const size_t HW = (size_t)W * H;
     const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -86,6 +86,7 @@ __device__ __forceinline__ float4 tex_rgba(const float4* __restrict__ img, int W
 
 __device__ __forceinline__ float tex_depth(const float* __restrict__ img, int W, int H, float x, float y, int quant)
 {
+#pragma clang fp contract(off)          // its result is thresholded (source validity): operation by operation like the oracle's tex_1
     const float xb = x - 0.5f, yb = y - 0.5f;
     const float fxi = floorf(xb), fyi = floorf(yb);
     const float a = quant8(xb - fxi, quant), b = quant8(yb - fyi, quant);
@@ -330,6 +331,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         }
         if (DEPTH) p.out_depth[pix] = wd_sum[q] / (tot_w[q] + eps);
         if (GEO) {
+            // The epilogue takes DECISIONS on what it computes (is the projected point inside the source image, is the source's depth
+            // within the threshold): no fused multiply-adds here, so that those coordinates are the oracle's bit for bit whenever the
+            // buffered weights are (once per pixel -- the blend loop above is what the kernel's time goes into)
+#pragma clang fp contract(off)
             const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
             const float pdx = pxf[q] - cx, pdy = pyf[q] - cy;
             float tw = 0.f, med = 0.f;
