@@ -8,12 +8,26 @@
 // Everything is enqueued on the caller's stream; no device-wide synchronisation, no allocation
 // (arenas are caller-owned), no persistent library state.
 #include "common.h"
+#include <stdlib.h>
+#include <stdio.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <vector>
 
 namespace ibgs {
+
+TileMap tile_map_from_env(const char* name, TileMap dflt)
+{   // "rr" | "g<N>" | "b<X>x<Y>" (common.h); anything else keeps the default
+    const char* v = getenv(name);
+    if (!v) return dflt;
+    TileMap m = dflt;
+    int a = 0, b = 0;
+    if (v[0] == 'r') m = TileMap{TMAP_RR, 1, 1, 1};
+    else if (v[0] == 'g' && sscanf(v + 1, "%d", &a) == 1 && a >= 1 && a <= 4096) m = TileMap{TMAP_GROUP, a, 1, 1};
+    else if (v[0] == 'b' && sscanf(v + 1, "%dx%d", &a, &b) == 2 && a >= 1 && b >= 1 && a * b <= 4096) m = TileMap{TMAP_BLOCK, 1, a, b};
+    return m;
+}
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...)

@@ -214,6 +214,46 @@ __device__ __forceinline__ PlaneEval plane_eval(int mode, const float* __restric
     return e;
 }
 
+// ---- workgroup -> work item (tile, wave of the tile) ------------------------------------------------------------------------------
+// Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2 (MI355X_MICROARCH.md).  Which tiles share
+// an XCD decides (i) whether the two halves of a 128-byte line of an output plane -- 32 pixels = two tiles side by side -- meet in ONE
+// L2 and leave as a full line, (ii) how much of the source textures' halo the geo epilogue's gathers find already cached, (iii) how
+// evenly a non-uniform image spreads over the chip.  Three layouts, chosen per kernel by measurement:
+//   RR     item = workgroup id: neighbouring items on different XCDs (best balance, every output line split over two L2s)
+//   GROUP  runs of `g` consecutive items per XCD: with g x (waves per tile) covering 2+ tiles, output lines are completed in one L2
+//   BLOCK  bx x by tile blocks per XCD (2-D locality for the gathers)
+// IBGS_TILE_MAP_{FWD,BWD,FWD_GEO,BWD_GEO} = "rr" | "g<N>" | "b<X>x<Y>" override the defaults (experiments: tools/sweep_tile_map.sh).
+enum { TMAP_RR = 0, TMAP_GROUP = 1, TMAP_BLOCK = 2 };
+struct TileMap { int mode, g, bx, by; };
+TileMap tile_map_from_env(const char* name, TileMap dflt);
+inline int tile_map_grid(const TileMap& m, int gx, int gy, int ipt)
+{
+    if (m.mode == TMAP_BLOCK) {
+        const int nb = ((gx + m.bx - 1) / m.bx) * ((gy + m.by - 1) / m.by);
+        return ((nb + 7) / 8) * 8 * m.bx * m.by * ipt;
+    }
+    const int g = m.mode == TMAP_GROUP ? m.g : 1;
+    return ((gx * gy * ipt + 8 * g - 1) / (8 * g)) * 8 * g;
+}
+__device__ __forceinline__ bool tile_map_item(const TileMap& m, int b, int gx, int gy, int ipt, int& tile, int& sub)
+{
+    const int xcd = b & 7, idx = b >> 3;
+    if (m.mode == TMAP_BLOCK) {
+        const int per = m.bx * m.by * ipt;
+        const int blk = (idx / per) * 8 + xcd, within = idx % per;
+        const int nbx = (gx + m.bx - 1) / m.bx;
+        const int t = within / ipt;
+        const int tx = (blk % nbx) * m.bx + t % m.bx, ty = (blk / nbx) * m.by + t / m.bx;
+        sub = within % ipt;
+        tile = ty * gx + tx;
+        return tx < gx && ty < gy;
+    }
+    int item = b;
+    if (m.mode == TMAP_GROUP) item = ((idx / m.g) * 8 + xcd) * m.g + idx % m.g;
+    tile = item / ipt; sub = item % ipt;
+    return item < gx * gy * ipt;
+}
+
 int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g);
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
 

@@ -30,6 +30,7 @@ struct FwdParams {
     const uint32_t* ranges; const uint32_t* point_list; const float4* rec;
     Cam cam;
     int ntiles;
+    TileMap tmap;
     // batched depth-only views (stacked tile grid): rows per view, per-view focal lengths
     int n_views, gyv; float fxv[IBGS_MAX_VIEWS], fyv[IBGS_MAX_VIEWS];
     // geo
@@ -97,11 +98,7 @@ __device__ __forceinline__ float tex_depth(const float* __restrict__ img, int W,
     return (1.f - a) * (1.f - b) * t00 + a * (1.f - b) * t10 + (1.f - a) * b * t01 + a * b * t11;
 }
 
-// Block -> work item: the identity.  Consecutive workgroups are dealt round-robin to the 8 XCDs, so neighbouring tiles land on
-// different XCDs and a dense region of the image is spread over the whole chip.  (Round 1 gave every XCD a contiguous band of tiles so
-// that neighbours share Gaussian records in one L2: no faster on the uniform C3 scene -- the blend is VALU-bound -- and 5 % (forward) /
-// 9 % (backward) slower when half of the Gaussians sit in one blob, `bench.py --cluster 0.5`: the XCDs that own the blob finish last.)
-__device__ __forceinline__ int tile_of_block(int b, int n) { (void)n; return b; }
+// Workgroup -> (tile, wave of the tile): tile_map_item, common.h.
 
 // MAXL = compile-time capacity of the per-pixel median buffer (4 covers the reference's default
 // buffer_length = 4 with half the select chains of 8).
@@ -115,11 +112,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 
     const int lane = threadIdx.x;
     constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
-    const int nitems = p.ntiles * IPT;
-    const int item = tile_of_block(blockIdx.x, nitems);
-    if (item >= nitems) return;
-    const int tile = item / IPT;
-    const int quad0 = (item % IPT) * PPL;
+    int tile, sub;
+    if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.ntiles / p.cam.gx, IPT, tile, sub)) return;
+    const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
     int trow = tile / p.cam.gx, view = 0;
     if (DEPTH && p.n_views > 1) { view = trow / p.gyv; trow -= view * p.gyv; }      // which camera's grid this tile belongs to
@@ -461,29 +456,29 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     }
     p.ntiles *= p.n_views;
     const int nt = p.ntiles;
+    const int gx = p.cam.gx, gyt = nt / gx;          // (stacked) tile grid
+    // measured (profiles/r03_tile_map.txt): the colour / depth kernels are VALU-bound on every layout; 4 x 4-tile blocks balance a clustered
+    // image best.  The geo kernel's epilogue gathers from the packed source images: 8 x 8-tile blocks cut its L2 <-> fabric traffic
+    // from 2.39 GB to 1.37 GB (= the algorithmic bytes) and its time by 3 %
+    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_FWD", TileMap{TMAP_BLOCK, 1, 4, 4});
+    static const TileMap map_geo = tile_map_from_env("IBGS_TILE_MAP_FWD_GEO", TileMap{TMAP_BLOCK, 1, 8, 8});
+    p.tmap = a.render_geo ? map_geo : map_color;
+    auto grid = [&](int ipt) { return dim3((unsigned)tile_map_grid(p.tmap, gx, gyt, ipt)); };
     if (a.render_depth_only && !a.render_geo) {
-        const int grid = ((nt + 7) / 8) * 8;
-        if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 4>), dim3(grid), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 8>), dim3(grid), dim3(64), 0, s, p);
+        if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 4>), grid(1), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 8>), grid(1), dim3(64), 0, s, p);
     } else if (a.render_geo) {
-        const int items = nt * 4;
-        const int grid = ((items + 7) / 8) * 8;
         // geo: half tiles (two quadrants per lane) on large frames, single quadrants on small ones; IBGS_FLAG_*_WAVES force either
         const bool half = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
-        if (half && a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), dim3(((nt * 2 + 7) / 8) * 8), dim3(64), 0, s, p);
-        else if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), dim3(grid), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), dim3(grid), dim3(64), 0, s, p);
+        if (half && a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), grid(2), dim3(64), 0, s, p);
+        else if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), grid(4), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), grid(4), dim3(64), 0, s, p);
     } else {
         // Small frames: one wave per 8x8 quadrant instead of per tile, otherwise the chip (1024 SIMDs x 8 waves) stays
         // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).
         const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096);
-        if (small) {
-            const int grid = ((nt * 4 + 7) / 8) * 8;
-            hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 1, 4>), dim3(grid), dim3(64), 0, s, p);
-        } else {
-            const int grid = ((nt + 7) / 8) * 8;
-            hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), dim3(grid), dim3(64), 0, s, p);
-        }
+        if (small) hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 1, 4>), grid(4), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), grid(1), dim3(64), 0, s, p);
     }
     IBGS_HIP(hipGetLastError());
     return 0;

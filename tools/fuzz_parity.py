@@ -11,6 +11,7 @@ from tests.test_gpu_parity import add_sources, scene
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # replay ONE case of the sequence and print where the two sides part
 worst = {"color": 0.0, "grad": 0.0, "ncontrib": 1.0}
 bad = 0
 for case in range(n_cases):
@@ -19,9 +20,15 @@ for case in range(n_cases):
     deg = int(rng.integers(0, 4)); geo = bool(rng.integers(0, 3) == 0)
     opacity = str(rng.choice(["init", "trained"])); smul = float(rng.choice([0.5, 1.0, 2.5]))
     rasterizer.WAVE_SHAPE = [None, "tile", "quadrant"][int(rng.integers(0, 3))]
-    inp = scene(P=P, W=W, H=H, deg=deg, seed=int(rng.integers(0, 10**6)), opacity=opacity, planes=geo, scale_mul=smul)
+    sseed = int(rng.integers(0, 10**6))
+    n_src, Lb = (int(rng.integers(1, 6)), int(rng.integers(1, 9))) if geo else (1, 4)
+    if only is not None and case != only:          # consume the same draws as the full run
+        rng.standard_normal((3, H, W))
+        if geo: rng.standard_normal((3, H, W)); rng.standard_normal((1, H, W)); rng.standard_normal((15, H, W))
+        continue
+    inp = scene(P=P, W=W, H=H, deg=deg, seed=sseed, opacity=opacity, planes=geo, scale_mul=smul)
     if geo:
-        inp = add_sources(inp, n_src=int(rng.integers(1, 6)), L=int(rng.integers(1, 9)))
+        inp = add_sources(inp, n_src=n_src, L=Lb)
     ref = oracle.forward(inp, cull=True)
     outs, lv, _ = hipref.run_forward(inp)
     ist = hipref.internal_state(outs, inp)
@@ -47,6 +54,30 @@ for case in range(n_cases):
         a = lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape)
         if np.abs(rb[k]).sum() > 0:
             gr = max(gr, float(rel_l2(a, rb[k])))
+    if gr > 1e-3:          # explain it: every gradient, beside the oracle's own fma / no-fma difference on the same case
+        with oracle.variant("fma"):
+            r1 = oracle.forward(inp, cull=True)
+            b1 = oracle.backward(inp, r1, g, gn, gdp, gw) if geo else oracle.backward(inp, r1, g)
+        allk = {"dL_dmeans3D": "means3D", "dL_dmeans2D": "means2D", "dL_dopacity": "opacities", "dL_dsh": "shs", "dL_dscales": "scales", "dL_drotations": "rotations"}
+        if geo: allk["dL_dall_map"] = "all_map"
+        print("     case %d detail (HIP vs oracle | oracle fma vs no-fma): " % case + ", ".join(
+            "%s %.1e|%.1e" % (v, rel_l2(lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape), rb[k]), rel_l2(b1[k], rb[k])) for k, v in allk.items() if np.abs(rb[k]).sum() > 0))
+        k = "dL_dall_map" if geo else "dL_dscales"
+        a = lv[names.get(k, "scales")].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape); e = np.abs(a - rb[k]).reshape(a.shape[0], -1).sum(1)
+        i = int(np.argmax(e))
+        co = ref["conic_opacity"][i]
+        print("     worst Gaussian %d: %s HIP %s oracle %s twin %s | 1 - b^2/(ac) = %.2e, radius %d" % (i, k, a[i].ravel()[:5], np.asarray(rb[k])[i].ravel()[:5], np.asarray(b1[k])[i].ravel()[:5], 1 - co[1] ** 2 / max(co[0] * co[2], 1e-30), ref["radii"][i]))
+    if only is not None:
+        HW = H * W
+        print("     n_contrib differs at pixels", np.flatnonzero(ist["n_contrib"] != ref["n_contrib"])[:10], "final_T max diff %.2e" % np.abs(ist["final_T"] - ref["final_T"]).max())
+        dcol = np.abs(o["color"] - ref["color"]).max(0).ravel()
+        for pix in np.argsort(-dcol)[:3]:
+            print("     colour diff %.2e at pixel %d (x %d y %d): n_contrib HIP %d oracle %d, final_T %.6g / %.6g" % (dcol[pix], pix, pix % W, pix // W, ist["n_contrib"][pix], ref["n_contrib"][pix], ist["final_T"][pix], ref["final_T"][pix]))
+        if geo:
+            for k in ("median_depth", "normal_map", "warped_image", "min_depth_diff"):
+                dk = np.abs(o[k] - ref[k]).max(0).ravel(); pix = int(np.argmax(dk))
+                print("     %s max diff %.2e at pixel %d; low/high HIP %s oracle (%d, %d); sum_w %.6g / %.6g; valid HIP %s oracle %s" % (k, dk[pix], pix, ist["low_high"][pix], ref["cache_low"][pix], ref["cache_high"][pix],
+                      ist["sum_w"][pix], ref["cache_sum_w"][pix], ist["valid_idx"][:, pix], ref["valid_src_idx"][:, pix]))
     worst["color"] = max(worst["color"], dc); worst["grad"] = max(worst["grad"], gr); worst["ncontrib"] = min(worst["ncontrib"], nc)
     flag = ok and dc < 1e-5 and gr < (2e-2 if geo else 5e-3) and nc > 0.995
     bad += not flag
