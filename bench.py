@@ -337,6 +337,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="factored", choices=["factored", "dense"],
                     help="N > 1: factored = all-gather 3-float dL/dRGB per view + local SH expansion (default); dense = all-reduce of every gradient")
+    ap.add_argument("--agree-every", type=int, default=1,
+                    help="N > 1 ranks: run the reducer's host-side agreement every K-th step only (and whenever sizes change); 1 = every step")
     ap.add_argument("--forward-only", action="store_true", help="time the forward render alone (BASELINE configs[1]: --config C2 --forward-only)")
     ap.add_argument("--geo", action="store_true", help="make render_geo=True, n_src=4, L=4 the timed workload (second line of SURVEY 8(d))")
     ap.add_argument("--no-geo-line", action="store_true", help="skip the extra (untimed for `value`) geo measurement in the default line")
@@ -369,7 +371,10 @@ def main():
     wl = Workload(a.config, rank % 8, dev, a.opacity, a.geo, a.forward_only, 1234 + rank)
     reducer = None
     if world > 1:
-        reducer = vdist.ViewParallelReducer(wl.params, sh=wl.leaves["shs"], means3D=wl.leaves["means3D"], factored=(a.exchange == "factored"))
+        # the leaves go into the rasterizer as they are: its backward writes their gradients straight into the all-reduce bucket
+        reducer = vdist.ViewParallelReducer(wl.params, sh=wl.leaves["shs"], means3D=wl.leaves["means3D"], factored=(a.exchange == "factored"),
+                                            agree_every=a.agree_every,
+                                            direct={k: wl.leaves[k] for k in ("means3D", "opacities", "scales", "rotations")})
 
     def step():
         if reducer is None or a.forward_only:
@@ -405,7 +410,11 @@ def main():
         local_ms = (time.perf_counter() - t0) / n_x * 1e3
         rccl = {"world": dist.get_world_size(), "backend": backend, "exchange": a.exchange, "exchange_ms": statistics.median(xs),
                 "step_without_exchange_ms": local_ms, "exposed_ms": m["ms_step"] - local_ms,
-                "bytes_per_rank": reducer.last_bytes}
+                "bytes_per_rank": reducer.last_bytes,
+                # host time of the agreement round trip (the GPU keeps running the backward meanwhile), how often it ran, and how many
+                # parameter gradients still had to be copied into the flat bucket (0 = the backward wrote them there itself)
+                "agree_every": a.agree_every, "agree_host_ms": reducer.last_agree_ms, "agreements": reducer.n_agreements,
+                "grads_copied_into_bucket": reducer.last_packed}
 
     geo_line = None
     if world == 1 and not (a.geo or a.forward_only or a.no_geo_line):

@@ -117,25 +117,41 @@ class ViewParallelReducer:
     (e.g. ``lambda: [g["params"][0] for g in optimizer.param_groups]``) when the trainer replaces its Parameters --
     the reference's densification does (scene/gaussian_model.py:377-463: cat_tensors_to_optimizer, _prune_optimizer):
     they are re-resolved on every reduce() and the flat bucket is rebuilt when sizes change.  A fixed list that has
-    gone stale (no gradient on any tensor, or a Gaussian count that differs from the captured views') raises.
+    gone stale (no gradient on any tensor, or a Gaussian count that differs from the captured views') raises -- on
+    EVERY rank, after the agreement below (a rank that raised on its own would leave its peers waiting in a collective).
 
     Order of one reduce() (collectives are issued with async_op, i.e. on the backend's own stream):
-      1. agreement: a few integers (views captured, P, M, degree, "has a dense SH gradient") are all-reduced on the
-         HOST over a gloo side group, so ranks can never enter different collective sequences (a rank that captured
-         nothing would otherwise leave the others hanging in the all-gather); it costs no GPU time -- the GPU is still
-         running the backward kernels enqueued before;
+      1. agreement: a few integers (views captured, P, M, degree, sizes, "has a dense SH gradient", "local error") are MAX-reduced
+         on the HOST over a gloo side group, so ranks can never enter different collective sequences (a rank that captured nothing
+         would otherwise leave the others hanging in the all-gather).  It is started asynchronously before the local buffers are
+         built and waited for just before the first data collective; the GPU is still running the backward kernels enqueued before,
+         so it costs host time only (`last_agree_ms`).  `agree_every = N > 1` runs it only when this rank's own numbers changed since
+         the last call, on the first call and every N-th call -- a lone rank whose numbers change in between then hangs with its
+         peers until the side group's timeout instead of raising at once; the default (1) checks every step;
       2. all-gather of the dL/dRGB factors (ready first);  3. flat all-reduce of the dense gradients;
       4. SH expansion on the compute stream as soon as the gather has landed, WHILE the all-reduce is in flight;
-      5. unpack.
+      5. the reduced gradients are handed back as VIEWS of the flat bucket (`p.grad = view`, no copy back).
+    The copy INTO the bucket is skipped as well for every parameter whose `.grad` already lives there: `direct=` names the leaves
+    that are fed to the rasterizer as they are ({"means3D": xyz, "opacities": o, "scales": s, "rotations": q}); inside capture() the
+    first backward then writes those four gradients straight into the bucket (rasterizer._grad_out_sink) and autograd adopts them.
+    A trainer whose leaves pass through activations first (the reference's exp / sigmoid / normalize) can call `attach_grads()`
+    instead of `zero_grad()`: every dense `p.grad` becomes a zeroed view of the bucket and autograd accumulates in place.
     SH gradients that did not come through the factored path (a backward outside capture(), colours converted in
     Python, another loss term on the SH leaves) are detected in step 1 and all-reduced densely on every rank."""
 
-    def __init__(self, params, sh=None, means3D=None, group=None, expand=None, factored=True):
+    def __init__(self, params, sh=None, means3D=None, group=None, expand=None, factored=True, agree_every=1, direct=None):
         self._params, self._sh, self._means3D = params, sh, means3D
         self.group, self._expand, self.factored = group, expand, factored
+        self.agree_every = max(1, int(agree_every))
+        self._direct = direct
         self.bucket = None
         self.items = None
         self.last_bytes = 0
+        self.last_agree_ms = 0.0
+        self.last_packed = 0          # parameters whose gradient had to be copied into the bucket by the last reduce()
+        self._calls = 0
+        self.n_agreements = 0
+        self._last_sig = None
         self._agree = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # host-side agreement channel: the default group when it is gloo already, else a gloo twin of it
@@ -154,23 +170,79 @@ class ViewParallelReducer:
         m = _resolve(self._means3D)
         return m[0] if m else None
 
+    def _dense(self):
+        params, sh_parts = _resolve(self._params), self.sh_parts
+        return [p for p in params if not any(p is q for q in sh_parts)]
+
+    def _views(self, tensors):
+        """Fresh view objects of the flat bucket, one per tensor (None when the bucket does not match `tensors`)."""
+        b = self.bucket
+        if b is None or b.numels != [t.numel() for t in tensors] or b.flat.device != tensors[0].device:
+            return None
+        return b.unpack()
+
+    def attach_grads(self):
+        """Instead of zero_grad(): every dense parameter's `.grad` becomes a zeroed view of the flat bucket (ONE memset), so autograd
+        accumulates this step's gradients in place and reduce() has nothing to copy.  Returns the number of bytes attached."""
+        dense = self._dense()
+        for q in self.sh_parts:          # the SH leaves get theirs from the factored exchange (a dense one would be all-reduced, see reduce())
+            q.grad = None
+        if not dense:
+            return 0
+        self._bucket_for(dense)
+        self.bucket.flat.zero_()
+        for p, v in zip(dense, self.bucket.unpack()):
+            p.grad = v
+        return self.bucket.flat.numel() * 4
+
     def capture(self):
         from . import rasterizer
         red = self
+
+        def sink():
+            direct = _resolve_dict(red._direct)
+            if not direct:
+                return None
+            dense = red._dense()
+            if not dense:
+                return None
+            red._bucket_for(dense)
+            out = {}
+            for p, v in zip(dense, red.bucket.unpack()):
+                for name, t in direct.items():
+                    if t is p and p.grad is None:          # autograd only adopts a returned tensor when the leaf has no gradient yet
+                        out[name] = v
+            return out or None
+
+        class _Sinked:
+            def __enter__(self):
+                self._prev_sink = rasterizer._grad_out_sink
+                rasterizer._grad_out_sink = sink()
+
+            def __exit__(self, *exc):
+                rasterizer._grad_out_sink = self._prev_sink
+
         if not self.factored:
-            class _Null:
+            class _Null(_Sinked):
                 def __enter__(self):
+                    super().__enter__()
                     red.items = []
                     return red.items
 
                 def __exit__(self, *exc):
+                    super().__exit__(*exc)
                     return False
             return _Null()
 
         class _Ctx(rasterizer.capture_sh_factors):
             def __enter__(self):
+                self._s = _Sinked(); self._s.__enter__()
                 red.items = super().__enter__()
                 return red.items
+
+            def __exit__(self, *exc):
+                self._s.__exit__(*exc)
+                return super().__exit__(*exc)
         return _Ctx()
 
     def _bucket_for(self, tensors):
@@ -180,60 +252,92 @@ class ViewParallelReducer:
         return self.bucket
 
     def reduce(self, average=False):
+        import time
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
         params, sh_parts, means3D = _resolve(self._params), self.sh_parts, self.means3D
         items, self.items = self.items or [], None
         dense = [p for p in params if not any(p is q for q in sh_parts)]
-        # ---- local sanity (stale references after densification surface here, not as silently frozen parameters)
+        # ---- local sanity (stale references after densification surface here, not as silently frozen parameters).  Nothing is
+        # raised before the agreement: a rank that left now would never enter the collectives its peers are about to wait in.
+        err = None
         if params and all(p.grad is None for p in params) and not items:
-            raise RuntimeError("ViewParallelReducer.reduce(): no tensor in `params` has a gradient -- were the Parameters replaced "
-                               "(densification)? Pass callables for params / sh / means3D or rebuild the reducer.")
+            err = ("ViewParallelReducer.reduce(): no tensor in `params` has a gradient -- were the Parameters replaced "
+                   "(densification)? Pass callables for params / sh / means3D or rebuild the reducer.")
         n_local = len(items)
         P = int(items[0]["dcolor"].shape[0]) if items else (int(means3D.shape[0]) if means3D is not None else -1)
         M = int(items[0]["M"]) if items else -1
         degree = int(items[0]["degree"]) if items else -1
         for it in items:
-            if int(it["dcolor"].shape[0]) != P or int(it["M"]) != M or int(it["degree"]) != degree:
-                raise RuntimeError("ViewParallelReducer: captured views disagree on (P, M, degree)")
-        if items and (means3D is None or int(means3D.shape[0]) != P):
-            raise RuntimeError("ViewParallelReducer: means3D has %s rows but the captured views have P = %d (stale reference after "
-                               "densification?)" % ("no" if means3D is None else int(means3D.shape[0]), P))
-        if items and sum(int(q.shape[1]) for q in sh_parts) != M:
-            raise RuntimeError("ViewParallelReducer: the `sh` leaves hold %d coefficients, the captured views M = %d"
-                               % (sum(int(q.shape[1]) for q in sh_parts), M))
+            if err is None and (int(it["dcolor"].shape[0]) != P or int(it["M"]) != M or int(it["degree"]) != degree):
+                err = "ViewParallelReducer: captured views disagree on (P, M, degree)"
+        if err is None and items and (means3D is None or int(means3D.shape[0]) != P):
+            err = ("ViewParallelReducer: means3D has %s rows but the captured views have P = %d (stale reference after "
+                   "densification?)" % ("no" if means3D is None else int(means3D.shape[0]), P))
+        if err is None and items and sum(int(q.shape[1]) for q in sh_parts) != M:
+            err = ("ViewParallelReducer: the `sh` leaves hold %d coefficients, the captured views M = %d"
+                   % (sum(int(q.shape[1]) for q in sh_parts), M))
         # an SH gradient that did not come through the factored path must be reduced densely
         sh_dense = any(q.grad is not None for q in sh_parts)
-        # ---- agreement across ranks, on the host
-        if world > 1:
-            mine = [n_local, P, M, degree, sum(p.numel() for p in dense), sum(q.numel() for q in sh_parts)]
-            v = torch.tensor(mine + [-x for x in mine] + [int(sh_dense)], dtype=torch.int64)
-            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._agree)
-            k = len(mine)
-            hi, lo = v[:k].tolist(), [-x for x in v[k:2 * k].tolist()]
-            if hi != lo:
-                raise RuntimeError("ViewParallelReducer: ranks disagree on (views captured, P, M, degree, dense numel, sh numel): "
-                                   "max %s min %s -- every rank must run the same number of backward passes inside capture()" % (hi, lo))
-            sh_dense = bool(v[2 * k].item())
-        # ---- 2. factors on the wire first
-        work_g, buf = None, None
-        if items:
+        # ---- 1. agreement across ranks, on the host, asynchronously: it travels while the buffers below are set up
+        mine = [n_local, P, M, degree, sum(p.numel() for p in dense), sum(q.numel() for q in sh_parts)]
+        sig = (tuple(mine), bool(sh_dense))
+        self._calls += 1
+        agree = world > 1 and (self.agree_every == 1 or self._calls == 1 or (self._calls - 1) % self.agree_every == 0
+                               or sig != self._last_sig or err is not None)
+        self._last_sig = sig
+        work_a, v, t_agree = None, None, 0.0
+        if agree:
+            v = torch.tensor(mine + [-x for x in mine] + [int(sh_dense), int(err is not None)], dtype=torch.int64)
+            t0 = time.perf_counter()
+            work_a = dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._agree, async_op=True)
+            self.n_agreements += 1
+            t_agree = time.perf_counter() - t0
+        elif world == 1 and err is not None:
+            raise RuntimeError(err)
+        # ---- buffers: factors of the local views; the flat bucket (gradients that already live in it are not copied)
+        buf = None
+        if items and err is None:
             dev = items[0]["dcolor"].device
             # one buffer per exchange: each view's (P, 3) factor followed by its camera centre -> ONE all-gather
             buf = torch.empty(n_local, P + 1, 3, dtype=torch.float32, device=dev)
             for i, it in enumerate(items):
                 buf[i, :P] = it["dcolor"]
                 buf[i, P] = it["campos"].to(dev)
-            if world > 1:
-                allb = torch.empty(world * n_local, P + 1, 3, dtype=buf.dtype, device=dev)
-                work_g = dist.all_gather_into_tensor(allb, buf, group=self.group, async_op=True)
-                buf = allb
+        if work_a is not None:
+            t0 = time.perf_counter()
+            work_a.wait()
+            self.last_agree_ms = (t_agree + time.perf_counter() - t0) * 1e3
+            k = len(mine)
+            hi, lo = v[:k].tolist(), [-x for x in v[k:2 * k].tolist()]
+            if bool(v[2 * k + 1].item()):
+                raise RuntimeError(err if err is not None else "ViewParallelReducer: another rank failed its local checks (stale parameters "
+                                   "after densification, or views that disagree on (P, M, degree)); no collective was started")
+            if hi != lo:
+                raise RuntimeError("ViewParallelReducer: ranks disagree on (views captured, P, M, degree, dense numel, sh numel): "
+                                   "max %s min %s -- every rank must run the same number of backward passes inside capture()" % (hi, lo))
+            sh_dense = bool(v[2 * k].item())
+        elif err is not None:
+            raise RuntimeError(err)
+        # ---- 2. factors on the wire first
+        work_g = None
+        if buf is not None and world > 1:
+            allb = torch.empty(world * n_local, P + 1, 3, dtype=buf.dtype, device=buf.device)
+            work_g = dist.all_gather_into_tensor(allb, buf, group=self.group, async_op=True)
+            buf = allb
         # ---- 3. dense gradients (plus the SH leaves when some rank holds a dense SH gradient)
         flat_list = dense + (sh_parts if sh_dense else [])
-        work_d, bucket = None, None
+        work_d, bucket, views = None, None, None
+        self.last_packed = 0
         if world > 1 and flat_list:
             bucket = self._bucket_for(flat_list)
-            flat = bucket.pack([p.grad for p in flat_list])
-            work_d = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            views = bucket.unpack()
+            for p, view in zip(flat_list, views):
+                g = p.grad
+                if g is None:
+                    view.zero_(); self.last_packed += 1
+                elif not (g.data_ptr() == view.data_ptr() and g.numel() == view.numel() and g.is_contiguous()):
+                    view.copy_(g.reshape(view.shape)); self.last_packed += 1          # a gradient that lives elsewhere: one copy in
+            work_d = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.last_bytes = (0 if bucket is None else bucket.flat.numel() * 4) + (0 if (buf is None or world == 1) else n_local * (P + 1) * 12)
         # ---- 4. SH expansion overlaps the all-reduce
         g_sh = None
@@ -245,16 +349,13 @@ class ViewParallelReducer:
                 from .shgrad import sh_grad_from_views as expand
             dcolor, campos = buf[:, :P], buf[:, P].contiguous()      # dcolor keeps the (P + 1) * 3 view stride
             g_sh = expand(means3D.detach(), campos, dcolor, degree, M)
-        # ---- 5. unpack
+        # ---- 5. hand the sums back: views of the bucket, no copy
         if work_d is not None:
             work_d.wait()
             if average:
                 bucket.flat.div_(world)
-            for p, g in zip(flat_list, bucket.unpack()):
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+            for p, view in zip(flat_list, views):
+                p.grad = view
         if g_sh is not None:
             if average:
                 g_sh = g_sh / world
@@ -264,6 +365,15 @@ class ViewParallelReducer:
                 gp = g_sh[:, off:off + m, :].contiguous() if len(sh_parts) > 1 else g_sh.view_as(part)
                 part.grad = gp if part.grad is None else part.grad + gp      # part.grad (if any) is already the all-rank sum
                 off += m
+
+
+def _resolve_dict(d):
+    """{"name": tensor | callable} or a callable returning such a dict -> {"name": tensor}."""
+    if d is None:
+        return {}
+    if callable(d):
+        d = d()
+    return {k: (v() if (callable(v) and not isinstance(v, torch.Tensor)) else v) for k, v in (d or {}).items()}
 
 
 def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None):
@@ -290,13 +400,37 @@ def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, gro
 def seed_for_densification(iteration, base_seed=0, devices=None):
     """Give every rank the SAME generator state before a densification step: seeds torch's CPU generator and the generators of
     `devices` (default: the current HIP device, if any) with a value that depends only on (base_seed, iteration).  Call it on every rank
-    right before `gaussians.densify_and_prune(...)`; the replicas then draw identical samples and stay bit-identical."""
+    right before `gaussians.densify_and_prune(...)`; the replicas then draw identical samples and stay bit-identical.
+    This reseeds the GLOBAL generators for good: everything drawn afterwards (the trainer's random background, augmentation noise) is
+    then identical on all ranks and restarts from a predictable value -- prefer `synchronized_densification_rng`, which puts the
+    generators back."""
     seed = (int(base_seed) * 1000003 + int(iteration)) & 0x7FFFFFFF
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         for d in (devices if devices is not None else [torch.cuda.current_device()]):
             torch.cuda.manual_seed(seed) if d == torch.cuda.current_device() else torch.cuda.default_generators[d].manual_seed(seed)
     return seed
+
+
+class synchronized_densification_rng:
+    """`with synchronized_densification_rng(iteration, base_seed): gaussians.densify_and_prune(...)` -- inside the block every rank
+    draws from generators seeded with the same (base_seed, iteration) value, so densify_and_split's `torch.normal` samples agree; on
+    exit the CPU and device generators continue exactly where they were (torch.random.fork_rng), so the ranks' other random draws stay
+    independent of each other and of the densification schedule."""
+
+    def __init__(self, iteration, base_seed=0, devices=None):
+        self.iteration, self.base_seed = iteration, base_seed
+        if devices is None:
+            devices = [torch.cuda.current_device()] if torch.cuda.is_available() else []
+        self.devices = list(devices)
+
+    def __enter__(self):
+        self._fork = torch.random.fork_rng(devices=self.devices)
+        self._fork.__enter__()
+        return seed_for_densification(self.iteration, self.base_seed, self.devices if self.devices else None)
+
+    def __exit__(self, *exc):
+        return self._fork.__exit__(*exc)
 
 
 def assert_replicas_identical(tensors, group=None, what="parameters"):

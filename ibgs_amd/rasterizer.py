@@ -56,6 +56,23 @@ def _shape_flag():
 _sh_factor_sink = None
 
 
+# Zero-copy gradient hand-over for the view-parallel exchange (ibgs_amd/dist.py): while set, the NEXT backward writes dL/dmeans3D,
+# dL/dopacity, dL/dscales, dL/drotations straight into these caller-owned buffers (views of the flat all-reduce bucket; ibgs_backward
+# writes to caller-supplied pointers anyway) and returns them as its gradients -- when the leaves are fed to the rasterizer as they are,
+# autograd adopts them as `.grad` and the exchange needs no pack copy.  {"means3D": (P,3), "opacities": (P,1), "scales": (P,3),
+# "rotations": (P,4)} -> tensors; consumed (emptied) by the first backward that uses it.
+_grad_out_sink = None
+
+
+def _sink_or_new(name, shape, new, opts):
+    sink = _grad_out_sink
+    if sink:
+        t = sink.pop(name, None)
+        if t is not None and tuple(t.shape) == tuple(shape) and t.is_contiguous() and t.dtype == torch.float32 and t.device == opts["device"]:
+            return t
+    return new(*shape, **opts)
+
+
 class capture_sh_factors:
     def __enter__(self):
         global _sh_factor_sink
@@ -344,7 +361,7 @@ class _CModule:
             # ibgs_backward overwrites every element of its outputs (zeros for invisible Gaussians): no memsets
             have_sr = scales is not None and scales.numel() != 0
             new = torch.empty if P != 0 else torch.zeros
-            dL_dmeans3D = new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
+            dL_dmeans3D = _sink_or_new("means3D", (P, 3), new, opts) if P != 0 else new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
             dL_dmeans2D_abs = new(P, 3, **opts)
             # gradients of inputs the mode does not use: zeros without a fill (the reference memsets them, rasterize_points.cu:196-206)
             fused = plane is not None and bool(plane[2])
@@ -355,7 +372,7 @@ class _CModule:
                 want = render_geo and P != 0
                 dL_dplane_normal = (new(P, 3, **opts) if want else _zeros_view((P, 3), device)) if (learnt and plane[0] is not None) else None
                 dL_dplane_offset = (new(P, 1, **opts) if want else _zeros_view((P, 1), device)) if (learnt and plane[1] is not None) else None
-            dL_dopacity = new(P, 1, **opts)
+            dL_dopacity = _sink_or_new("opacities", (P, 1), new, opts) if P != 0 else new(P, 1, **opts)
             factored = _sh_factor_sink is not None and M != 0 and P != 0
             # skip_unused (the autograd node sets it): dL/dcolors and dL/dcov3D are the gradients of colors_precomp / cov3D_precomp -- with
             # SH coefficients and scales + rotations as inputs nobody reads them (the reference writes them regardless, 36 B per Gaussian)
@@ -364,8 +381,8 @@ class _CModule:
             dL_dcolors = new(P, NUM_CHANNELS, **opts) if want_colors else _zeros_view((P, NUM_CHANNELS), device)
             dL_dcov3D = new(P, 6, **opts) if want_cov else _zeros_view((P, 6), device)
             dL_dsh = None if factored else new(P, M, 3, **opts)
-            dL_dscales = new(P, 3, **opts) if (have_sr and P != 0) else _zeros_view((P, 3), device)
-            dL_drotations = new(P, 4, **opts) if (have_sr and P != 0) else _zeros_view((P, 4), device)
+            dL_dscales = _sink_or_new("scales", (P, 3), new, opts) if (have_sr and P != 0) else _zeros_view((P, 3), device)
+            dL_drotations = _sink_or_new("rotations", (P, 4), new, opts) if (have_sr and P != 0) else _zeros_view((P, 4), device)
             if P != 0:
                 means3D_c = _dev_f32(means3D, device); colors_c = _dev_f32(colors, device)
                 scales_c = _dev_f32(scales, device); rot_c = _dev_f32(rotations, device)

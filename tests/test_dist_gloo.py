@@ -244,3 +244,75 @@ def test_densification_samples_agree_across_ranks(tmp_path):
     r0, r1 = torch.load(tmp_path / "d0.pt"), torch.load(tmp_path / "d1.pt")
     assert torch.equal(r0["split"], r1["split"])
     assert r0["err"] and r1["err"] and "diverged" in r0["err"] and "diverged" in r1["err"]      # the guard fires on both ranks
+
+
+# ---- round 3: a local error on ONE rank reaches every rank through the agreement; sparse agreement; gradients that live in the bucket ----
+def _worker_round3(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(0)
+    P, M, deg = 24, 16, 3
+    state = {"xyz": torch.randn(P, 3, generator=g).requires_grad_(True), "sh": torch.randn(P, M, 3, generator=g).requires_grad_(True),
+             "opa": torch.rand(P, 1, generator=g).requires_grad_(True)}
+    gr = torch.Generator().manual_seed(100 + rank)
+    out = {}
+
+    # (a) rank 1 alone holds a stale means3D (P differs from its captured views): BOTH ranks must raise, nobody may hang
+    stale = torch.randn(P + 5, 3)
+    red = vdist.ViewParallelReducer([state["xyz"], state["sh"], state["opa"]], sh=state["sh"], means3D=(stale if rank == 1 else state["xyz"]), expand=_expand_ref)
+    for k in ("xyz", "opa"):
+        state[k].grad = torch.randn(state[k].shape, generator=gr)
+    with red.capture() as sink:
+        sink.append({"dcolor": torch.randn(P, 3, generator=gr), "campos": torch.randn(3, generator=gr), "degree": deg, "M": M})
+    try:
+        red.reduce()
+        out["a"] = "no error"
+    except RuntimeError as ex:
+        out["a"] = str(ex)
+
+    # (b) agree_every = 4: the agreement runs on call 1, when the own numbers change, and every 4th call; sums stay right
+    red = vdist.ViewParallelReducer(lambda: [state["xyz"], state["sh"], state["opa"]], sh=lambda: state["sh"], means3D=lambda: state["xyz"],
+                                    expand=_expand_ref, agree_every=4)
+    out["b"] = []
+    for step in range(6):
+        if step == 2:          # "densification": every rank replaces its tensors, sizes change everywhere
+            state = {"xyz": torch.randn(P + 3, 3, generator=g).requires_grad_(True), "sh": torch.randn(P + 3, M, 3, generator=g).requires_grad_(True),
+                     "opa": torch.rand(P + 3, 1, generator=g).requires_grad_(True)}
+        n = state["xyz"].shape[0]
+        red.attach_grads()                                        # gradients accumulate inside the flat bucket
+        lx, lo = torch.randn(n, 3, generator=gr), torch.randn(n, 1, generator=gr)
+        state["xyz"].grad += lx; state["opa"].grad += lo          # what autograd's in-place accumulation does
+        with red.capture() as sink:
+            sink.append({"dcolor": torch.randn(n, 3, generator=gr), "campos": torch.randn(3, generator=gr), "degree": deg, "M": M})
+        red.reduce()
+        out["b"].append({"lx": lx, "xyz": state["xyz"].grad.clone(), "agreements": red.n_agreements, "packed": red.last_packed,
+                         "alias": state["xyz"].grad.data_ptr() == red.bucket.unpack()[0].data_ptr()})
+
+    # (c) the scoped generator for densification: same samples on every rank, generators back where they were afterwards
+    torch.manual_seed(1000 + rank)
+    _ = torch.rand(2 + rank)
+    before = torch.get_rng_state().clone()
+    with vdist.synchronized_densification_rng(iteration=700, base_seed=5):
+        out["c_split"] = torch.normal(mean=torch.zeros(4, 3), std=torch.ones(4, 3))
+    out["c_restored"] = torch.equal(before, torch.get_rng_state())
+    out["c_next"] = torch.rand(3)
+    torch.save(out, os.path.join(out_dir, "h%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_local_errors_sparse_agreement_and_bucket_resident_gradients(tmp_path):
+    world = 2
+    mp.spawn(_worker_round3, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "h%d.pt" % r)) for r in range(world)]
+    assert "stale reference" in res[1]["a"], res[1]["a"]                       # the rank that saw it reports it ...
+    assert "another rank failed its local checks" in res[0]["a"], res[0]["a"]  # ... and its peer raises too instead of waiting in a collective
+    for step in range(6):
+        want = res[0]["b"][step]["lx"] + res[1]["b"][step]["lx"]
+        for r in res:
+            np.testing.assert_allclose(r["b"][step]["xyz"].numpy(), want.numpy(), rtol=1e-6)
+            assert r["b"][step]["packed"] == 0 and r["b"][step]["alias"]       # nothing copied in, the sum is handed back as a view
+    assert [x["agreements"] for x in res[0]["b"]] == [1, 1, 2, 2, 3, 3]        # call 1, the size change at call 3, the 4th-call schedule at call 5
+    assert torch.equal(res[0]["c_split"], res[1]["c_split"])
+    assert res[0]["c_restored"] and res[1]["c_restored"]
+    assert not torch.equal(res[0]["c_next"], res[1]["c_next"])                 # the ranks' own streams stay independent

@@ -64,6 +64,8 @@ def test_bench_self_launches_its_ranks():
     x = d["rccl"]
     assert x["world"] == 2 and x["backend"] == "gloo" and x["exchange"] == "factored" and x["exchange_ms"] > 0 and x["bytes_per_rank"] > 0
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    # the backward wrote the four dense gradients straight into the all-reduce bucket (no pack copy), and the host agreed every step
+    assert x["grads_copied_into_bucket"] == 0 and x["agreements"] >= d["steps"] and x["agree_host_ms"] >= 0
 
 
 def test_bench_refuses_missing_gpus_without_touching_them():
