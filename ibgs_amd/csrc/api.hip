@@ -182,6 +182,16 @@ size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H) { size_t t; BinSta
 size_t ibgs_required_deterministic(int64_t R, int32_t P) { size_t t; DetState::carve(nullptr, (size_t)(R > 0 ? R : 0) * 4, (size_t)(P > 0 ? P : 0), &t); return t; }   // x 4: up to four waves per tile
 size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H) { return (size_t)n_src * W * H * sizeof(float4) + 128; }
 size_t ibgs_required_geo_table(int32_t W, int32_t H) { return geo_table_floats(W, H) * sizeof(float) + 128; }
+size_t ibgs_required_geo_table_for(int32_t W, int32_t H, int32_t L)
+{   // the window pass writes at most L entries and a terminator in slot L (render_bwd.hip); the blend loop reads no further
+    const int slots = (L >= 1 && L < IBGS_MAX_BUFFER_LENGTH) ? L + 1 : IBGS_MAX_BUFFER_LENGTH;
+    return (size_t)W * H * slots * GEO_TAB_FIELDS * sizeof(float) + 128;
+}
+size_t ibgs_required_deterministic_for(int64_t R, int32_t P, int32_t W, int32_t H, int32_t render_geo, uint32_t flags)
+{
+    ibgs_backward_args a{}; a.W = W; a.H = H; a.render_geo = render_geo; a.flags = flags;
+    size_t t; DetState::carve(nullptr, (size_t)(R > 0 ? R : 0) * render_backward_waves_per_tile(a), (size_t)(P > 0 ? P : 0), &t); return t;
+}
 
 #define OFF(base_struct, field) if (!strcmp(name, #field)) return (int64_t)((char*)base_struct.field - (char*)nullptr)
 int64_t ibgs_geom_offset(int32_t P, const char* name)
@@ -375,7 +385,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         }
         if (!a.out_depth || !a.out_warped || !a.ref_to_src || !a.src_images) { set_error("geo backward inputs missing"); return -IBGS_ERR_INVALID; }
         if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
-        if (!a.geo_table || a.geo_table_bytes < ibgs_required_geo_table(a.W, a.H)) { set_error("geo_table scratch too small"); return -IBGS_ERR_ALLOC; }
+        if (!a.geo_table || a.geo_table_bytes < (a.buffer_length > 0 ? ibgs_required_geo_table_for(a.W, a.H, a.buffer_length) : ibgs_required_geo_table(a.W, a.H))) { set_error("geo_table scratch too small"); return -IBGS_ERR_ALLOC; }
     }
     int rc;
     GeomState g = GeomState::carve(a.geom, (size_t)a.P, nullptr);
@@ -394,7 +404,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         DetState ds{};
         int ipt = 1;
         if (det) {
-            if (!a.det_scratch || a.det_scratch_bytes < ibgs_required_deterministic(a.R, a.P)) { set_error("det_scratch too small"); return -IBGS_ERR_ALLOC; }
+            if (!a.det_scratch || a.det_scratch_bytes < ibgs_required_deterministic_for(a.R, a.P, a.W, a.H, a.render_geo, a.flags)) { set_error("det_scratch too small"); return -IBGS_ERR_ALLOC; }
             ipt = render_backward_waves_per_tile(a);
             ds = DetState::carve(a.det_scratch, (size_t)a.R * ipt, (size_t)a.P, nullptr);
             if ((rc = launch_det_prepare(s, ds, (size_t)a.R * ipt))) return rc;

@@ -264,7 +264,8 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
                      uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false);
 size_t radix_zero_elems(size_t n, int nbits);      // leading words of `hist` the sort needs zeroed (see scratch_is_zero)
 // err_dev: device word (zeroed by the caller) that the single-launch look-back passes set to 1 when their bounded spin gives up --
-//          the pass has then scattered with a partial prefix; the caller must read it back and fail the call
+//          the pass has then scattered with a partial prefix; the caller must read it back and fail the call.  With err_dev == nullptr
+//          radix_sort_pairs reads its own flag back (one stream synchronisation) and fails the call itself
 // kept_dev: device word (zeroed by the caller).  When given, pairs whose key is 0xFFFFFFFF need not be carried: *kept_dev receives the
 //          number K of other pairs, the result holds those K pairs sorted in [0, K) and unspecified pairs behind them
 // scratch_is_zero: the caller has zeroed hist[0, radix_zero_elems(n, nbits)) on the stream already

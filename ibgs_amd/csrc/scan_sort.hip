@@ -499,6 +499,15 @@ static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t*
         IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
+    if (!err_dev) {
+        // A caller without an error word of its own (the deterministic backward's id sort, the knn's Morton sort: neither is on the
+        // training step's fast path) gets the flag checked HERE: a look-back that gave up has scattered with a partial prefix, and a
+        // mis-sorted result must fail the call instead of passing as "bit-identical" gradients.  One 4-byte read-back.
+        uint32_t flag = 0;
+        IBGS_HIP(hipMemcpyAsync(&flag, tickets + 32, sizeof(flag), hipMemcpyDeviceToHost, s));
+        IBGS_HIP(hipStreamSynchronize(s));
+        if (flag) { set_error("radix sort: a decoupled look-back timed out (result discarded)"); return -IBGS_ERR_HIP; }
+    }
     return 0;
 }
 

@@ -345,9 +345,10 @@ class _CModule:
                                      src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
                                      dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False):
+                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False, buffer_length=0):
         """The reference's 34 positional arguments and 10 results; with `plane` (see rasterize_gaussians) two more
-        results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1)."""
+        results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1).  `buffer_length` (the forward's; not among the reference's
+        arguments, 0 = unknown) only sizes the geo backward's scratch table."""
         lib = _lib.load()
         device = means3D.device
         P = int(means3D.size(0))
@@ -424,7 +425,8 @@ class _CModule:
                     else:
                         tex, _ = _tex_packed(device, nbytes)
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
-                    tab = _tex(device, lib.ibgs_required_geo_table(W, H), "geo_table")
+                    a.buffer_length = int(buffer_length)
+                    tab = _tex(device, lib.ibgs_required_geo_table_for(W, H, int(buffer_length)), "geo_table")
                     a.geo_table = tab.data_ptr(); a.geo_table_bytes = tab.numel()
                 a.dL_dcolor = _ptr(g_color); a.dL_dnormal = _ptr(g_normal); a.dL_ddepth = _ptr(g_depth); a.dL_dwarped = _ptr(g_warp)
                 a.grad_acc = grad_acc.data_ptr()
@@ -443,7 +445,7 @@ class _CModule:
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
                            | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag() | tex_flag)
                 if DETERMINISTIC and int(R) > 0:
-                    det = torch.empty(lib.ibgs_required_deterministic(int(R), P), dtype=torch.uint8, device=device)
+                    det = torch.empty(lib.ibgs_required_deterministic_for(int(R), P, W, H, int(render_geo), int(a.flags)), dtype=torch.uint8, device=device)
                     a.det_scratch = det.data_ptr(); a.det_scratch_bytes = det.numel()
                     a.flags |= _lib.FLAG_DETERMINISTIC
                 rc = lib.ibgs_backward(ctypes.byref(a))
@@ -615,6 +617,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if getattr(ctx, "packed_tex", None) is not None:
             kw["packed_tex"] = ctx.packed_tex
         kw["skip_unused"] = True
+        kw["buffer_length"] = int(raster_settings.buffer_length)
 
         # argument order of the reference's _C.rasterize_gaussians_backward (reference __init__.py:182-221)
         args = (raster_settings.bg, normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels,

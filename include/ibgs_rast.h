@@ -235,10 +235,16 @@ typedef struct ibgs_backward_args {
     char* geo_table; size_t geo_table_bytes;
     /* IBGS_FLAG_DETERMINISTIC: transient scratch of >= ibgs_required_deterministic(R, P) bytes (slab R x 16 floats + sort buffers) */
     char* det_scratch; size_t det_scratch_bytes;
+    /* the forward's buffer_length (0 = not stated).  When stated, geo_table only needs ibgs_required_geo_table_for(W, H, buffer_length)
+     * bytes and det_scratch ibgs_required_deterministic_for(R, P, W, H, render_geo, flags) */
+    int32_t buffer_length;
 } ibgs_backward_args;
 
-size_t ibgs_required_deterministic(int64_t R, int32_t P);
-size_t ibgs_required_geo_table(int32_t W, int32_t H);
+size_t ibgs_required_deterministic(int64_t R, int32_t P);          /* any frame, any flags: four rows per list entry */
+size_t ibgs_required_deterministic_for(int64_t R, int32_t P, int32_t W, int32_t H, int32_t render_geo, uint32_t flags);   /* rows = the waves per tile
+                                                                      the backward will use for this frame (1 from 4096 tiles on): a quarter at 1080p */
+size_t ibgs_required_geo_table(int32_t W, int32_t H);              /* any buffer_length (8 slots) */
+size_t ibgs_required_geo_table_for(int32_t W, int32_t H, int32_t buffer_length);   /* buffer_length + 1 slots: 250 MB instead of 400 MB at 1080p, L = 4 */
 size_t ibgs_required_geom(int32_t P);
 size_t ibgs_required_img(int32_t W, int32_t H);
 size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H);
