@@ -61,21 +61,40 @@ def algorithmic_bytes(P, R, HW, Mc, tiles, geo=False, n_src=0):
     return b_fwd, b_bwd, b_render_fwd, b_render_bwd
 
 
+def implementation_bytes(P, kept, R, C, HW, Mc):
+    """Bytes THIS design moves per step (DESIGN.md "Algorithmic bytes of the implementation"): SURVEY's model charges the reference's
+    R-sized 64-bit sort (R x 24 B x 6 passes); here the sort is P-sized and the lists are placed directly.
+    kept = Gaussians with tiles, C = coarse binning entries (one per Gaussian and 8 x 8-tile cell)."""
+    pre = P * (44 + 12 * Mc) + P * (64 + 16 + 4 + 4 + 24 + 1 + 8)          # inputs; record, footprint, depth, tiles, cov3D, clamp bits, sort pair
+    sort = P * 8 + kept * 16 * 4                                           # first pass reads every pair; four passes move the kept ones (key + id, in + out)
+    binning = kept * 16 * 3 + C * 16 * 3 + R * 4                           # footprints (gather, re-store, read); coarse entries (write, two reads); list write
+    fwd = R * (4 + 48) + HW * 20                                           # list + three record quads per entry; colour, final_T, n_contrib out
+    bwd = R * (4 + 48) + HW * (8 + 12) + kept * 128                        # the same walk; per-pixel state and dL/dC in; one 64-B row read-modify-write per touched Gaussian
+    pre_bwd = kept * (64 + 32 + 44 + 12 * Mc) + kept * (12 * Mc + 12 + 12 + 4 + 12 + 16) + P * 64          # rows, record, inputs; outputs; re-zeroed rows
+    return pre + sort + binning + fwd + bwd + pre_bwd
+
+
 def profile_counters(kernel_substr, workload_tag):
     """Per-launch PMC counters of one kernel from the committed rocprofv3 summary (profiles/counters_latest.json, written by
     profiles/summarize.py).  Returns (counters, source) -- (None, reason) when the summary was taken on other kernel
     sources or another workload: stale numbers are dropped, not quoted next to fresh timings."""
-    path = os.path.join(ROOT, "profiles", "counters_latest.json")
-    if not os.path.exists(path):
-        return None, "no profiles/counters_latest.json"
-    try:
-        d = json.load(open(path))
-    except Exception as ex:   # noqa: BLE001
-        return None, "unreadable profile summary: %s" % ex
-    if d.get("csrc_sha") != csrc_sha():
-        return None, "profile taken on csrc %s, this build is %s" % (d.get("csrc_sha"), csrc_sha())
-    if d.get("workload") != workload_tag:
-        return None, "profile workload %r != %r" % (d.get("workload"), workload_tag)
+    # every profiles/*_counters.json carries the workload tag and the kernel-source fingerprint it was taken on: pick the one that matches both
+    import glob
+    sha, reason, d = csrc_sha(), "no profiles/*_counters.json for workload %r" % workload_tag, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), key=os.path.getmtime, reverse=True):
+        try:
+            c = json.load(open(path))
+        except Exception:   # noqa: BLE001
+            continue
+        if c.get("workload") != workload_tag:
+            continue
+        if c.get("csrc_sha") != sha:
+            reason = "profile of %r taken on csrc %s, this build is %s" % (workload_tag, c.get("csrc_sha"), sha)
+            continue
+        d = c
+        break
+    if d is None:
+        return None, reason
     for k, c in d.get("per_launch_counters", {}).items():
         if kernel_substr in k:
             return c, "profiles/%s @ csrc %s (%s)" % (d.get("tag", "counters_latest") + "_counters.json", d["csrc_sha"], d.get("date", "?"))
@@ -85,6 +104,7 @@ def profile_counters(kernel_substr, workload_tag):
 class Workload:
     """One view of one BASELINE config resident on `dev`: leaves, settings, the step closure."""
     CLUSTER = 0.0
+    torch_l1 = False
 
     def __init__(self, cfg, view, dev, opacity, geo, forward_only, target_seed):
         c = syn.CONFIGS[cfg]
@@ -138,6 +158,16 @@ class Workload:
         self.geo_targets = (torch.zeros(3, H, W, device=dev), torch.zeros(1, H, W, device=dev), torch.full((15, H, W), 0.5, device=dev)) if geo else None
         self.R = 0
 
+    def hop_to(self, view):
+        """Point the (colour) workload at another orbit camera: same Gaussians, same target, new matrices."""
+        cam = syn.make_camera(self.W, self.H, azimuth_deg=45.0 * view)
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.dev)
+        if not hasattr(self, "_hop"):
+            self._hop = {}
+        if view not in self._hop:
+            self._hop[view] = GaussianRasterizer(self.st._replace(viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"])))
+        self.rast = self._hop[view]
+
     def _call(self):
         lv = self.leaves
         return self.rast(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
@@ -156,7 +186,10 @@ class Workload:
         for v in self.leaves.values():
             v.grad = None
         outs = self._call()
-        loss = l1_loss(outs[0], self.target)          # the reference's l1_loss (utils/loss_utils.py:23-24) as one pass: value + gradient
+        if self.torch_l1:
+            loss = torch.abs(outs[0] - self.target).mean()          # utils/loss_utils.py:23-24 as the reference writes it
+        else:
+            loss = l1_loss(outs[0], self.target)      # the same value and gradient in one pass each (ibgs_amd.losses)
         if self.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
             loss = loss + l1_loss(outs[2], self.geo_targets[0]) + l1_loss(outs[3], self.geo_targets[1]) + l1_loss(outs[5], self.geo_targets[2])
         self.R = outs[0].grad_fn.num_rendered
@@ -284,6 +317,81 @@ def cpu_baseline(inp, c):
                       % (t1 - t0, t2 - t1, c)}
 
 
+def cpu_baseline_c1(dev):
+    """config C1 (10 k Gaussians, 400 x 400, SH 3) on the host cores with 8 threads (what the reference pins:
+    train.py:453, render.py:396) and with all cores, median of 5 after one warm-up, forward and forward + backward; the HIP path at the
+    same inputs beside it.  The CPU path is the oracle (oracle/ibgs_oracle.c, OpenMP over pixels / Gaussians) -- the reference itself has
+    no CPU rasterizer."""
+    import oracle
+    lib = oracle.lib()
+    c = syn.CONFIGS["C1"]
+    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"])
+    g = np.random.default_rng(1).standard_normal((3, c["H"], c["W"])).astype(np.float32)
+    all_cores = int(lib.orc_num_threads())
+    res = {}
+    for n in (8, all_cores):
+        lib.orc_set_num_threads(int(n))
+        tf, tb = [], []
+        for it in range(6):
+            t0 = time.perf_counter(); f = oracle.forward(inp); t1 = time.perf_counter(); oracle.backward(inp, f, g); t2 = time.perf_counter()
+            if it:
+                tf.append((t1 - t0) * 1e3); tb.append((t2 - t0) * 1e3)
+        res["threads_%d" % n] = {"fwd_ms": statistics.median(tf), "fwd_bwd_ms": statistics.median(tb)}
+    lib.orc_set_num_threads(all_cores)
+    wl = Workload("C1", 0, dev, "init", False, False, 7)
+    gt = torch.as_tensor(g, device=dev)
+
+    def hip_step(backward):
+        for v in wl.leaves.values():
+            v.grad = None
+        o = wl._call()[0]
+        if backward:
+            (o * gt).sum().backward()
+    out = {}
+    for name, bw in (("fwd_ms", False), ("fwd_bwd_ms", True)):
+        for _ in range(5):
+            hip_step(bw)
+        ts = []
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); hip_step(bw); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        out[name] = statistics.median(ts)
+    res["hip"] = out
+    res["speedup_fwd_bwd_vs_8_threads"] = res["threads_8"]["fwd_bwd_ms"] / out["fwd_bwd_ms"]
+    res["config"] = "C1: 10000 random-init Gaussians, 400x400, SH degree 3, render_geo=False, seed 1; median of 5 (CPU) / 20 (HIP)"
+    return res
+
+
+def test_frame(dev, c):
+    """The reference's test-time frame (render.py:126-156, gaussian_renderer/__init__.py:228-267 with do_render_src_depth): the depth maps of
+    the 4 source views are rendered first (here ONE batched depth-only pass), then the main geo pass warps into them.  No gradients.
+    C3-sized scene through ibgs_amd.renderer.render() -- the Python surface the reference's render.py calls; the colour network that
+    follows in the reference is outside the rasterizer path and not part of the number."""
+    from ibgs_amd import renderer, simple_scene
+    P, W, H = c["P"], c["W"], c["H"]
+    g = syn.make_gaussians(P, c["seed"], sh_degree=3, max_coeffs=16, opacity="init")
+    rng = np.random.default_rng(0)
+    g["normal"] = rng.normal(size=(P, 3)).astype(np.float32); g["offset"] = (0.01 * rng.normal(size=(P, 1))).astype(np.float32)
+    pc = simple_scene.SimpleGaussians(g, sh_degree=3, device=dev)
+    cams = simple_scene.orbit_cameras(W, H, n_views=8, device=dev, nearest=4)
+    scene = simple_scene.SimpleScene(cams, images=torch.rand(8, 3, H, W, device=dev), device=dev)
+    pipe, args = simple_scene.default_pipe(), simple_scene.default_args()
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        fn = lambda: renderer.render(cams[0], pc, scene, pipe, args, bg, True, 4, 4, render_geo=True, do_render_src_depth=True, return_depth_normal=False)
+        for _ in range(3):
+            fn()
+        fence(1); t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            fn()
+        fence(1)
+        ms = (time.perf_counter() - t0) / n * 1e3
+    return {"ms_per_frame": ms, "fps": 1000.0 / ms,
+            "workload": "%d Gaussians, %dx%d: 4 source depth maps in one batched depth-only pass + the main render_geo pass (n_src 4, L 4), learnt normals, no gradients" % (P, W, H)}
+
+
 def self_launch(a, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (this process has not touched the
     GPU and never will), rank r on GPU r, rendezvous on 127.0.0.1.  Exit code = first failing rank's, 2 if devices are missing."""
@@ -342,6 +450,7 @@ def main():
     ap.add_argument("--forward-only", action="store_true", help="time the forward render alone (BASELINE configs[1]: --config C2 --forward-only)")
     ap.add_argument("--geo", action="store_true", help="make render_geo=True, n_src=4, L=4 the timed workload (second line of SURVEY 8(d))")
     ap.add_argument("--no-geo-line", action="store_true", help="skip the extra (untimed for `value`) geo measurement in the default line")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (view hopping, test-time frame, torch-L1 step, C1 CPU baseline protocol)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -416,6 +525,46 @@ def main():
                 "agree_every": a.agree_every, "agree_host_ms": reducer.last_agree_ms, "agreements": reducer.n_agreements,
                 "grads_copied_into_bucket": reducer.last_packed}
 
+    extras = {}
+    if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
+        from ibgs_amd import rasterizer as _r
+        # (e) the same step with the reference's own L1 expression (six small torch kernels) instead of the one-pass loss: what part of
+        # the step time is the rasterizer's and what the loss's
+        Workload.torch_l1 = True
+        for _ in range(3):
+            wl.local_step()
+        fence(1); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            wl.local_step()
+        fence(1)
+        extras["ms_per_step_with_torch_l1"] = (time.perf_counter() - t0) / a.steps * 1e3
+        Workload.torch_l1 = False
+        # (d) fraction of HBM peak on the bytes THIS design moves (its sort is P-sized; SURVEY's model charges the reference's R-sized one)
+        wl.local_step(); torch.cuda.synchronize()
+        R_, C_, _m = _lib.last_forward_stats()
+        with torch.no_grad():
+            kept = int((wl._call()[1] > 0).sum().item())
+        if C_ > 0:
+            ib = implementation_bytes(wl.P, kept, R_, C_, wl.H * wl.W, int(wl.inp["shs"].shape[1]))
+            extras["implementation_bytes"] = {"bytes_per_step": ib, "coarse_entries": C_, "gaussians_with_tiles": kept,
+                                              "step_frac_impl": ib / (m["ms_step"] * 1e-3) / HBM_PEAK}
+        # (a) a trainer hops between cameras (train.py:275-281): 8 orbit views round-robin.  The first round fills the window of the
+        # R hint (a miss = binning + render run twice); afterwards every call is sized by the largest R of the last 16
+        miss0 = _r.HINT_MISSES
+        for k in range(8):
+            wl.hop_to(k); wl.local_step()
+        fence(1)
+        miss1 = _r.HINT_MISSES
+        n_hop = 24
+        t0 = time.perf_counter()
+        for k in range(n_hop):
+            wl.hop_to(k % 8); wl.local_step()
+        fence(1)
+        extras["view_hopping"] = {"views": 8, "steps": n_hop, "ms_per_step": (time.perf_counter() - t0) / n_hop * 1e3,
+                                  "hint_misses_first_round": miss1 - miss0, "hint_misses_steady": _r.HINT_MISSES - miss1,
+                                  "note": "same Gaussians, 8 orbit cameras round-robin, fwd+bwd; R differs per camera"}
+        wl.hop_to(rank % 8)
+
     geo_line = None
     if world == 1 and not (a.geo or a.forward_only or a.no_geo_line):
         # second line of SURVEY 8(d) under the same clock: C3 + render_geo, n_src 4, L 4 (extra key; never part of `value`)
@@ -429,6 +578,8 @@ def main():
                     "num_rendered": int(gwl.R), "stages_ms": gm["stages"], "roofline": grf}
         del gwl
 
+    if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
+        extras["test_frame"] = test_frame(dev, wl.c)
     if rank == 0:
         tag = "%s%s%s opacity=%s%s" % (a.config, " geo" if a.geo else "", " forward-only" if a.forward_only else "", a.opacity,
                                        (" cluster=%g" % a.cluster) if a.cluster > 0 else "")
@@ -449,8 +600,11 @@ def main():
             out["rccl"] = rccl
         if geo_line is not None:
             out["geo"] = geo_line
+        out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl.inp, a.config)
+            if not a.no_extras:
+                out["cpu_baseline"]["c1_protocol"] = cpu_baseline_c1(dev)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1:

@@ -107,7 +107,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
-           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for",
+           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats",
            "ibgs_required_l1", "ibgs_l1_loss", "ibgs_l1_grad",
            "ibgs_last_error", "ibgs_version"]
 
@@ -174,6 +174,8 @@ def load():
     lib.ibgs_l1_grad.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
     lib.ibgs_required_geo_table.restype = ctypes.c_size_t
     lib.ibgs_required_geo_table.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.ibgs_last_forward_stats.restype = None
+    lib.ibgs_last_forward_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
     lib.ibgs_required_geo_table_for.restype = ctypes.c_size_t
     lib.ibgs_required_geo_table_for.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     lib.ibgs_required_deterministic_for.restype = ctypes.c_size_t
@@ -223,3 +225,10 @@ def timing_collect():
 
 def last_error():
     return load().ibgs_last_error().decode("utf-8", "replace")
+
+
+def last_forward_stats():
+    """(R, coarse binning entries or -1, hint missed?) of this thread's last ibgs_forward."""
+    out = (ctypes.c_int64 * 3)()
+    load().ibgs_last_forward_stats(out)
+    return int(out[0]), int(out[1]), bool(out[2])

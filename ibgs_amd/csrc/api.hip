@@ -216,11 +216,16 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
 }
 #undef OFF
 
-// Pinned host word + event for the R read-back, one per calling thread (created on first use, never freed).
+// Pinned host words + event for the R read-back, one per calling thread AND device (created on first use, never freed): an event
+// belongs to the device that was current when it was created, so a thread that drives several GPUs needs one per device.
 struct RSlot { uint32_t* host; hipEvent_t ev; };
 static RSlot* rslot()
 {
-    static thread_local RSlot slot = {nullptr, nullptr};
+    constexpr int MAX_DEV = 32;
+    static thread_local RSlot slots[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { set_error("hipGetDevice failed / device index out of range"); return nullptr; }
+    RSlot& slot = slots[dev];
     if (!slot.host) {
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
@@ -229,6 +234,11 @@ static RSlot* rslot()
     }
     return &slot;
 }
+
+// what the last ibgs_forward of this thread saw (bench / tests): R, coarse binning entries C (deferred sizing only, else -1), whether the
+// rendered_hint was too small and binning + render ran twice
+static thread_local int64_t g_last_stats[3] = {0, -1, 0};
+void ibgs_last_forward_stats(int64_t* out) { out[0] = g_last_stats[0]; out[1] = g_last_stats[1]; out[2] = g_last_stats[2]; }
 
 int64_t ibgs_forward(const ibgs_forward_args* ap)
 {
@@ -341,12 +351,15 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         return stage_check(s, debug, "render");
     };
     if ((rc = tail(cap, deferred))) return rc;
+    g_last_stats[1] = -1; g_last_stats[2] = 0;
     if (deferred) {
         IBGS_HIP(hipEventSynchronize(rs->ev));
         if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
         R = (int64_t)rs->host[0];
         const bool coarse_overflow = (int64_t)rs->host[2] > cap;      // Gaussians were dropped: the binning's own R is incomplete too
+        g_last_stats[1] = (int64_t)rs->host[2];
         if (R > cap || coarse_overflow) {
+            g_last_stats[2] = 1;
             // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be released by the
             // second callback) and redo binning + render with the exact size (every output element is rewritten).  Same results
             // as without a hint, one wasted pass.
@@ -358,6 +371,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             if ((rc = tail(R, false))) return rc;
         }
     }
+    g_last_stats[0] = R;
     return R;
 }
 

@@ -93,6 +93,7 @@ class capture_sh_factors:
 # RENDERED_HINT = False restores the reference's synchronous sizing.
 RENDERED_HINT = True
 RENDERED_WINDOW = 16
+HINT_MISSES = 0          # forwards whose hint was too small (binning + render ran twice); a trainer hopping between cameras pays these only while the window fills
 _last_rendered = {}           # key -> R of the last call, or a list of recent R values
 LAST_NUM_RENDERED = 0         # diagnostic: R of the most recent forward
 LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent forward carved its binning arena for
@@ -331,7 +332,9 @@ class _CModule:
                 hist = _last_rendered.get(hkey)
                 hist = (hist if isinstance(hist, list) else ([int(hist)] if hist else [])) + [rendered]
                 _last_rendered[hkey] = hist[-RENDERED_WINDOW:]
-                global LAST_BINNING_CAPACITY, LAST_NUM_RENDERED
+                global LAST_BINNING_CAPACITY, LAST_NUM_RENDERED, HINT_MISSES
+                if a.rendered_hint and rendered > int(a.rendered_hint):
+                    HINT_MISSES += 1
                 LAST_NUM_RENDERED = rendered
                 LAST_BINNING_CAPACITY = max(rendered, int(a.rendered_hint)) if a.rendered_hint else rendered
                 binningBuffer = holder.get("t", binningBuffer)

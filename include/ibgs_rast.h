@@ -251,6 +251,9 @@ size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H);
 size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H);
 
 int64_t ibgs_forward(const ibgs_forward_args* args);
+/* diagnostics of the calling thread's last ibgs_forward: out[0] = R, out[1] = coarse binning entries (-1 unless rendered_hint was used),
+ * out[2] = 1 when the hint was too small and binning + render ran a second time with the exact size */
+void ibgs_last_forward_stats(int64_t* out3);
 int32_t ibgs_backward(const ibgs_backward_args* args);
 int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                           const float* projmatrix, uint8_t* present /* P bools */);

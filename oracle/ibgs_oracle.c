@@ -952,8 +952,10 @@ void orc_preprocess_backward(
 #ifdef _OPENMP
 #include <omp.h>
 int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
 int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
 #endif
 
 /* Test hook: SH colour (before +0.5 / clamp) through the same sh_basis() the preprocess uses. */

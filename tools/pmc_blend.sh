@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" "SQ_IFETCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LEVEL_WAVES SQ_WAVES SQ_ACTIVE_INST_MISC SQ_INSTS_LDS SQ_INST_LEVEL_LDS"; do
   n=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/r01b_$n -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01b_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/r01b_$n -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r01b_$n.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcq
-rocprofv3 --kernel-trace --pmc $1 --output-format csv -d gpurun_out/pmcq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $2 > gpurun_out/pmcq.log 2>&1
+rocprofv3 --kernel-trace --pmc $1 --output-format csv -d gpurun_out/pmcq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $2 > gpurun_out/pmcq.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

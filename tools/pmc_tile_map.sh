@@ -9,7 +9,7 @@ for m in $1; do
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     d=gpurun_out/tmpmc_${m}_$(echo $c | cut -d' ' -f1)
     rm -rf $d
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 bench.py --geo --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $d.log
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 bench.py --geo --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $d.log
   done
   python3 - $m >> $out <<'PY'
 import csv, glob, collections, sys

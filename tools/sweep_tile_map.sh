@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 out=gpurun_out/tile_map_sweep.txt
 : > $out
 for m in ${MAPS:-rr g2 g4 g8 g16 g64 b2x2 b4x2 b4x4 b8x4 b8x8 g1024}; do
-  IBGS_TILE_MAP_FWD=$m IBGS_TILE_MAP_BWD=$m IBGS_TILE_MAP_FWD_GEO=$m IBGS_TILE_MAP_BWD_GEO=$m python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/tm_$m.json 2> gpurun_out/tm_$m.err
+  IBGS_TILE_MAP_FWD=$m IBGS_TILE_MAP_BWD=$m IBGS_TILE_MAP_FWD_GEO=$m IBGS_TILE_MAP_BWD_GEO=$m python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > gpurun_out/tm_$m.json 2> gpurun_out/tm_$m.err
   python3 - $m >> $out <<'PY'
 import json, sys
 m = sys.argv[1]
