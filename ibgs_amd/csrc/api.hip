@@ -60,6 +60,7 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.tmask_hi = c.take<uint64_t>(P * (IBGS_CULL_WORDS - 1));
     g.fp_sorted = c.take<uint4>(P);
     g.clamped = c.take<uint8_t>(P);
+    g.alive64 = c.take<uint64_t>((P + 63) / 64);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
     g.offsets = c.take<uint32_t>(P + 4);

@@ -47,6 +47,7 @@ struct GeomState {
     uint64_t* tmask_hi;    // P x (IBGS_CULL_WORDS - 1)  mask bits 64.. (rectangles of 65..IBGS_CULL_MAX_TILES tiles only)
     uint4* fp_sorted;      // P   the footprints in depth order (written by the binning's count pass, read by its place pass)
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
+    uint64_t* alive64;     // ceil(P / 64)  lane mask per wave of the preprocess kernel: Gaussians that reach a tile list (what sh_color_kernel evaluates)
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered
     uint32_t* offsets;     // P+4: exclusive scan of the tiles touched (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back

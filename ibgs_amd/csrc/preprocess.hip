@@ -12,6 +12,7 @@
 // (oracle/ibgs_oracle.c: orc_preprocess) -- the integer outputs (radii, tiles touched) are
 // parity-tested exactly.
 #include "common.h"
+#include <stdlib.h>
 
 namespace ibgs {
 
@@ -34,6 +35,7 @@ struct PreParams {
     int depth_only;
     int32_t* radii;
     float* rec; float* depths; float* cov3D; uint32_t* tiles; uint4* fp; uint64_t* tmask_hi; uint8_t* clamped;
+    uint64_t* alive64;      // split mode only (else nullptr): per wave of 64 Gaussians, who reaches a tile list
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
     uint32_t* zero_a; uint32_t zero_a_n; uint32_t* zero_b; uint32_t zero_b_n;      // words the next stages want zeroed (the depth sort's scratch, its counters)
@@ -67,14 +69,13 @@ __device__ __forceinline__ float ln_portable(float x)
 // values (and the masks) stay bit-identical; one v_med3_f32 instead of two compare + select pairs
 __device__ __forceinline__ float clampf_(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
-// What is needed to test one tile of one Gaussian; a plain struct so that a whole wave can work on the tiles of ONE Gaussian
-// (fields are broadcast with shuffles) as well as a lane on its own.
-struct CullJob { float px, py, A, B, C, qmax, nbc, nba; int x0, y0, w, h; };
-enum { CULL_NONE = 0, CULL_AABB = 1, CULL_LANE = 2, CULL_WAVE = 3 };
+// What the row loop of one Gaussian needs (oracle/ibgs_oracle.c: tile_cull, same operations in the same order).
+struct CullJob { float px, py, A, B, C, det, qmax; int x0, y0, w, h; };
+enum { CULL_NONE = 0, CULL_AABB = 1, CULL_ROWS = 2 };
 
 // Tightens the rectangle to the ellipse's extent and decides how its tiles are tested: CULL_NONE (nothing can pass: no tiles),
-// CULL_AABB (more than IBGS_CULL_MAX_TILES tiles, or a degenerate conic: keep the whole rectangle), CULL_LANE (<= 64 tiles: the
-// owning lane loops over them), CULL_WAVE (65..256 tiles: the wave tests them together, 64 per round, masks straight from ballots).
+// CULL_AABB (more than IBGS_CULL_MAX_TILES tiles, or a degenerate / near-singular conic: keep the whole rectangle), CULL_ROWS (the owning
+// lane walks the tile rows).
 __device__ __forceinline__ int cull_setup(float px, float py, float sxx, float syy, float A, float B, float C, float o,
                                           int& x0, int& y0, int& x1, int& y1, CullJob& j)
 {
@@ -89,28 +90,52 @@ __device__ __forceinline__ int cull_setup(float px, float py, float sxx, float s
     if (tx1 <= tx0 || ty1 <= ty0) { x1 = x0; y1 = y0; return CULL_NONE; }
     x0 = tx0; x1 = tx1; y0 = ty0; y1 = ty1;
     const int w = tx1 - tx0, h = ty1 - ty0;
-    if (w * h > IBGS_CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f)) return CULL_AABB;
-    j.px = px; j.py = py; j.A = A; j.B = B; j.C = C; j.qmax = qmax; j.x0 = tx0; j.y0 = ty0; j.w = w; j.h = h;
-    j.nbc = -B / C; j.nba = -B / A;          /* minimiser of q along an edge x = const / y = const, per unit of x / y */
-    return (w * h > 64) ? CULL_WAVE : CULL_LANE;
+    const float det = A * C - B * B;
+    if (w * h > IBGS_CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return CULL_AABB;
+    j.px = px; j.py = py; j.A = A; j.B = B; j.C = C; j.det = det; j.qmax = qmax; j.x0 = tx0; j.y0 = ty0; j.w = w; j.h = h;
+    return CULL_ROWS;
 }
 
-// Does the pixel-centre box of tile (tx, ty) reach into the ellipse q <= qmax?  (closest point of the quadratic on the box)
-__device__ __forceinline__ bool tile_keep(const CullJob& j, int tx, int ty)
+// bits [start, start + len) of a 256-bit mask (len >= 1)
+__device__ __forceinline__ void set_run(uint64_t (&m)[IBGS_CULL_WORDS], int start, int len)
 {
-    const float A = j.A, B = j.B, C = j.C, nbc = j.nbc, nba = j.nba, qmax = j.qmax;
-    const float X0 = (float)(tx * 16) - j.px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - j.py, Y1 = Y0 + 15.0f;
-    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return true;
-    float qmin, t, q;
-    t = clampf_(nbc * X0, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
-    t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = __builtin_fminf(q, qmin);
-    t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = __builtin_fminf(q, qmin);
-    t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = __builtin_fminf(q, qmin);
-    return !(qmin > qmax);
+#pragma unroll
+    for (int k = 0; k < IBGS_CULL_WORDS; k++) {
+        const int lo = max(start, 64 * k), hi = min(start + len, 64 * k + 64);
+        if (lo < hi) m[k] |= ((hi - lo == 64) ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << (lo - 64 * k);
+    }
+}
+
+// Row by row (see the oracle for the derivation): inside the band of pixel centres of one tile row the ellipse q <= qmax is convex, so
+// the tiles it reaches there are one run of consecutive tiles, bounded by the x-range of the ellipse over the band -- whose ends sit at
+// y* = -B sqrt(qmax / (C det)) (upper) and -y* (lower), clamped into the band.  ~30 operations per row instead of ~50 per tile.
+__device__ __forceinline__ uint32_t cull_rows(const CullJob& j, uint64_t (&m)[IBGS_CULL_WORDS])
+{
+    const float A = j.A, B = j.B, C = j.C, det = j.det, qmax = j.qmax;
+    const float invA = 1.0f / A, aq = A * qmax;
+    const float ymax = sqrtf(aq / det), ystar = -B * sqrtf(qmax / (C * det));
+    uint32_t cnt = 0;
+    for (int r = 0; r < j.h; r++) {
+        const int ty = j.y0 + r;
+        const float Y0 = (float)(ty * 16) - j.py, Y1 = Y0 + 15.0f;
+        const float yb0 = Y0 > -ymax ? Y0 : -ymax, yb1 = Y1 < ymax ? Y1 : ymax;
+        if (yb0 > yb1) continue;
+        const float yu = clampf_(ystar, yb0, yb1), yl = clampf_(-ystar, yb0, yb1);
+        const float eu = aq - det * yu * yu, el = aq - det * yl * yl;
+        const float du = eu > 0.0f ? eu : 0.0f, dl = el > 0.0f ? el : 0.0f;
+        const float xhi = (-B * yu + sqrtf(du)) * invA, xlo = (-B * yl - sqrtf(dl)) * invA;
+        int t0 = (int)ceilf((xlo - 0.01f + j.px - 15.0f) / 16.0f), t1 = (int)floorf((xhi + 0.01f + j.px) / 16.0f);
+        t0 = max(t0, j.x0); t1 = min(t1, j.x0 + j.w - 1);
+        if (t1 >= t0) { set_run(m, r * j.w + (t0 - j.x0), t1 - t0 + 1); cnt += (uint32_t)(t1 - t0 + 1); }
+    }
+    return cnt;
 }
 
 // One thread per Gaussian. The AoS inputs (12..192 B per Gaussian) are read with plain per-lane
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
+// WITH_SH = false: the SH -> RGB evaluation is left to sh_color_kernel below (the launcher's default when SH coefficients are given):
+// without the 48 coefficients and 16 basis values live next to the cull state this kernel needs far fewer registers.
+template <bool WITH_SH>
 __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam)
 {
     __shared__ float4 s_stage_all[4][64 * 5];                 // 64 records at a stride of 5 quads (conflict-free 16-byte LDS accesses)
@@ -118,7 +143,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t z = (uint32_t)gi; z < p.zero_a_n; z += gridDim.x * blockDim.x) p.zero_a[z] = 0u;      // instead of two fill launches
     if ((uint32_t)gi < p.zero_b_n) p.zero_b[gi] = 0u;
-    const bool valid = gi < p.P;          // lanes past the end stay in the wave: the cooperative tile test below needs all 64
+    const bool valid = gi < p.P;          // lanes past the end stay in the wave: the record transpose below is wave-wide
     const int i = valid ? gi : p.P - 1;   // (they recompute the last Gaussian and store nothing)
 
     // defaults: culled Gaussians keep radius 0, zero tiles and sort last
@@ -211,14 +236,10 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
                     cull_mode = cull_setup(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, job);
                     if (cull_mode == CULL_NONE) { ntiles = 0; tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull; }
                     else if (cull_mode == CULL_AABB) ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-                    else if (cull_mode == CULL_LANE) {
-                        uint64_t m = 0; uint32_t cnt = 0;
-                        for (int ty = job.y0; ty < job.y0 + job.h; ty++)
-                            for (int tx = job.x0; tx < job.x0 + job.w; tx++)
-                                if (tile_keep(job, tx, ty)) { m |= 1ull << ((ty - job.y0) * job.w + (tx - job.x0)); cnt++; }
-                        tmask[0] = m; tmask[1] = tmask[2] = tmask[3] = 0ull; ntiles = cnt;
+                    else {          // CULL_ROWS
+                        tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull;
+                        ntiles = cull_rows(job, tmask);
                     }
-                    // CULL_WAVE: counted below, by the whole wave
                 }
                 big_rect = (x1 - x0) * (y1 - y0) > 64;
                 rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
@@ -227,7 +248,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
                 rec[R_CA] = cc * det_inv; rec[R_CB] = -cb * det_inv; rec[R_CC] = ca * det_inv;
                 if (p.colors_precomp) {
                     rec[R_R] = p.colors_precomp[3 * i]; rec[R_G] = p.colors_precomp[3 * i + 1]; rec[R_B] = p.colors_precomp[3 * i + 2];
-                } else if (!p.depth_only) {
+                } else if (WITH_SH && !p.depth_only) {
                     // ---- SH -> RGB ----
                     float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2 = pz3 - cam.campos[2];
                     const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
@@ -304,35 +325,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
         for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     }
 
-    // ---- rectangles of 65..256 tiles: the wave tests the tiles of one such Gaussian at a time, 64 tiles per round; the mask
-    // words are the ballots themselves.  (A lane looping over 256 tiles on its own would hold its 63 neighbours for 256 rounds.)
-    {
-        const int lane = threadIdx.x & 63;
-        uint64_t pending = __ballot(valid && alive && cull_mode == CULL_WAVE);
-        while (pending != 0ull) {
-            const int src = __ffsll((unsigned long long)pending) - 1;
-            pending &= pending - 1ull;
-            CullJob b;
-            b.px = __shfl(job.px, src, WAVE); b.py = __shfl(job.py, src, WAVE); b.A = __shfl(job.A, src, WAVE); b.B = __shfl(job.B, src, WAVE);
-            b.C = __shfl(job.C, src, WAVE); b.qmax = __shfl(job.qmax, src, WAVE); b.nbc = __shfl(job.nbc, src, WAVE); b.nba = __shfl(job.nba, src, WAVE);
-            b.x0 = __shfl(job.x0, src, WAVE); b.y0 = __shfl(job.y0, src, WAVE); b.w = __shfl(job.w, src, WAVE); b.h = __shfl(job.h, src, WAVE);
-            const int area = b.w * b.h;
-            uint64_t words[IBGS_CULL_WORDS]; uint32_t cnt = 0;
-#pragma unroll
-            for (int r = 0; r < IBGS_CULL_WORDS; r++) {
-                const int t = r * 64 + lane;
-                bool keep = false;
-                if (t < area) { const int row = t / b.w; keep = tile_keep(b, b.x0 + (t - row * b.w), b.y0 + row); }
-                words[r] = __ballot(keep);
-                cnt += (uint32_t)__popcll(words[r]);
-            }
-            if (lane == src) {
-#pragma unroll
-                for (int r = 0; r < IBGS_CULL_WORDS; r++) tmask[r] = words[r];
-                ntiles = cnt;
-            }
-        }
-    }
     {   // the 64-byte records leave through LDS: a lane storing its own record spreads every store instruction over 64 lines; transposed, the
         // wave writes its 4 KB as four fully coalesced 1 KB stores
         const int lane = threadIdx.x & 63;
@@ -346,6 +338,10 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
             const int q = it * 64 + lane, row = q >> 2;
             if (row < nrow) out[q] = s_stage[row * 5 + (q & 3)];
         }
+    }
+    if (p.alive64) {          // (a full-wave ballot: lanes past the end are still here)
+        const uint64_t am = __ballot(valid && alive && ntiles > 0);
+        if ((threadIdx.x & 63) == 0) p.alive64[gi >> 6] = am;
     }
     if (!valid) return;
 
@@ -368,6 +364,113 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     // Gaussians without any tile (culled, or fully tile-culled) sort last and emit nothing
     p.sort_key[o] = (alive && ntiles > 0) ? __float_as_uint(depth) : 0xFFFFFFFFu;
     p.sort_val[o] = (uint32_t)o;
+}
+
+// ---- SH -> RGB as its own pass (forward.cu:58-109, 280-286) ------------------------------------------------------------------------
+// One wave per 64 consecutive Gaussians.  Their coefficient rows are one contiguous 12 KB block (M = 16): the wave fetches it with twelve
+// fully coalesced 1 KB loads (float4 per lane, all in flight together) -- skipping the 16-byte pieces of rows whose Gaussian reaches no
+// tile list (culled, off screen: 40 % of C3; the preprocess kernel left a lane mask per wave) -- and transposes it through LDS in two
+// rounds of 32 rows (rows padded to 52 words: conflict-free 16-byte accesses both ways; 6.5 KB per wave, so the register budget and not
+// LDS sets the occupancy): round h parks rows 32h .. 32h + 31, lane 32h + r reads row r back.  Every load instruction covers one
+// contiguous kilobyte, every cache line is fetched once.  In the step it runs at ~3 TB/s of useful bytes -- what a 100-200 MB read gets
+// right after kernels that left the caches full of dirty lines (tests/csrc/probe_read_bw.hip "cold": 2.9 TB/s; 6.2 TB/s when nothing
+// has to drain), whatever its occupancy or load shape (three variants measured).  The evaluation is the oracle's, operation by
+// operation and in its order (this file is compiled without contraction): colours and clamp flags stay bit-identical.  Writes quad 2 of
+// the render record and the clamp bits.
+constexpr int SHC_ROW = 52;          // LDS words per row: 48 coefficients + 4 words of padding
+__global__ void __launch_bounds__(256) sh_color_kernel(PreParams p, Cam cam)
+{
+    __shared__ float s_sh_all[4][32 * SHC_ROW];
+    float* s_sh = s_sh_all[threadIdx.x >> 6];          // private to the wave (LDS operations of one wave execute in order)
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int first = wave * 64;          // this wave's Gaussians: [first, first + 64) cut at P
+    if (first >= p.P) return;
+    const uint64_t alive_m = p.alive64[wave];          // wave-uniform
+    if (alive_m == 0ull) return;
+    const int i = min(first + lane, p.P - 1);
+    const bool alive = (alive_m >> lane) & 1ull;
+    const int D = p.D, M = p.M;
+    const int nb = (D + 1) * (D + 1);
+    const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
+    float shv[48];
+    if (M == 16) {
+        const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)first * 12;
+        const int nq = min(64, p.P - first) * 12;          // float4 pieces of this wave's block
+        float4 v[12];
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int q = it * 64 + lane;
+            const int row = q / 12, piece = q - row * 12;
+            const bool ok = q < nq && ((alive_m >> row) & 1ull) && 4 * piece < 3 * nb;
+            v[it] = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int q = it * 64 + lane;          // piece index within this round's 32 rows
+                const int row = q / 12, piece = q - row * 12;
+                *reinterpret_cast<float4*>(s_sh + row * SHC_ROW + piece * 4) = v[h * 6 + it];
+            }
+            if ((lane >> 5) == h) {
+                const float4* row4 = reinterpret_cast<const float4*>(s_sh + (lane & 31) * SHC_ROW);
+#pragma unroll
+                for (int k = 0; k < 12; k++) { const float4 q = row4[k]; shv[4 * k] = q.x; shv[4 * k + 1] = q.y; shv[4 * k + 2] = q.z; shv[4 * k + 3] = q.w; }
+            }
+        }
+    } else {          // other coefficient counts: plain per-lane loads of the row's first 3 * nb floats
+        const float* sh = p.shs + (size_t)i * M * 3;
+#pragma unroll
+        for (int k = 0; k < 48; k++) shv[k] = (alive && k < 3 * nb) ? sh[k] : 0.f;
+    }
+    if (!alive) return;
+    float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2 = pz3 - cam.campos[2];
+    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    d0 /= len; d1 /= len; d2 /= len;
+    float B[16];
+    B[0] = kC0;
+    if (D > 0) {
+        const float x = d0, y = d1, z = d2;
+        B[1] = -kC1 * y; B[2] = kC1 * z; B[3] = -kC1 * x;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = kC2[0] * xy; B[5] = kC2[1] * yz; B[6] = kC2[2] * (2.0f * zz - xx - yy);
+            B[7] = kC2[3] * xz; B[8] = kC2[4] * (xx - yy);
+            if (D > 2) {
+                B[9] = kC3[0] * y * (3.0f * xx - yy);
+                B[10] = kC3[1] * xy * z;
+                B[11] = kC3[2] * y * (4.0f * zz - xx - yy);
+                B[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                B[13] = kC3[4] * x * (4.0f * zz - xx - yy);
+                B[14] = kC3[5] * z * (xx - yy);
+                B[15] = kC3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+    float col[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) col[ch] = B[0] * shv[ch];
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+        if (k < nb) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) col[ch] = col[ch] + B[k] * shv[3 * k + ch];
+        }
+    }
+    const int o = p.inst0 + i;
+    uint8_t clampbits = 0;
+    float4 out;
+    float* oc = &out.x;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float v = col[ch] + 0.5f;
+        if (v < 0) clampbits |= (uint8_t)(1u << ch);
+        oc[ch] = fmaxf(v, 0.0f);
+    }
+    out.w = 0.f;
+    reinterpret_cast<float4*>(p.rec)[(size_t)o * 4 + 2] = out;
+    p.clamped[o] = clampbits;
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* means3D, Cam cam, uint8_t* present)
@@ -399,7 +502,17 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         p.inst0 = v * a.P; p.tile_row0 = v * gy;
         const Cam cam = make_cam(a.viewmatrix + 16 * v, a.projmatrix + 16 * v, a.campos + 3 * v, a.bg,
                                  nv > 1 ? a.view_tanfovx[v] : a.tanfovx, nv > 1 ? a.view_tanfovy[v] : a.tanfovy, a.W, a.H);
-        hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p, cam);
+        // SH coefficients: geometry first (few registers, every Gaussian), then the colours of the Gaussians that reach a tile
+        // (coalesced row loads); IBGS_PREPROCESS_SPLIT=0 keeps the one-kernel form for comparisons
+        static const bool split_env = !(getenv("IBGS_PREPROCESS_SPLIT") && atoi(getenv("IBGS_PREPROCESS_SPLIT")) == 0);
+        const bool split = split_env && a.shs && !a.colors_precomp && !a.render_depth_only;
+        p.alive64 = split ? g.alive64 : nullptr;
+        if (split) {
+            hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
+            hipLaunchKernelGGL(sh_color_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        } else {
+            hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, s, p, cam);
+        }
     }
     IBGS_HIP(hipGetLastError());
     return 0;

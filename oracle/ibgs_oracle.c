@@ -210,22 +210,26 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
     if (tx1 <= tx0 || ty1 <= ty0) { *x1 = *x0; *y1 = *y0; for (int k = 0; k < CULL_WORDS; k++) mask[k] = 0; return 0; }
     *x0 = tx0; *x1 = tx1; *y0 = ty0; *y1 = ty1;
     const int w = tx1 - tx0, h = ty1 - ty0;
-    if (w * h > CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f)) return (uint32_t)(w * h);
+    const float det = A * C - B * B;
+    if (w * h > CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return (uint32_t)(w * h);
     uint64_t m[CULL_WORDS] = {0, 0, 0, 0}; uint32_t cnt = 0;
-    const float nbc = -B / C, nba = -B / A;      /* minimiser of q along an edge x = const / y = const, per unit of x / y */
-    for (int ty = ty0; ty < ty1; ty++) for (int tx = tx0; tx < tx1; tx++) {
-        const float X0 = (float)(tx * 16) - px, X1 = X0 + 15.0f, Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
-        int keep;
-        if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) keep = 1;
-        else {
-            float qmin, t, q;
-            t = clampf_(nbc * X0, Y0, Y1); qmin = A * X0 * X0 + 2.0f * B * X0 * t + C * t * t;
-            t = clampf_(nbc * X1, Y0, Y1); q = A * X1 * X1 + 2.0f * B * X1 * t + C * t * t; qmin = q < qmin ? q : qmin;
-            t = clampf_(nba * Y0, X0, X1); q = A * t * t + 2.0f * B * t * Y0 + C * Y0 * Y0; qmin = q < qmin ? q : qmin;
-            t = clampf_(nba * Y1, X0, X1); q = A * t * t + 2.0f * B * t * Y1 + C * Y1 * Y1; qmin = q < qmin ? q : qmin;
-            keep = !(qmin > qmax);
-        }
-        if (keep) { const int bit = (ty - ty0) * w + (tx - tx0); m[bit >> 6] |= 1ull << (bit & 63); cnt++; }
+    /* Row by row: the part of the ellipse inside the band of pixel centres y in [Y0, Y1] of one tile row is convex, so the tiles it
+     * reaches in that row are those whose centre box [16 tx, 16 tx + 15] meets its x-range -- one run of consecutive tiles.  For a fixed y
+     * the ellipse spans x = (-B y -+ sqrt(A qmax - det y^2)) / A; the upper end is concave in y with its maximum at
+     * y* = -B sqrt(qmax / (C det)) (the lower end at -y*), so over the band the extremes sit at y* clamped into the band.
+     * ~30 operations per ROW instead of ~50 per tile; the same tiles as a closest-point test per tile, up to the 0.01 px slack below. */
+    const float invA = 1.0f / A, aq = A * qmax;
+    const float ymax = sqrtf(aq / det), ystar = -B * sqrtf(qmax / (C * det));
+    for (int ty = ty0; ty < ty1; ty++) {
+        const float Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
+        const float yb0 = fmaxf_(Y0, -ymax), yb1 = fminf_(Y1, ymax);
+        if (yb0 > yb1) continue;
+        const float yu = clampf_(ystar, yb0, yb1), yl = clampf_(-ystar, yb0, yb1);
+        const float du = fmaxf_(aq - det * yu * yu, 0.0f), dl = fmaxf_(aq - det * yl * yl, 0.0f);
+        const float xhi = (-B * yu + sqrtf(du)) * invA, xlo = (-B * yl - sqrtf(dl)) * invA;
+        int t0 = (int)ceilf((xlo - 0.01f + px - 15.0f) / 16.0f), t1 = (int)floorf((xhi + 0.01f + px) / 16.0f);
+        t0 = imax(t0, tx0); t1 = imin(t1, tx1 - 1);
+        for (int tx = t0; tx <= t1; tx++) { const int bit = (ty - ty0) * w + (tx - tx0); m[bit >> 6] |= 1ull << (bit & 63); cnt++; }
     }
     for (int k = 0; k < CULL_WORDS; k++) mask[k] = m[k];
     return cnt;
