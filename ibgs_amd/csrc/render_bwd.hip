@@ -620,7 +620,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.slot_c = im.slot_c; p.meta = im.meta; p.tab = geo_tab;
     const int nt = p.ntiles;
     // as the forward (render_fwd.hip): blocks of tiles per XCD; geo 8 x 4 (fetch traffic 0.73 -> 0.35 GB, clustered image 1.92 -> 1.83 ms)
-    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_BWD", TileMap{TMAP_BLOCK, 1, 4, 4});
+    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_BWD", TileMap{TMAP_BLOCK, 1, 8, 8});
     static const TileMap map_geo = tile_map_from_env("IBGS_TILE_MAP_BWD_GEO", TileMap{TMAP_BLOCK, 1, 8, 4});
     p.tmap = a.render_geo ? map_geo : map_color;
     auto grid = [&](int ipt) { return dim3((unsigned)tile_map_grid(p.tmap, p.cam.gx, p.cam.gy, ipt)); };

@@ -457,10 +457,10 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.ntiles *= p.n_views;
     const int nt = p.ntiles;
     const int gx = p.cam.gx, gyt = nt / gx;          // (stacked) tile grid
-    // measured (profiles/r03_tile_map.txt): the colour / depth kernels are VALU-bound on every layout; 4 x 4-tile blocks balance a clustered
-    // image best.  The geo kernel's epilogue gathers from the packed source images: 8 x 8-tile blocks cut its L2 <-> fabric traffic
+    // measured (profiles/r03_tile_map.txt): the colour / depth kernels are VALU-bound on every layout and within +-1.5 % of each other;
+    // 8 x 8-tile blocks are the fastest on the uniform scene and equal to round-robin on a clustered one.  The geo kernel's epilogue gathers from the packed source images: 8 x 8-tile blocks cut its L2 <-> fabric traffic
     // from 2.39 GB to 1.37 GB (= the algorithmic bytes) and its time by 3 %
-    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_FWD", TileMap{TMAP_BLOCK, 1, 4, 4});
+    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_FWD", TileMap{TMAP_BLOCK, 1, 8, 8});
     static const TileMap map_geo = tile_map_from_env("IBGS_TILE_MAP_FWD_GEO", TileMap{TMAP_BLOCK, 1, 8, 8});
     p.tmap = a.render_geo ? map_geo : map_color;
     auto grid = [&](int ipt) { return dim3((unsigned)tile_map_grid(p.tmap, gx, gyt, ipt)); };

@@ -37,14 +37,15 @@ def test_results_do_not_depend_on_the_hint(cfg):
         inp = add_sources(scene(P=4000, W=192, H=128, deg=2, seed=26, opacity="trained", planes=True, scale_mul=1.5), n_src=3, L=4)
     base_o, base_l, base = _run(inp, None)
     R = base["R"]
-    assert base["binning_capacity"] // 32 == R // 32          # synchronous sizing: carved for R itself
+    # (the capacity is recovered from the arena's size, whose carve-up is 128-byte aligned: it is known to a few dozen entries)
+    assert abs(base["binning_capacity"] - R) < 64          # synchronous sizing: carved for R itself
     g = torch.randn_like(base_o["color"])
     (base_o["color"] * g).sum().backward()
     for prev in (R, 3 * R, max(R // 10, 1), 1):
         o, l, st = _run(inp, prev)
         hint = prev + prev // 4 + 4096
         assert st["R"] == R and int(o["color"].grad_fn.num_rendered) == R
-        assert st["binning_capacity"] // 32 == max(hint, R) // 32 if hint >= R else st["binning_capacity"] // 32 == R // 32
+        assert abs(st["binning_capacity"] - (max(hint, R) if hint >= R else R)) < 64
         assert np.array_equal(st["point_list"], base["point_list"]) and np.array_equal(st["ranges"], base["ranges"])
         for k in ("color", "median_depth", "normal_map", "warped_image", "cam_feat", "use_first_src_frame_mask"):
             assert torch.equal(o[k], base_o[k]), (k, prev)
