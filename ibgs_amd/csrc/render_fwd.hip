@@ -108,7 +108,12 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     constexpr bool GEO = (MODE == MODE_GEO);
     constexpr bool DEPTH = (MODE == MODE_DEPTH);
     constexpr int NQ = GEO ? 4 : 3;          // record quads staged per Gaussian
-    __shared__ float4 s_rec[NQ][WAVE];
+    // Records per staging round.  Colour / depth-only: 64, one record per lane (3 KB: eight waves per SIMD fit).  Geo: 16, lane l fetches quad
+    // l % 4 of record l / 4 (one coalesced 64-byte line per record, 1 KB of LDS): with the 4 KB of ring-buffer columns below a wave then
+    // holds 5 KB instead of 8, and LDS stops limiting the kernel to five waves per SIMD.  The next round's quad is fetched before the
+    // current round is blended (one float4 per lane in flight), so the shorter rounds do not expose their load latency.
+    constexpr int CHUNK = GEO ? 16 : WAVE;
+    __shared__ float4 s_rec[NQ][CHUNK];
 
     const int lane = threadIdx.x;
     constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
@@ -178,9 +183,27 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
     const int n = (int)(r1 - r0);
 
-    for (int base = 0; base < n; base += WAVE) {
+    // geo: what lane l stages -- quad l % 4 of entry base + l / 4 (fetched one round ahead)
+    auto fetch_quad = [&](int base) -> float4 {
+        const int e = base + (lane >> 2);
+        if (e < n) return p.rec[(size_t)p.point_list[r0 + e] * 4 + (lane & 3)];
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 ahead = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (GEO) ahead = fetch_quad(0);
+    for (int base = 0; base < n; base += CHUNK) {
         uint64_t riskm = 0ull;          // staged records whose conic is near-singular: the reference's power expression decides for them (common.h)
-        {   // stage up to 64 records: lane e loads the quads of entry base+e
+        if constexpr (GEO) {
+            float4 v = ahead;
+            const int qd = lane & 3;
+            const bool risky = qd == 1 && base + (lane >> 2) < n && conic_is_risky(v.x, v.y, v.z);
+            // stage_for_exp2 (common.h), one quad per lane: quad 0 carries the opacity, quad 1 the conic
+            if (qd == 0) v.z = -__builtin_amdgcn_logf(v.z);
+            if (qd == 1) { v.x *= EXP2_SCALE; v.y *= EXP2_SCALE; v.z *= EXP2_SCALE; }
+            s_rec[qd][lane >> 2] = v;
+            if (p.power_skip) riskm = __builtin_amdgcn_ballot_w64(risky);          // record j of the round = bit 4 j + 1 (its quad-1 lane)
+            ahead = fetch_quad(base + CHUNK);
+        } else {   // stage up to 64 records: lane e loads the quads of entry base+e
             const int e = base + lane;
             bool risky = false;
             if (e < n) {
@@ -192,12 +215,11 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 s_rec[0][lane] = c0;
                 s_rec[1][lane] = c1;
                 s_rec[2][lane] = DEPTH ? r[3] : r[2];          // rgb (colour / geo) or the normal (depth-only)
-                if constexpr (GEO) s_rec[3][lane] = r[3];
             }
             if (p.power_skip) riskm = __builtin_amdgcn_ballot_w64(risky);
         }
         __syncthreads();
-        const int count = min(WAVE, n - base);
+        const int count = min(CHUNK, n - base);
         for (int j = 0; j < count; j++) {
             const float4 q0 = s_rec[0][j];      // x, y, opacity
             const float4 q1 = s_rec[1][j];      // conic a, b, c, plane distance
@@ -222,7 +244,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
                 p2q[3] = fmaf(128.0f, q1.y, p2q[2] + (p2q[1] - P0));          // E(d - (8,8)) = E2 + (E1 - E0) + 128 b: three instructions instead of four
             }
-            if ((riskm >> j) & 1ull) {          // wave-uniform and rare: the record as preprocess wrote it, the reference's expression per pixel
+            if ((riskm >> (GEO ? 4 * j + 1 : j)) & 1ull) {          // wave-uniform and rare: the record as preprocess wrote it, the reference's expression per pixel
                 const uint32_t gid = p.point_list[r0 + e];
                 const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
 #pragma unroll
@@ -325,49 +347,54 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             p.out_color[2 * HW + pix] = C[q][2] + T[q] * p.cam.bg[2];
         }
         if (DEPTH) p.out_depth[pix] = wd_sum[q] / (tot_w[q] + eps);
-        if (GEO) {
-            // The epilogue takes DECISIONS on what it computes (is the projected point inside the source image, is the source's depth
-            // within the threshold): no fused multiply-adds here, so that those coordinates are the oracle's bit for bit whenever the
-            // buffered weights are (once per pixel -- the blend loop above is what the kernel's time goes into)
+        if (GEO) { p.out_normal[pix] = Nacc[q][0]; p.out_normal[HW + pix] = Nacc[q][1]; p.out_normal[2 * HW + pix] = Nacc[q][2]; }
+    }
+    // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
+    // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --
+    // the kernel's register count is the blend loop's.
+    if (GEO) {
+        // The epilogue takes DECISIONS on what it computes (is the projected point inside the source image, is the source's depth within the
+        // threshold): no fused multiply-adds here, so that those coordinates are the oracle's bit for bit whenever the buffered weights are
 #pragma clang fp contract(off)
+#pragma unroll 1
+        for (int q = 0; q < PPL; q++) {
+            const int qq = quad0 + q;
+            const int pxq = tx0 + (qq & 1) * 8 + (lane & 7), pyq = ty0 + (qq >> 1) * 8 + (lane >> 3);
+            if (!(pxq < W && pyq < H)) continue;
+            const size_t pix = vbase + (size_t)pyq * W + pxq;
+            const float pxfq = (float)pxq, pyfq = (float)pyq;
+            const float rayxq = (pxfq - cx) / fx, rayyq = (pyfq - cy) / fy;          // as before the blend loop: the same two divisions
             const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
-            const float pdx = pxf[q] - cx, pdy = pyf[q] - cy;
+            const float pdx = pxfq - cx, pdy = pyfq - cy;
+            // (1) the buffered contributors: weight and ray/plane depth per slot, their weighted mean = the median depth.  The depth takes
+            // the contributor number's place in the LDS column (a register-held ring keeps both in registers): step (2) walks the slots
+            // in a rolled loop and the epilogue needs no more registers than the blend loop
+            float dv[RING_LDS ? 1 : MAXL];
             float tw = 0.f, med = 0.f;
-            float tw_src[IBGS_MAX_SRC], wc[IBGS_MAX_SRC][3];
-#pragma unroll
-            for (int si = 0; si < IBGS_MAX_SRC; si++) { tw_src[si] = 0.f; wc[si][0] = wc[si][1] = wc[si][2] = 0.f; }
             uint32_t lo = RING_LDS ? s_bc[q][0][lane] : bc[q][0], hi = lo;     // Q4: slot 0 even when empty
+#pragma unroll 1
             for (int s = 0; s < L; s++) {
-                float w = 0.f, d = 0.f; uint32_t c = 0;
-#pragma unroll
-                for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (!RING_LDS && k == s) { w = bw[q][k]; c = bc[q][k]; }
+                float w = 0.f; uint32_t c = 0;
                 if (RING_LDS) { w = s_bw[q][s][lane]; c = s_bc[q][s][lane]; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (k == s) { w = bw[q][k]; c = bc[q][k]; }
+                }
                 p.slot_c[(size_t)s * HW + pix] = (w == 0.0f) ? 0u : c;      // the backward's window pass starts from these (render_bwd.hip)
-                if (w == 0.0f) continue;
-                {   // depth of buffered contributor c (1-based list position): same expression as the blend loop would use
+                float d = 0.f;
+                if (w != 0.0f) {
+                    // depth of buffered contributor c (1-based list position): same expression as the blend loop would use
                     const uint32_t gid = p.point_list[r0 + c - 1u];
                     const float4 g1 = p.rec[(size_t)gid * 4 + 1], g3 = p.rec[(size_t)gid * 4 + 3];
-                    d = -g1.w / (g3.x * rayx[q] + g3.y * rayy[q] + g3.z + eps);
+                    d = -g1.w / (g3.x * rayxq + g3.y * rayyq + g3.z + eps);
+                    tw += w; med += w * d;
+                    lo = min(lo, c); hi = max(hi, c);
                 }
-                const float X = pdx * d * inv_fx, Y = pdy * d * inv_fy, Z = d;
+                if (RING_LDS) s_bc[q][s][lane] = __float_as_uint(d);
+                else {
 #pragma unroll
-                for (int si = 0; si < IBGS_MAX_SRC; si++) {
-                    if (si < p.n_src) {
-                        const float* r = p.ref_to_src + 16 * si;
-                        const float tx = r[0] * X + r[1] * Y + r[2] * Z + r[3] * 1.0f;
-                        const float ty = r[4] * X + r[5] * Y + r[6] * Z + r[7] * 1.0f;
-                        const float tz = r[8] * X + r[9] * Y + r[10] * Z + r[11] * 1.0f;
-                        const float iz = 1.0f / (tz + eps);
-                        const float u = tx * fx * iz + cx, v = ty * fy * iz + cy;
-                        if (u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1)) {
-                            const float4 col = tex_rgba(p.src_rgba + (size_t)si * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
-                            wc[si][0] += w * col.x; wc[si][1] += w * col.y; wc[si][2] += w * col.z;
-                            tw_src[si] += w;
-                        }
-                    }
+                    for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (k == s) dv[k] = d;
                 }
-                tw += w; med += w * d;
-                lo = min(lo, c); hi = max(hi, c);
             }
             p.low_high[2 * pix] = lo; p.low_high[2 * pix + 1] = hi; p.sum_w[pix] = tw;
             med /= (tw + eps);
@@ -382,39 +409,65 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             rd0 /= rl; rd1 /= rl; rd2 /= rl;
             p.out_camera_ray[pix] = rd0; p.out_camera_ray[HW + pix] = rd1; p.out_camera_ray[2 * HW + pix] = rd2;
 
+            // (2) source by source: is the median point seen by the source at a consistent depth (forward.cu:596-663)?  Only then are
+            // the buffered points warped into it -- the reference warps into every source first and keeps the valid ones; the sums
+            // are formed in the same order, the outputs are identical, and four accumulators are live instead of twenty.
             int nvalid = 0, first_ok = 0; float min_err = 1.0f;
-#pragma unroll
-            for (int si = 0; si < IBGS_MAX_SRC; si++) {
-                if (si < p.n_src && nvalid < IBGS_MAX_SRC) {
-                    const float* r = p.ref_to_src + 16 * si;
-                    const float tx = r[0] * mX + r[1] * mY + r[2] * mZ + r[3] * 1.0f;
-                    const float ty = r[4] * mX + r[5] * mY + r[6] * mZ + r[7] * 1.0f;
-                    const float tz = r[8] * mX + r[9] * mY + r[10] * mZ + r[11] * 1.0f;
-                    const float iz = 1.0f / (tz + eps);
-                    const float u = tx * fx * iz + cx, v = ty * fy * iz + cy;
-                    float wdep = 0.0f;
+#pragma unroll 1
+            for (int si = 0; si < p.n_src; si++) {
+                if (nvalid >= IBGS_MAX_SRC) break;
+                const float* r = p.ref_to_src + 16 * si;
+                const float r0_ = r[0], r1_ = r[1], r2_ = r[2], r3_ = r[3], r4_ = r[4], r5_ = r[5], r6_ = r[6], r7_ = r[7], r8_ = r[8], r9_ = r[9], r10_ = r[10], r11_ = r[11];          // wave-uniform: scalar registers
+                float wdep = 0.0f, err, tzm, izm;
+                {
+                    const float tx = r0_ * mX + r1_ * mY + r2_ * mZ + r3_ * 1.0f;
+                    const float ty = r4_ * mX + r5_ * mY + r6_ * mZ + r7_ * 1.0f;
+                    tzm = r8_ * mX + r9_ * mY + r10_ * mZ + r11_ * 1.0f;
+                    izm = 1.0f / (tzm + eps);
+                    const float u = tx * fx * izm + cx, v = ty * fy * izm + cy;
                     if (u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1))
                         wdep = tex_depth(p.src_depths + (size_t)si * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
-                    const float err = fabsf(wdep - tz) * iz;
-                    if (wdep > 0.0f && err < p.thr) {
-                        const float iw = 1.0f / (tw_src[si] + eps);
-                        const float* sp = p.src_cam_pos + 3 * si;
+                    err = fabsf(wdep - tzm) * izm;
+                }
+                if (!(wdep > 0.0f && err < p.thr)) continue;
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f, tws = 0.f;
+                const float4* img = p.src_rgba + (size_t)si * HW;
+#pragma unroll 1
+                for (int s = 0; s < L; s++) {
+                    float w = 0.f, d = 0.f;
+                    if (RING_LDS) { w = s_bw[q][s][lane]; d = __uint_as_float(s_bc[q][s][lane]); }
+                    else {
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++) {
-                            p.out_cam_feat[((size_t)nvalid * 4 + ch) * HW + pix] = p.cam.campos[ch] - sp[ch];
-                            p.out_warped[((size_t)nvalid * 3 + ch) * HW + pix] = wc[si][ch] * iw;
-                        }
-                        float s0 = wx - sp[0], s1 = wy - sp[1], s2 = wz - sp[2];
-                        const float sl = sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + eps;
-                        s0 /= sl; s1 /= sl; s2 /= sl;
-                        p.out_cam_feat[((size_t)nvalid * 4 + 3) * HW + pix] = s0 * rd0 + s1 * rd1 + s2 * rd2;
-                        if (si == 0) first_ok = 1;
-                        p.valid_idx[(size_t)nvalid * HW + pix] = si;
-                        p.valid_w[(size_t)nvalid * HW + pix] = tw_src[si];
-                        nvalid++;
-                        min_err = fminf(min_err, err);
+                        for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (k == s) { w = bw[q][k]; d = dv[k]; }
+                    }
+                    const float X = pdx * d * inv_fx, Y = pdy * d * inv_fy, Z = d;
+                    const float tx = r0_ * X + r1_ * Y + r2_ * Z + r3_ * 1.0f;
+                    const float ty = r4_ * X + r5_ * Y + r6_ * Z + r7_ * 1.0f;
+                    const float tz = r8_ * X + r9_ * Y + r10_ * Z + r11_ * 1.0f;
+                    const float iz = 1.0f / (tz + eps);
+                    const float u = tx * fx * iz + cx, v = ty * fy * iz + cy;
+                    if (w != 0.0f && u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1)) {
+                        const float4 col = tex_rgba(img, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
+                        c0 += w * col.x; c1 += w * col.y; c2 += w * col.z; tws += w;
                     }
                 }
+                const float iw = 1.0f / (tws + eps);
+                const float* sp = p.src_cam_pos + 3 * si;
+                p.out_cam_feat[((size_t)nvalid * 4 + 0) * HW + pix] = p.cam.campos[0] - sp[0];
+                p.out_cam_feat[((size_t)nvalid * 4 + 1) * HW + pix] = p.cam.campos[1] - sp[1];
+                p.out_cam_feat[((size_t)nvalid * 4 + 2) * HW + pix] = p.cam.campos[2] - sp[2];
+                p.out_warped[((size_t)nvalid * 3 + 0) * HW + pix] = c0 * iw;
+                p.out_warped[((size_t)nvalid * 3 + 1) * HW + pix] = c1 * iw;
+                p.out_warped[((size_t)nvalid * 3 + 2) * HW + pix] = c2 * iw;
+                float s0 = wx - sp[0], s1 = wy - sp[1], s2 = wz - sp[2];
+                const float sl = sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + eps;
+                s0 /= sl; s1 /= sl; s2 /= sl;
+                p.out_cam_feat[((size_t)nvalid * 4 + 3) * HW + pix] = s0 * rd0 + s1 * rd1 + s2 * rd2;
+                if (si == 0) first_ok = 1;
+                p.valid_idx[(size_t)nvalid * HW + pix] = si;
+                p.valid_w[(size_t)nvalid * HW + pix] = tws;
+                nvalid++;
+                min_err = fminf(min_err, err);
             }
             if (nvalid <= IBGS_MAX_SRC - 1) p.valid_idx[(size_t)nvalid * HW + pix] = -1;
             // unused source slots and the mask are written too, so the caller needs no 36-plane memset per frame
@@ -428,7 +481,6 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             p.out_mask[pix] = first_ok;
             p.out_min_depth_diff[pix] = min_err;
             p.out_depth[pix] = med;
-            p.out_normal[pix] = Nacc[q][0]; p.out_normal[HW + pix] = Nacc[q][1]; p.out_normal[2 * HW + pix] = Nacc[q][2];
         }
     }
 }
