@@ -57,6 +57,7 @@ __device__ __forceinline__ float quant8b(float a, int quant) { return quant ? fl
 
 __device__ __forceinline__ float4 tex_rgba_b(const float4* __restrict__ img, int W, int H, float x, float y, int quant)
 {
+#pragma clang fp contract(off)          // operation by operation like the oracle's tex_rgb (the pass that calls it is bound by its gathers)
     const float xb = x - 0.5f, yb = y - 0.5f;
     const float fxi = floorf(xb), fyi = floorf(yb);
     const float a = quant8b(xb - fxi, quant), b = quant8b(yb - fyi, quant);
@@ -370,14 +371,37 @@ __global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
                 const float den = (Wc * dep + r[11]);
                 const float dpx = fx * (U * r[11] - Wc * r[3]) / (den * den);
                 const float dpy = fy * (V * r[11] - Wc * r[7]) / (den * den);
-                // four linear-filtered fetches at integer coordinates
+                // four linear-filtered fetches at integer coordinates (u0, v0), (u0 + 1, v0), (u0, v0 + 1), (u0 + 1, v0 + 1).  With
+                // texel centres at i + 0.5 each of them averages the 2 x 2 texels around its corner (weights 1/4 each), and the four
+                // corners share the 3 x 3 block of texels u0 - 1 .. u0 + 1, v0 - 1 .. v0 + 1 (clamped): NINE loads instead of sixteen, the
+                // same operations in the same order per fetch (no fused multiply-adds, like tex_rgba_b and the oracle's tex_rgb).  This pass
+                // runs at the L1 bandwidth of the chip (16-byte gathers: 20 per (buffered contributor, source) before, 13 now).
                 const float uu = u + 0.5f, vv2 = vv_ + 0.5f;
                 const int u0 = (int)floorf(uu), v0 = (int)floorf(vv2);
                 const float fu = uu - (float)u0, fv = vv2 - (float)v0, fu1 = 1.0f - fu, fv1 = 1.0f - fv;
-                const float4 I00 = tex_rgba_b(img, W, H, (float)u0, (float)v0, p.tex_quant);
-                const float4 I01 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)v0, p.tex_quant);
-                const float4 I10 = tex_rgba_b(img, W, H, (float)u0, (float)(v0 + 1), p.tex_quant);
-                const float4 I11 = tex_rgba_b(img, W, H, (float)(u0 + 1), (float)(v0 + 1), p.tex_quant);
+                float4 I00, I01, I10, I11;
+                {
+                    const int xi0 = min(W - 1, max(0, u0 - 1)), xi1 = min(W - 1, max(0, u0)), xi2 = min(W - 1, max(0, u0 + 1));
+                    const int yj0 = min(H - 1, max(0, v0 - 1)), yj1 = min(H - 1, max(0, v0)), yj2 = min(H - 1, max(0, v0 + 1));
+                    const float4 t00 = img[(size_t)yj0 * W + xi0], t10 = img[(size_t)yj0 * W + xi1], t20 = img[(size_t)yj0 * W + xi2];
+                    const float4 t01 = img[(size_t)yj1 * W + xi0], t11 = img[(size_t)yj1 * W + xi1], t21 = img[(size_t)yj1 * W + xi2];
+                    const float4 t02 = img[(size_t)yj2 * W + xi0], t12 = img[(size_t)yj2 * W + xi1], t22 = img[(size_t)yj2 * W + xi2];
+                    // tex_rgba_b at an integer coordinate: a = b = 0.5 exactly (also after the 8-bit weight rounding), all four weights 0.25
+                    const float a = quant8b(0.5f, p.tex_quant), b = quant8b(0.5f, p.tex_quant);
+                    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+                    auto quad = [&](const float4& q00, const float4& q10, const float4& q01, const float4& q11) {
+                        float4 r;
+                        r.x = w00 * q00.x + w10 * q10.x + w01 * q01.x + w11 * q11.x;
+                        r.y = w00 * q00.y + w10 * q10.y + w01 * q01.y + w11 * q11.y;
+                        r.z = w00 * q00.z + w10 * q10.z + w01 * q01.z + w11 * q11.z;
+                        r.w = 1.0f;
+                        return r;
+                    };
+                    I00 = quad(t00, t10, t01, t11);          // corner (u0, v0): texels u0 - 1 .. u0, v0 - 1 .. v0
+                    I01 = quad(t10, t20, t11, t21);          // corner (u0 + 1, v0)
+                    I10 = quad(t01, t11, t02, t12);          // corner (u0, v0 + 1)
+                    I11 = quad(t11, t21, t12, t22);          // corner (u0 + 1, v0 + 1)
+                }
                 const float dIu0 = -fv1 * I00.x + fv1 * I01.x - fv * I10.x + fv * I11.x;
                 const float dIu1 = -fv1 * I00.y + fv1 * I01.y - fv * I10.y + fv * I11.y;
                 const float dIu2 = -fv1 * I00.z + fv1 * I01.z - fv * I10.z + fv * I11.z;
