@@ -95,8 +95,8 @@ struct BinState {
 // that offset (an fma instead of a mul), so what the inner loop holds per pixel is E = -log2(alpha before the 0.99 clamp):
 //   alpha      = min(0.99, exp2(-E))             (exp2 with a free source negation: no multiply by o, none by log2 e)
 //   skip test  : alpha >= 1/255  <=>  E <= log2(255), ONE compare against a constant (forward.cu:420-425 tests power > 0 and
-//                alpha < 1/255; power <= 0 holds for every positive definite conic up to rounding noise, and where that noise makes the
-//                reference's own formula positive it skips a pixel at the very centre line of a needle-shaped Gaussian -- not reproduced)
+//                alpha < 1/255; power <= 0 holds for every positive definite conic up to rounding noise; the Gaussians for which that
+//                noise can make the reference's own formula positive take the branch described at conic_is_risky below)
 // Two multiplies less per (pixel, Gaussian) pair in both passes, which take the same decisions because they stage the same numbers.
 // The record keeps the unscaled conic and the opacity (bit-identical to the oracle's; preprocess_bwd reads them).
 constexpr float EXP2_SCALE = 0.5f * 1.4426950408889634f;
