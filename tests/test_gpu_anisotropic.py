@@ -92,7 +92,7 @@ def test_geo_path_on_plane_like_gaussians():
     assert (ref["valid_src_idx"][0] >= 0).mean() > 0.2, "scene does not exercise the warp path"
     assert np.array_equal(ist["low_high"][:, 0], ref["cache_low"]) and np.array_equal(ist["low_high"][:, 1], ref["cache_high"])
     same = np.all(canon_valid(ist["valid_idx"]) == canon_valid(ref["valid_src_idx"]), axis=0)
-    assert same.mean() > 0.999
+    assert (~same).sum() <= 2
     assert l1(o["normal_map"], ref["normal_map"]) < 1e-6
     ok = same.reshape(H, W)
     for k, tol in (("median_depth", 1e-4), ("cam_feat", 1e-5), ("warped_image", 1e-5), ("min_depth_diff", 1e-5), ("camera_ray", 1e-5)):

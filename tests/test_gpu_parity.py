@@ -50,6 +50,9 @@ def check_stages(ist, o, ref):
 
 
 def check_color(o, ist, ref, frac_contrib=2e-4):
+    """The north star's image bar is on the MEAN (1e-4 L1 per pixel; asserted a hundred times tighter).  A single pixel may differ by up to
+    alpha_min * T = 0.004 when a Gaussian sits at alpha = 1/255 to the last bit and the two exp implementations fall on different sides of the
+    reference's skip test -- hence the separate, looser bound on the maximum."""
     assert l1(o["color"], ref["color"]) <= L1_TOL * 1e-2
     assert float(np.abs(o["color"] - ref["color"]).max()) < 5e-3
     bad = (ist["n_contrib"] != ref["n_contrib"]).mean()
@@ -291,7 +294,10 @@ def test_geo_path_forward_backward(L, n_src):
     assert (ref["valid_src_idx"][0] >= 0).mean() > 0.2, "scene does not exercise the warp path"
     assert np.array_equal(ist["low_high"][:, 0], ref["cache_low"]) and np.array_equal(ist["low_high"][:, 1], ref["cache_high"])
     same = np.all(canon_valid(ist["valid_idx"]) == canon_valid(ref["valid_src_idx"]), axis=0)
-    assert same.mean() > 0.999                       # validity is a threshold test on an interpolated depth
+    print("\n[geo L=%d n_src=%d] valid-source sets equal on %.4f %% of the pixels (%d differ)" % (L, n_src, 100 * same.mean(), int((~same).sum())))
+    # validity is a threshold test on an interpolated depth; since the geo path takes its decisions on uncontracted arithmetic (DESIGN.md
+    # section 3) the sets agree on every pixel of these scenes (round 2: 99.9 %, the rest masked out of the comparisons below)
+    assert (~same).sum() <= 2
     assert l1(o["normal_map"], ref["normal_map"]) < 1e-6
     assert l1(ist["sum_w"], ref["cache_sum_w"]) < 1e-6
     ok = same.reshape(H, W)
