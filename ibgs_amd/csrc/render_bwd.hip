@@ -448,6 +448,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
     const size_t HW = (size_t)W * H;
 
     float T[PPL], S[PPL];
+    const bool bg0 = p.cam.bg[0] == 0.f && p.cam.bg[1] == 0.f && p.cam.bg[2] == 0.f;      // wave-uniform (scalar loads), as in the colour body
     uint32_t ncontrib[PPL], next_c[PPL], slot[PPL], pixo[PPL];
     uint32_t nmax = 0;
     const float pxf0 = (float)(tx0 + (quad0 & 1) * 8 + (lane & 7)), pyf0 = (float)(ty0 + (quad0 >> 1) * 8 + (lane >> 3));
@@ -503,8 +504,9 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
             stable = stable && (ncm[q] == __builtin_amdgcn_ballot_w64((uint32_t)(top - 1) < ncontrib[q]));
         }
         __syncthreads();
-        auto chunk = [&](auto stable_tag) {
+        auto chunk = [&](auto stable_tag, auto bg0_tag) {
             constexpr bool STABLE = decltype(stable_tag)::value;
+            constexpr bool BG0 = decltype(bg0_tag)::value;          // black background: the -T_final (bg . g) / (1 - alpha) term is zero
             for (int j = 0; j < count; j++) {
                 const uint32_t k = (uint32_t)(top - 1 - j);
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j];
@@ -566,7 +568,8 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                                 next_c[q] = (slot[q] < (uint32_t)IBGS_MAX_BUFFER_LENGTH) ? __float_as_uint(e[(size_t)GEO_TAB_FIELDS * HW]) : 0u;
                             }
                         }
-                        dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);
+                        if constexpr (BG0) dL_dalpha = dL_dalpha * T[q];
+                        else dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);
                         const float qv = oG * dL_dalpha;
                         Q[q] = qv;
                         aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);      // |a b| = |a| |b|: one v_fma with source modifiers
@@ -605,7 +608,8 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                 }
             }
         };
-        if (stable) chunk(std::true_type{}); else chunk(std::false_type{});
+        if (bg0) { if (stable) chunk(std::true_type{}, std::true_type{}); else chunk(std::false_type{}, std::true_type{}); }
+        else { if (stable) chunk(std::true_type{}, std::false_type{}); else chunk(std::false_type{}, std::false_type{}); }
         __syncthreads();
         top -= count;
     }
