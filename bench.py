@@ -223,14 +223,18 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     """W untimed warm-ups, then EXACTLY K steps between barrier + synchronize on both sides (wall clock, max over ranks);
     every timed step is also bracketed by hipEvents on the op's stream (= torch's current stream) for the median."""
     kstage = "render_fwd" if wl.forward_only else "render_bwd"
-    for _ in range(warmup):
-        step()
     # The interpreter's cyclic garbage collector is kept out of the timed steps: with torch imported a full collection walks ~170 k
     # objects = 33-42 ms, i.e. up to twenty C3 steps, whenever its allocation counters happen to trip (measured: 2 of 5 runs of the
     # 20-step geo line had one such step).  Everything alive now moves to the permanent generation (gc.freeze) and later collections
     # only see what the steps themselves allocate.  A training loop should do the same once after set-up (INTEGRATION.md).
+    # The collection runs BEFORE the warm-up steps: it idles the GPU for those 40 ms, and the first ten steps after an idle gap run up
+    # to 30 % slower while the clocks come back (per_step_ms_hipevent showed 2.31, 1.97, 1.94, 1.91 ... 1.79 at the start of the timed
+    # region when the collection sat between warm-up and timing) -- that is what warm-up steps are for.
     gc.collect()
     gc.freeze()
+    for _ in range(warmup):
+        step()
+    gc.freeze()          # what the warm-up steps left behind (caches, scratch): no collection, just out of the collector's sight
     _lib.timing_enable([kstage])     # hipEvents around the dominant kernel only, on the op's stream
     _lib.timing_collect()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -264,6 +268,7 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     stages = {k: v[0] / float(n_stage_steps) for k, v in _lib.timing_collect().items()}
     _lib.timing_enable([])
     return {"dt": dt, "ms_step": dt / steps * 1e3, "median_ms": statistics.median(per_step), "min_ms": min(per_step), "max_ms": max(per_step),
+            "per_step": [round(x, 3) for x in per_step],
             "kernel_ms": tm[kstage][0] / max(tm[kstage][1], 1), "fwd_ms": fwd_ms, "stages": stages}
 
 
@@ -592,6 +597,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe(a.opacity, world, a.exchange), "num_rendered": int(wl.R), "parallelism": "view-parallel x%d" % world},
             "median_ms_hipevent": m["median_ms"], "min_ms_hipevent": m["min_ms"], "max_ms_hipevent": m["max_ms"],
+            "per_step_ms_hipevent": m["per_step"],          # every timed step: where the wall clock differs from the median, it is these outliers
             "forward_only_ms": m["fwd_ms"],
             "roofline": rf,
             "stages_ms": m["stages"],
