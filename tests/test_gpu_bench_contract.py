@@ -68,6 +68,25 @@ def test_bench_self_launches_its_ranks():
     assert x["grads_copied_into_bucket"] == 0 and x["agreements"] >= d["steps"] and x["agree_host_ms"] >= 0
 
 
+@pytest.mark.gpu
+def test_bench_eight_view_step_on_one_gpu():
+    """BASELINE config C4's step shape -- 8 views per step, one per rank, gradients exchanged -- with the 8 ranks sharing this box's one GPU
+    over gloo (small C1-sized scene): the factored exchange gathers 8 views' factors, every rank ends the step, one line with n_gpus = 8.
+    (An 8-GPU RCCL run is the driver's; this checks the code path it will take.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(IBGS_BENCH_SHARE_GPU="1", IBGS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--config", "C1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "view-parallel x8" and d["scaling"] == "weak"
+    x = d["rccl"]
+    assert x["world"] == 8 and x["exchange"] == "factored" and x["grads_copied_into_bucket"] == 0
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
 def test_bench_refuses_missing_gpus_without_touching_them():
     """CPU container: zero devices -> `--gpus 2` exits with code 2 before any rank is started."""
     import torch
