@@ -259,6 +259,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         set_error("provide exactly one of scales+rotations / cov3D_precomp"); return -IBGS_ERR_INVALID;
     }
     if (a.shs && (a.D < 0 || a.D > 3 || (a.D + 1) * (a.D + 1) > a.M)) { set_error("bad SH degree D=%d M=%d", a.D, a.M); return -IBGS_ERR_INVALID; }
+    // rows of 16 coefficients are fetched with 16-byte loads (preprocess.hip, preprocess_bwd.hip): the base must be 16-byte aligned (any torch
+    // allocation is; a view that starts in the middle of one may not be)
+    if (a.shs && a.M == 16 && (reinterpret_cast<uintptr_t>(a.shs) & 15u)) { set_error("shs (M = 16) must be 16-byte aligned"); return -IBGS_ERR_INVALID; }
     if (a.render_geo && a.render_depth_only) { set_error("render_geo together with render_depth_only is not supported"); return -IBGS_ERR_INVALID; }
     if (a.plane_mode != IBGS_PLANE_NONE) {
         if (a.all_map) { set_error("give either all_map or plane_mode, not both"); return -IBGS_ERR_INVALID; }
@@ -389,6 +392,9 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         set_error("missing gradient output"); return -IBGS_ERR_INVALID;
     }
     if (a.shs && !a.dL_dsh && !(a.flags & IBGS_FLAG_SH_FACTORED)) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
+    if (a.shs && a.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) & 15u) || (a.dL_dsh && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u)))) {
+        set_error("shs / dL_dsh (M = 16) must be 16-byte aligned"); return -IBGS_ERR_INVALID;
+    }
     if (!a.dL_dcolors && (!a.shs || (a.flags & IBGS_FLAG_SH_FACTORED))) { set_error("dL_dcolors required (precomputed colours, or IBGS_FLAG_SH_FACTORED)"); return -IBGS_ERR_INVALID; }
     if (!a.dL_dcov3D && a.cov3D_precomp) { set_error("dL_dcov3D required with cov3D_precomp"); return -IBGS_ERR_INVALID; }
     if (a.scales && (!a.dL_dscale || !a.dL_drot)) { set_error("dL_dscale / dL_drot required"); return -IBGS_ERR_INVALID; }

@@ -115,7 +115,10 @@ def _dev_f32(t, device):
         t = t.to(device)
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() & 15:          # a view that starts in the middle of an allocation: the kernels fetch rows with 16-byte loads
+        t = t.clone()
+    return t
 
 
 def _ptr(t):

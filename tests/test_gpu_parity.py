@@ -399,3 +399,27 @@ def test_frame_with_more_cells_than_one_placement_slice(wave_shape):
     used = np.flatnonzero(rg[:, 1] > rg[:, 0])
     assert used.size > 2000 and (used // (((W + 15) // 16))).max() > 100           # tiles in use down to the last rows: cells of both slices
     check_stages(ist, o, ref); check_color(o, ist, ref)
+
+
+def test_inputs_that_are_views_into_the_middle_of_an_allocation():
+    """SH rows are fetched with 16-byte loads: a tensor that starts 4 bytes into an allocation must still work through the Python surface
+    (it is copied to an aligned buffer), and the C ABI refuses the raw pointer instead of faulting."""
+    import ctypes
+    from ibgs_amd import _lib
+    inp = scene(P=1000, W=96, H=64, deg=3, seed=12, opacity="trained")
+    ref = oracle.forward(inp, cull=True)
+    st = hipref.settings_from(inp, "cuda")
+    lv = hipref.leaf_inputs(inp, "cuda", requires_grad=False)
+    big = torch.empty(lv["shs"].numel() + 1, device="cuda")
+    shifted = big[1:].view_as(lv["shs"]); shifted.copy_(lv["shs"])
+    assert shifted.data_ptr() % 16 == 4
+    out = rasterizer.GaussianRasterizer(st)(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
+                                            shs=shifted, scales=lv["scales"], rotations=lv["rotations"])
+    assert l1(out[0].cpu().numpy(), ref["color"]) < 1e-6
+    a = _lib.ForwardArgs()
+    a.P, a.D, a.M, a.W, a.H = 1000, 3, 16, 96, 64
+    dummy = torch.zeros(64, device="cuda")
+    for k in ("means3D", "opacities", "viewmatrix", "projmatrix", "campos", "bg", "scales", "rotations"):
+        setattr(a, k, dummy.data_ptr())
+    a.radii = dummy.data_ptr(); a.shs = shifted.data_ptr()
+    assert _lib.load().ibgs_forward(ctypes.byref(a)) < 0 and "16-byte aligned" in _lib.last_error()
