@@ -174,13 +174,6 @@ class ViewParallelReducer:
         params, sh_parts = _resolve(self._params), self.sh_parts
         return [p for p in params if not any(p is q for q in sh_parts)]
 
-    def _views(self, tensors):
-        """Fresh view objects of the flat bucket, one per tensor (None when the bucket does not match `tensors`)."""
-        b = self.bucket
-        if b is None or b.numels != [t.numel() for t in tensors] or b.flat.device != tensors[0].device:
-            return None
-        return b.unpack()
-
     def attach_grads(self):
         """Instead of zero_grad(): every dense parameter's `.grad` becomes a zeroed view of the flat bucket (ONE memset), so autograd
         accumulates this step's gradients in place and reduce() has nothing to copy.  Returns the number of bytes attached."""
