@@ -36,6 +36,7 @@ TILE_CULL = True
 # to singular for it to fire (csrc/common.h); False = IBGS_FLAG_NO_REF_POWER_SKIP, every Gaussian takes the fast path.
 REF_POWER_SKIP = True
 
+KEEP_DET_SCRATCH = False          # diagnostics: keep the last deterministic backward's scratch alive as _CModule.last_det
 # Deterministic backward (IBGS_FLAG_DETERMINISTIC): no float atomics, gradients bit-identical from run to run (CI mode, slower).
 DETERMINISTIC = False
 
@@ -452,6 +453,8 @@ class _CModule:
                            | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag() | tex_flag)
                 if DETERMINISTIC and int(R) > 0:
                     det = torch.empty(lib.ibgs_required_deterministic_for(int(R), P, W, H, int(render_geo), int(a.flags)), dtype=torch.uint8, device=device)
+                    if KEEP_DET_SCRATCH:
+                        _CModule.last_det = det          # tools/pairing_stats.py reads the slab: which (list entry, wave) rows the backward wrote
                     a.det_scratch = det.data_ptr(); a.det_scratch_bytes = det.numel()
                     a.flags |= _lib.FLAG_DETERMINISTIC
                 rc = lib.ibgs_backward(ctypes.byref(a))
