@@ -454,6 +454,7 @@ def main():
                     help="N > 1 ranks: run the reducer's host-side agreement every K-th step only (and whenever sizes change); 1 = every step")
     ap.add_argument("--forward-only", action="store_true", help="time the forward render alone (BASELINE configs[1]: --config C2 --forward-only)")
     ap.add_argument("--geo", action="store_true", help="make render_geo=True, n_src=4, L=4 the timed workload (second line of SURVEY 8(d))")
+    ap.add_argument("--wave-shape", default=None, choices=["tile", "quadrant"], help="force the blend kernels' work decomposition (experiments)")
     ap.add_argument("--no-geo-line", action="store_true", help="skip the extra (untimed for `value`) geo measurement in the default line")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (view hopping, test-time frame, torch-L1 step, C1 CPU baseline protocol)")
     a = ap.parse_args()
@@ -482,6 +483,9 @@ def main():
     _lib.load()
 
     Workload.CLUSTER = a.cluster
+    if a.wave_shape:
+        from ibgs_amd import rasterizer as _rz
+        _rz.WAVE_SHAPE = a.wave_shape
     wl = Workload(a.config, rank % 8, dev, a.opacity, a.geo, a.forward_only, 1234 + rank)
     reducer = None
     if world > 1:

@@ -31,6 +31,7 @@
 // same fast exp2 as the forward (the reference uses __expf forward / exp backward); 1/(1-alpha) is the hardware
 // reciprocal (1 ulp) instead of an IEEE division.
 #include "common.h"
+#include <stdlib.h>
 #include "wave_reduce.h"
 #include <type_traits>
 
@@ -667,7 +668,8 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             IBGS_HIP(hipGetLastError());
             return 0;
         }
-        hipLaunchKernelGGL(render_bwd_color_kernel, grid(1), dim3(64), 0, s, p);
+        static const int pad_lds = getenv("IBGS_BWD_PAD_LDS") ? atoi(getenv("IBGS_BWD_PAD_LDS")) : 0;      // experiments: dynamic LDS that nobody uses = fewer waves per SIMD
+        hipLaunchKernelGGL(render_bwd_color_kernel, grid(1), dim3(64), pad_lds, s, p);
     }
     IBGS_HIP(hipGetLastError());
     return 0;

@@ -163,6 +163,9 @@ CONFIGS = {
     "C1": dict(P=10_000, W=400, H=400, sh_degree=3, seed=1),
     "C2": dict(P=100_000, W=800, H=800, sh_degree=0, seed=2),
     "C3": dict(P=1_000_000, W=1920, H=1080, sh_degree=3, seed=3),
+    # not a BASELINE config: C3's Gaussians on a 720p frame (3 600 tiles: one resident round of the blend kernels even at 4 waves per SIMD);
+    # used by occupancy experiments (bench.py --config C3_720p --wave-shape tile)
+    "C3_720p": dict(P=1_000_000, W=1280, H=720, sh_degree=3, seed=3),
 }
 
 
