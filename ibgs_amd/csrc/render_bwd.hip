@@ -51,7 +51,6 @@ struct BwdParams {
     const float* dL_dcolor; const float* dL_dnormal; const float* dL_ddepth; const float* dL_dwarped;
     float* gacc;
     const uint32_t* slot_c; const uint32_t* meta; float* tab;     // geo: the forward's buffered contributor numbers (+ slot count); the window pass's table
-    const float* depths;  // per-Gaussian view depth (the lists' sort key): the pair kernel merges two tile lists on it
     float* slab;          // IBGS_FLAG_DETERMINISTIC: (R x waves per tile) x 16, one row per (list entry, wave of its tile), written instead of the atomics (else nullptr)
 };
 
@@ -617,224 +616,10 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
     }
 }
 
-
-// ---- colour variant for PAIRS of tiles ---------------------------------------------------------------------------------------------
-// One wave owns two horizontally adjacent 16 x 16 tiles (8 pixels per lane) and walks BOTH tile lists back to front, merged in depth
-// order inside the wave.  79 % of the (Gaussian, tile) entries the backward processes have their Gaussian processed in the horizontal
-// neighbour as well (tools/pairing_stats.py): for those the 12-value transpose-reduce and the atomic -- 160 of ~600 cycles per entry --
-// are paid once for two tiles.  Nothing upstream changes: the lists, the tile ranges and every per-pixel counter stay per 16 x 16 tile.
-//   * per round up to 16 entries of each list are staged (lanes 0..15: tile A, lanes 16..31: tile B) with their sort key
-//     (view depth bits, Gaussian id: the lists are ordered by exactly that, ties by id);
-//   * the 32 staging lanes rank their entry among the other tile's staged entries (<= 16 broadcast compares): rank = position in the
-//     merged back-to-front order; an entry of A and its twin in B (same Gaussian) land next to each other and share a slot;
-//   * only the merged prefix that cannot be overtaken by entries not staged yet is processed: up to the last staged entry of a list
-//     that still has entries further down; the lists' cursors advance by what was consumed;
-//   * a slot runs the colour body once per tile it belongs to (the same arithmetic, the same decisions as render_bwd_color_body), adds
-//     the two tiles' moments (they are sums over pixels of absolute quantities) and reduces / adds ONCE.
-// 9.8 KB of LDS and ~100 VGPRs per wave = four waves per SIMD, which this kernel does not notice, and 4 080
-// work items at 1080p: still one resident round.
-__device__ __forceinline__ void render_bwd_color_pair_body(const BwdParams& p)
-{
-    constexpr int CH = 16;
-    __shared__ float4 s_rec[2][3][CH];
-    __shared__ uint2 s_key[2][CH];
-    __shared__ uint32_t s_sched[2 * CH];
-    __shared__ float4 s_gpix[8][WAVE];
-
-    const int lane = threadIdx.x;
-    int col = reduce12_column(lane);
-    if (col >= 11) col = -1;
-    const int gx = p.cam.gx, gxp = (gx + 1) >> 1;
-    int ptile, sub;
-    if (!tile_map_item(p.tmap, blockIdx.x, gxp, p.cam.gy, 1, ptile, sub)) return;
-    const int tyi = ptile / gxp, txa = (ptile - tyi * gxp) * 2;
-    const bool hasB = txa + 1 < gx;
-    const int tileA = tyi * gx + txa, tileB = tileA + 1;
-    const int W = p.cam.W, H = p.cam.H;
-    const int tx0 = txa * TILE, ty0 = tyi * TILE;
-    const size_t HW = (size_t)W * H;
-
-    float T[8], S[8];
-    uint32_t ncontrib[8];
-    uint32_t nmaxA = 0, nmaxB = 0;
-    const float pxf0A = (float)(tx0 + (lane & 7)), pyf0 = (float)(ty0 + (lane >> 3));
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int px = tx0 + (q >> 2) * 16 + (q & 1) * 8 + (lane & 7), py = ty0 + ((q >> 1) & 1) * 8 + (lane >> 3);
-        const bool inside = px < W && py < H;
-        const size_t pix = (size_t)py * W + px;
-        const float T_final = inside ? p.final_T[pix] : 0.f;
-        T[q] = T_final;
-        ncontrib[q] = inside ? p.n_contrib[pix] : 0u;
-        if (q < 4) nmaxA = max(nmaxA, ncontrib[q]); else nmaxB = max(nmaxB, ncontrib[q]);
-        S[q] = 0.f;
-        float4 g;
-        g.x = (inside && p.dL_dcolor) ? p.dL_dcolor[pix] : 0.f;
-        g.y = (inside && p.dL_dcolor) ? p.dL_dcolor[HW + pix] : 0.f;
-        g.z = (inside && p.dL_dcolor) ? p.dL_dcolor[2 * HW + pix] : 0.f;
-        g.w = -T_final * (p.cam.bg[0] * g.x + p.cam.bg[1] * g.y + p.cam.bg[2] * g.z);
-        s_gpix[q][lane] = g;
-    }
-    nmaxA = wave_max_u32(nmaxA); nmaxB = wave_max_u32(nmaxB);
-    const uint32_t r0A = p.ranges[2 * tileA], r1A = p.ranges[2 * tileA + 1];
-    const uint32_t r0B = hasB ? p.ranges[2 * tileB] : 0u, r1B = hasB ? p.ranges[2 * tileB + 1] : 0u;
-    int topA = __builtin_amdgcn_readfirstlane(min((int)nmaxA, (int)(r1A - r0A)));
-    int topB = __builtin_amdgcn_readfirstlane(min((int)nmaxB, (int)(r1B - r0B)));
-    const bool bg0 = p.cam.bg[0] == 0.f && p.cam.bg[1] == 0.f && p.cam.bg[2] == 0.f;      // wave-uniform
-
-    auto traverse = [&](auto bg0_tag) {
-    constexpr bool BG0 = decltype(bg0_tag)::value;          // black background: the -T_final (bg . g) / (1 - alpha) term is zero
-    while (topA > 0 || topB > 0) {
-        const int cntA = min(CH, topA), cntB = min(CH, topB);
-        const bool fullA = cntA == topA, fullB = cntB == topB;          // nothing of the list is left below the staged window
-        // ---- stage: lanes 0..15 tile A, lanes 16..31 tile B; slot i of a half = its list entry top - 1 - i
-        const int hf = (lane >> 4) & 1, i = lane & 15;
-        const bool stg = lane < 32 && i < (hf ? cntB : cntA);
-        uint32_t mk = 0u, mid = 0u;
-        bool risky = false;
-        if (stg) {
-            const uint32_t pos = (uint32_t)((hf ? topB : topA) - 1 - i);
-            const uint32_t id = p.point_list[(hf ? r0B : r0A) + pos];
-            const float4* r = p.rec + (size_t)id * 4;
-            float4 ra = r[0];
-            ra.w = __uint_as_float(id);
-            float4 c1 = r[1];
-            risky = conic_is_risky(c1.x, c1.y, c1.z);
-            stage_for_exp2(ra, c1);
-            s_rec[hf][0][i] = ra; s_rec[hf][1][i] = c1; s_rec[hf][2][i] = r[2];
-            mk = __float_as_uint(p.depths[id]); mid = id;
-            s_key[hf][i] = make_uint2(mk, mid);
-        }
-        const uint64_t riskm = p.power_skip ? __builtin_amdgcn_ballot_w64(risky) : 0ull;          // bit = staging lane (half * 16 + slot)
-        __syncthreads();
-        // ---- rank: how many staged entries of the OTHER tile come before mine in the back-to-front order (larger (depth, id) first);
-        // an entry of A goes in front of its twin in B
-        int rank = 0, twin = -1;
-        {
-            const int ocnt = hf ? cntA : cntB;
-            int before = 0;
-            for (int j = 0; j < ocnt; j++) {
-                const uint2 o = s_key[hf ^ 1][j];
-                const bool gt = o.x > mk || (o.x == mk && o.y > mid);
-                const bool eq = o.x == mk && o.y == mid;
-                before += (gt || (eq && hf == 1)) ? 1 : 0;
-                twin = eq ? j : twin;
-            }
-            rank = i + before;
-        }
-        if (stg) s_sched[rank] = (hf == 0) ? ((uint32_t)i | ((twin >= 0 ? (uint32_t)twin : 255u) << 8)) : (twin >= 0 ? 0xFFFFu : (255u | ((uint32_t)i << 8)));
-        // ---- how much of the merged window may run now, and what that consumes of either list
-        const int nslots = cntA + cntB;
-        const int lastA = cntA > 0 ? __builtin_amdgcn_readlane(rank, cntA > 0 ? cntA - 1 : 0) : -1;
-        const int lastB = cntB > 0 ? __builtin_amdgcn_readlane(rank, cntB > 0 ? 16 + cntB - 1 : 16) : -1;
-        int nproc = nslots;
-        if (!fullA) nproc = min(nproc, lastA + 1);
-        if (!fullB) nproc = min(nproc, lastB + 1);
-        // an A entry is consumed when its slot runs; a B entry when its slot runs or its twin's slot (one in front of it) does
-        const uint64_t consumed = __builtin_amdgcn_ballot_w64(stg && (rank < nproc || (hf == 1 && twin >= 0 && rank - 1 < nproc)));
-        const int consA = __builtin_popcountll(consumed & 0xFFFFull), consB = __builtin_popcountll(consumed & 0xFFFF0000ull);
-        __syncthreads();
-
-        for (int sidx = 0; sidx < nproc; sidx++) {
-            const uint32_t e = __builtin_amdgcn_readfirstlane(s_sched[sidx]);
-            if (e == 0xFFFFu) continue;          // a B entry that runs with its twin
-            const int ia = (int)(e & 255u), jb = (int)((e >> 8) & 255u);
-            const bool inA = ia != 255, inB = jb != 255;
-            const int hsel = inA ? 0 : 1, slot = inA ? ia : jb;
-            const float4 q0 = s_rec[hsel][0][slot], q1 = s_rec[hsel][1][slot], q2 = s_rec[hsel][2][slot];
-            const float ca = q1.x, cb = q1.y, cc = q1.z, nlo = q0.z;
-            const bool isrisk = (riskm >> (hsel * 16 + slot)) & 1ull;
-            const uint32_t id = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
-            float v[12];
-#pragma unroll
-            for (int c = 0; c < 12; c++) v[c] = 0.f;
-            float aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f;
-            bool any = false;
-            uint32_t krow = 0u;          // the deterministic slab's row: this entry's position in tile A's list, else in tile B's
-            auto half_body = [&](auto htag, int slot_h, int top_h, uint32_t r0_h) {
-                constexpr int h = decltype(htag)::value;
-                const uint32_t k = (uint32_t)(top_h - 1 - slot_h);
-                if (h == 0 || !inA) krow = r0_h + k;
-                const float pxf0 = pxf0A + (float)(h * 16);
-                const float dx0 = q0.x - pxf0, dy0 = q0.y - pyf0;
-                const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
-                const float P0 = fmaf(dx0, lx0, fmaf(dy0, ly0, nlo));
-                float p2q[4], lxq[4], lyq[4];
-                p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
-                p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
-                lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0);
-                p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
-                p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));
-                lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
-                lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
-                if (isrisk) {
-                    const float4 g0 = p.rec[(size_t)id * 4], g1 = p.rec[(size_t)id * 4 + 1];
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        p2q[q] = ref_power_E(g0.x - (pxf0 + (float)((q & 1) * 8)), g0.y - (pyf0 + (float)((q >> 1) * 8)), g1.x, g1.y, g1.z, nlo);
-                }
-                float Q[4];
-                bool anyh = false;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int qq = h * 4 + q;
-                    const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[qq]) & __builtin_amdgcn_ballot_w64(p2q[q] <= ALPHA_SKIP_E);
-                    Q[q] = 0.f;
-                    if (okm != 0ull) {
-                        anyh = true;
-                        const float oG = select_or_zero_after_trans(okm, __builtin_amdgcn_exp2f(-p2q[q]));
-                        const float alpha = min_099(oG);
-                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T[qq] = T[qq] * rinv;
-                        const float w = alpha * T[qq];
-                        const float4 gp = s_gpix[qq][lane];
-                        const float cg = q2.x * gp.x + q2.y * gp.y + q2.z * gp.z;
-                        float dL_dalpha = cg - S[qq];
-                        S[qq] = fmaf(alpha, dL_dalpha, S[qq]);
-                        vR = fmaf(w, gp.x, vR); vG = fmaf(w, gp.y, vG); vB = fmaf(w, gp.z, vB);
-                        if constexpr (BG0) dL_dalpha = dL_dalpha * T[qq];
-                        else dL_dalpha = fmaf(dL_dalpha, T[qq], gp.w * rinv);
-                        const float qv = oG * dL_dalpha;
-                        Q[q] = qv;
-                        aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(anyh) != 0ull) {          // wave-uniform: this tile's moments join the entry's sums
-                    any = true;
-                    const float A = Q[1] + Q[3], B = Q[2] + Q[3], S0 = (Q[0] + Q[2]) + A;
-                    const float t = dx0 * S0, u = dy0 * S0;
-                    const float m0 = fmaf(-8.0f, A, t);
-                    v[0] += m0; v[1] += fmaf(-8.0f, B, u);
-                    v[4] += fmaf(dx0, fmaf(-16.0f, A, t), 64.0f * A);
-                    v[6] += fmaf(dy0, fmaf(-16.0f, B, u), 64.0f * B);
-                    v[5] += fmaf(-8.0f, fmaf(-8.0f, Q[3], dx0 * B), dy0 * m0);
-                    v[7] += S0;
-                }
-            };
-            if (inA) half_body(std::integral_constant<int, 0>{}, ia, topA, r0A);
-            if (inB) half_body(std::integral_constant<int, 1>{}, jb, topB, r0B);
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                v[2] = aX; v[3] = aY; v[8] = vR; v[9] = vG; v[10] = vB; v[11] = 0.f;
-                const float tot = wave_transpose_reduce12(v, lane);
-                if (col >= 0) {
-                    if (p.slab) p.slab[(size_t)krow * GACC_FLOATS + col] = tot;
-                    else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
-                }
-            }
-        }
-        __syncthreads();
-        topA -= consA; topB -= consB;
-    }
-    };
-    if (bg0) traverse(std::true_type{}); else traverse(std::false_type{});
-}
-
 // One entry point per variant so that each gets its own register budget.  Large frames: one wave per tile; small frames (fewer
 // tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up.
 __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_color_body<4>(p); }
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_color_body<1>(p); }
-__global__ void __launch_bounds__(64, 4) render_bwd_color_pair_kernel(BwdParams p) { render_bwd_color_pair_body(p); }
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_body<4>(p); }
 __global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_geo_body<1>(p); }
 
@@ -860,7 +645,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
     p.depth_pixels = a.out_depth; p.warped_pixels = a.out_warped;
     p.dL_dcolor = a.dL_dcolor; p.dL_dnormal = a.dL_dnormal; p.dL_ddepth = a.dL_ddepth; p.dL_dwarped = a.dL_dwarped;
-    p.gacc = a.grad_acc; p.slab = slab; p.depths = g.depths;
+    p.gacc = a.grad_acc; p.slab = slab;
     p.slot_c = im.slot_c; p.meta = im.meta; p.tab = geo_tab;
     const int nt = p.ntiles;
     // as the forward (render_fwd.hip): blocks of tiles per XCD; geo 8 x 4 (fetch traffic 0.73 -> 0.35 GB, clustered image 1.92 -> 1.83 ms)
@@ -880,13 +665,6 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     } else {
         if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {
             hipLaunchKernelGGL(render_bwd_color_small_kernel, grid(4), dim3(64), 0, s, p);
-            IBGS_HIP(hipGetLastError());
-            return 0;
-        }
-        static const int pairs = getenv("IBGS_BWD_PAIRS") ? atoi(getenv("IBGS_BWD_PAIRS")) : 0;
-        if (pairs) {
-            const int gxp = (p.cam.gx + 1) / 2;
-            hipLaunchKernelGGL(render_bwd_color_pair_kernel, dim3((unsigned)tile_map_grid(p.tmap, gxp, p.cam.gy, 1)), dim3(64), 0, s, p);
             IBGS_HIP(hipGetLastError());
             return 0;
         }
