@@ -66,7 +66,6 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.offsets = c.take<uint32_t>(P + 4);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
-    g.place = c.take<uint32_t>(place_scratch_elems(P));
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return g;
 }
@@ -306,11 +305,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
       // (the preprocess kernel has zeroed the sort's scratch, the look-back error flag [Pn + 1] that travels back with R, and [Pn + 3])
       // Gaussians without tiles (key 0xFFFFFFFF) are not carried through the sort; [Pn + 3] = how many others there are
-      // (with the look-back placement the sort's histogram kernel also counts the coarse entries per cell, binning.hip)
-      const int cgx = (gx + BIN_CELL - 1) / BIN_CELL, cgy = (gy + BIN_CELL - 1) / BIN_CELL;
-      const CellHistJob cells{g.fp, g.tmask_hi, g.place, cgx, cgx * cgy};
-      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.offsets + Pn + 1, g.offsets + Pn + 3, true,
-                                 place_lookback_ok((size_t)Pn, gx, gy) ? &cells : nullptr))) return rc; }
+      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.offsets + Pn + 1, g.offsets + Pn + 3, true))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
     // R = total number of (Gaussian, tile) pairs.  The binning arena is sized from it, and it is only known on the device.
     //  * no hint (first call of a shape, or debug): the tiles-touched counts are scanned, R travels to the host through a pinned
@@ -328,7 +323,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
         IBGS_HIP(hipEventRecord(rs->ev, s));
         IBGS_HIP(hipEventSynchronize(rs->ev));
-        if (rs->host[1]) { set_error("depth sort / placement: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
+        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
         *R_out = (int64_t)rs->host[0];
         return 0;
     };
@@ -336,12 +331,12 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if (deferred) cap = a.rendered_hint < (int64_t)0xFFFF0000ll ? a.rendered_hint : (int64_t)0xFFFF0000ll;
     else { if ((rc = exact_R(&R))) return rc; cap = R; }
 
-    auto tail = [&](int64_t n, bool read_back, bool redo) -> int {
+    auto tail = [&](int64_t n, bool read_back) -> int {
         int rc;
         char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, Hn), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, redo))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges))) return rc; }
         if (read_back) {
             // R as the binning counted it, the depth sort's error flag, the coarse slots in use: adjacent words, one copy, queued
             // HERE so that the host is served while the list scatter and the render still run
@@ -359,11 +354,11 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }
         return stage_check(s, debug, "render");
     };
-    if ((rc = tail(cap, deferred, false))) return rc;
+    if ((rc = tail(cap, deferred))) return rc;
     g_last_stats[1] = -1; g_last_stats[2] = 0;
     if (deferred) {
         IBGS_HIP(hipEventSynchronize(rs->ev));
-        if (rs->host[1]) { set_error("depth sort / placement: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
+        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
         R = (int64_t)rs->host[0];
         const bool coarse_overflow = (int64_t)rs->host[2] > cap;      // Gaussians were dropped: the binning's own R is incomplete too
         g_last_stats[1] = (int64_t)rs->host[2];
@@ -377,7 +372,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
                 if ((rc = exclusive_scan_u32(s, g.tiles, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
                 if ((rc = exact_R(&R))) return rc;
             }
-            if ((rc = tail(R, false, true))) return rc;
+            if ((rc = tail(R, false))) return rc;
         }
     }
     g_last_stats[0] = R;

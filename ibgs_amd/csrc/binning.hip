@@ -22,11 +22,124 @@
 // to the tiles the exact cull keeps); tests compare them with the oracle entry by entry.
 #include "common.h"
 #include "wave_bits.h"
-#include "footprint.h"
-#include <cstdlib>
 
 namespace ibgs {
 
+constexpr int CB = BIN_CELL;            // tiles per cell edge (8)
+constexpr int XCHUNK = BIN_XCHUNK;      // coarse entries per expansion chunk = 4 rounds of one wave
+
+// A Gaussian's rectangle and tile mask, loaded once into registers (the mask words beyond the first only exist for rectangles of
+// more than 64 tiles, preprocess.hip)
+struct RectU { uint32_t x0, x1, y0, y1; };
+// (the mask words are four scalars, not an array: selecting a word by a run-time index must stay a chain of register selects -- with an array
+// the compiler turns the chain into an indexed load, the whole footprint moves to scratch memory and every row of a large rectangle pays a
+// store -> load round trip.  2 % of C3's Gaussians take that path, a third of the waves hold one: cell_count 31 -> 23 us, cell_place 38 -> 28 us)
+struct Footprint { RectU r; uint64_t m0, m1, m2, m3; bool masked; };
+static_assert(IBGS_CULL_WORDS == 4, "four mask words");
+__device__ __forceinline__ Footprint make_footprint(const uint4 rr, const uint64_t* __restrict__ tmask_hi, uint32_t id)
+{
+    Footprint f;
+    f.r = RectU{rr.x & 0xFFFFu, rr.x >> 16, rr.y & 0xFFFFu, rr.y >> 16};
+    const uint32_t area = (f.r.x1 - f.r.x0) * (f.r.y1 - f.r.y0);
+    f.masked = area <= (uint32_t)IBGS_CULL_MAX_TILES;            // larger rectangles keep every tile (preprocess.hip)
+    f.m0 = ((uint64_t)rr.w << 32) | rr.z;
+    const uint64_t* mw = tmask_hi + (size_t)id * (IBGS_CULL_WORDS - 1);
+    f.m1 = (f.masked && area > 64u) ? mw[0] : 0ull;
+    f.m2 = (f.masked && area > 128u) ? mw[1] : 0ull;
+    f.m3 = (f.masked && area > 192u) ? mw[2] : 0ull;
+    return f;
+}
+
+// up to 8 bits of the row-major tile mask, starting at bit `start`
+__device__ __forceinline__ uint32_t mask_bits(const Footprint& f, uint32_t start, uint32_t len)
+{
+    const uint32_t w = start >> 6, o = start & 63u;
+    const uint64_t a0 = f.m0, a1 = f.m1, a2 = f.m2, a3 = f.m3;          // values, not addresses
+    const uint64_t lo = w == 0 ? a0 : (w == 1 ? a1 : (w == 2 ? a2 : a3));
+    const uint64_t hi = w == 0 ? a1 : (w == 1 ? a2 : a3);          // (only used when the run crosses into the next word)
+    uint64_t v = lo >> o;
+    if (o + len > 64u) v |= hi << (64u - o);
+    return (uint32_t)v & ((1u << len) - 1u);
+}
+
+// surviving tiles of one Gaussian inside cell (ccx, ccy): bit ly * 8 + lx for tile (8 ccx + lx, 8 ccy + ly)
+__device__ __forceinline__ uint64_t cell_mask(const Footprint& f, uint32_t ccx, uint32_t ccy)
+{
+    const RectU& r = f.r;
+    const uint32_t cx0 = ccx * CB, cy0 = ccy * CB;
+    const uint32_t xa = max(r.x0, cx0), xb = min(r.x1, cx0 + CB), ya = max(r.y0, cy0), yb = min(r.y1, cy0 + CB);
+    if (xa >= xb || ya >= yb) return 0ull;
+    const uint32_t w = r.x1 - r.x0;
+    const uint32_t len = xb - xa;
+    uint64_t m = 0ull;
+    for (uint32_t ty = ya; ty < yb; ty++) {
+        const uint32_t bits = f.masked ? mask_bits(f, (ty - r.y0) * w + (xa - r.x0), len) : ((1u << len) - 1u);
+        m |= (uint64_t)bits << ((ty - cy0) * CB + (xa - cx0));
+    }
+    return m;
+}
+
+// ---- cells in depth order by DIRECT PLACEMENT ------------------------------------------------------------------------------------
+// What a stable sort of (cell, depth rank) keys would produce, without materialising keys: a counting sort whose digits (the cells
+// a Gaussian reaches) are recomputed from the Gaussian's rectangle and tile mask instead of being read from an array.
+//   cell_count_kernel   one workgroup per block of G consecutive depth ranks: entries per cell (LDS histogram) -> cnt[cell][block]
+//   cell_colscan_kernel one workgroup per cell: exclusive scan over the blocks, in place; the cell's total
+//   cell_setup_kernel   one workgroup: first entry of every cell, chunk bookkeeping, C (the number of coarse entries)
+//   cell_place_kernel   same traversal as the count; an entry's slot = first entry of its cell + entries of earlier blocks + entries
+//                       of earlier ranks in its own block.  The last term: per batch of 64 ranks (a wave, lane = rank) every cell
+//                       collects the lanes that reach it as a 64-bit word in LDS (ds_or); rank inside the batch = set bits below
+//                       the own lane, plus the words of the block's earlier waves.
+// Cells are handled in slices of at most PLACE_MAX_CELLS (LDS tables); one slice covers a 4K frame.
+constexpr int PLACE_THREADS = 256;       // four waves, one batch of 64 consecutive depth ranks each per round
+constexpr int PLACE_MAX_CELLS = 1024;
+
+struct PlaceGeom { int P, G, nblk, cgx; int c0, nc; };            // G = depth ranks per block (a multiple of 256); cells [c0, c0 + nc) in this launch
+
+// The common case: a rectangle of at most 8 x 8 tiles reaches at most 2 x 2 cells and its whole mask is word 0.  The rows are spread
+// to a stride of 8 once; the part inside a cell is that image shifted by the rectangle's offset from the cell, columns that wrap
+// masked off.  Four fixed slots (cell < 0: none), so the callers run straight-line code and keep the masks between their sweeps.
+struct Cells4 { int cell[4]; uint64_t m[4]; };
+__device__ __forceinline__ bool small_cells(const PlaceGeom& pg, const Footprint& fp, Cells4& out)
+{
+    const RectU& r = fp.r;
+    const uint32_t w = r.x1 - r.x0, h = r.y1 - r.y0;          // (unsigned: an empty, culled rectangle fails the test below or yields no cell)
+#pragma unroll
+    for (int k = 0; k < 4; k++) { out.cell[k] = -1; out.m[k] = 0ull; }
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return true;            // culled: no tiles
+    if (w > (uint32_t)CB || h > (uint32_t)CB) return false;
+    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
+    uint64_t img = 0ull;
+    const uint64_t rowm = (1ull << w) - 1ull;
+    for (uint32_t i = 0; i < h; i++) img |= ((fp.m0 >> (i * w)) & rowm) << (8u * i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t cx = c0x + (uint32_t)(k & 1), cy = c0y + (uint32_t)(k >> 1);
+        if (cx > c1x || cy > c1y) continue;
+        const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+        if (cell < 0 || cell >= pg.nc) continue;
+        const int dx = (int)r.x0 - (int)(cx * CB), dy = (int)r.y0 - (int)(cy * CB);          // both in (-8, 8)
+        uint64_t m = dx >= 0 ? (img << dx) & (0x0101010101010101ull * (uint64_t)((0xFFu << dx) & 0xFFu))
+                             : (img >> (-dx)) & (0x0101010101010101ull * (uint64_t)(0xFFu >> (-dx)));
+        m = dy >= 0 ? m << (8 * dy) : m >> (8 * (-dy));
+        if (m != 0ull) { out.cell[k] = cell; out.m[k] = m; }
+    }
+    return true;
+}
+
+// larger rectangles: calls f(cell, mask) for every cell of the slice that holds a surviving tile of the Gaussian
+template <typename F>
+__device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& fp, F f)
+{
+    const RectU& r = fp.r;
+    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
+    for (uint32_t cy = c0y; cy <= c1y; cy++)
+        for (uint32_t cx = c0x; cx <= c1x; cx++) {
+            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+            if (cell < 0 || cell >= pg.nc) continue;
+            const uint64_t m = cell_mask(fp, cx, cy);
+            if (m != 0ull) f(cell, m);
+        }
+}
 
 __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi,
@@ -157,197 +270,6 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
             s_base[c] += (uint32_t)(__popcll(s_touch[c]) + __popcll(s_touch[nc + c]) + __popcll(s_touch[2 * nc + c]) + __popcll(s_touch[3 * nc + c]));
         __syncthreads();                                   // (blocks of more than 256 ranks: the next round clears the lane words)
     }
-}
-
-// ---- the same placement in ONE kernel -------------------------------------------------------------------------------------------------
-// The four launches above exist because a block of depth ranks needs, per cell, the entries of every earlier block (count -> column scan)
-// and the first entry of the cell (setup) before it can place.  Here
-//   * the entries per cell -- which do not depend on the depth order -- were counted by the depth sort's histogram kernel on its way over
-//     the keys (scan_sort.hip, CellHistJob); every workgroup scans those <= 1024 totals itself (the first one also writes the cell starts,
-//     the chunk bookkeeping and C for the expansion kernels);
-//   * a workgroup counts its own PLACE_LB_RANKS ranks per cell, publishes the counts and obtains the entries of the earlier blocks by
-//     DECOUPLED LOOK-BACK over their status rows (one word per cell: 2 flag bits + 30-bit count, agent-scope relaxed atomics; blocks are
-//     handed out through a ticket, so a workgroup only waits for workgroups that are running -- as the depth sort's passes do);
-//   * it then places its entries as cell_place_kernel does.  The footprints are gathered once and stay in registers between the two sweeps:
-//     no depth-ordered copy of them is written.
-// Results are identical to the four-kernel path (the same slots); C3: count 31 + column scan 8 + setup 7 + place 38 us -> one kernel.
-constexpr int LB_THREADS = 512, LB_WAVES = LB_THREADS / 64, LB_ROUNDS = PLACE_LB_RANKS / LB_THREADS;
-constexpr uint32_t LB_FLAG_AGG = 1u << 30, LB_FLAG_INC = 2u << 30, LB_VAL_MASK = (1u << 30) - 1u;
-
-// exclusive scan over the workgroup (LB_THREADS values); *total = the sum.  s_w: LB_WAVES + 1 words
-__device__ __forceinline__ uint32_t lb_block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* s_w)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
-    __syncthreads();                                      // (s_w may still be read from an earlier call)
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < LB_WAVES; w++) { const uint32_t t = s_w[w]; before += (w < wave) ? t : 0u; all += t; }
-    *total = all;
-    return before + inc - v;
-}
-
-__global__ void __launch_bounds__(LB_THREADS) cell_place_lookback_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
-                                                                         const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi,
-                                                                         const uint32_t* __restrict__ cell_total, uint32_t* __restrict__ ctrl /* [0] ticket */, uint32_t* __restrict__ err,
-                                                                         uint32_t* __restrict__ status /* blocks x nc, zeroed */,
-                                                                         uint32_t* __restrict__ cell_start /* ncells + 1 */, uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */,
-                                                                         uint32_t* __restrict__ C_out, uint4* __restrict__ cent, int dbg)
-{
-    extern __shared__ unsigned long long s_place[];        // LB_WAVES x nc lane words (one table per wave), then nc next-free slots, nc counts
-    __shared__ uint32_t s_w[LB_WAVES + 1];
-    __shared__ uint32_t s_bid;
-    const int nc = pg.nc;
-    unsigned long long* s_touch = s_place;
-    uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + LB_WAVES * nc);
-    uint32_t* s_cnt = s_base + nc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_bid = atomicAdd(&ctrl[0], 1u);
-    for (int c = tid; c < nc; c += LB_THREADS) s_cnt[c] = 0u;
-    for (int c = tid; c < LB_WAVES * nc; c += LB_THREADS) s_touch[c] = 0ull;
-
-    // first entry of every cell: exclusive scan over the totals, a strip of consecutive cells per thread (nc <= 2 x LB_THREADS)
-    const int per = (nc + LB_THREADS - 1) / LB_THREADS;
-    const int c0 = min(nc, tid * per), c1 = min(nc, c0 + per);
-    uint32_t sum = 0;
-    for (int c = c0; c < c1; c++) sum += cell_total[c];
-    uint32_t C;
-    uint32_t run = lb_block_exclusive_scan(sum, &C, s_w);          // (the barriers inside also publish s_bid and the cleared tables)
-    const uint32_t bid = s_bid;
-    // clamped to the capacity: entries that do not fit are dropped below, nobody reads past it, the call is redone (api.hip)
-    for (int c = c0; c < c1; c++) { s_base[c] = min(run, ccap); run += cell_total[c]; }
-    if (bid == 0) {                                       // (uniform) what cell_setup_kernel writes: cell starts, chunk bookkeeping, C
-        __syncthreads();
-        uint32_t chunks = 0;
-        for (int c = c0; c < c1; c++) {
-            const uint32_t a = s_base[c], e = (c + 1 < nc) ? s_base[c + 1] : min(C, ccap);
-            cell_start[c] = a;
-            chunks += (e - a + XCHUNK - 1) / XCHUNK;
-        }
-        uint32_t nchunks;
-        uint32_t crun = lb_block_exclusive_scan(chunks, &nchunks, s_w);
-        for (int c = c0; c < c1; c++) {
-            const uint32_t a = s_base[c], e = (c + 1 < nc) ? s_base[c + 1] : min(C, ccap);
-            cell_chunk0[c] = crun; crun += (e - a + XCHUNK - 1) / XCHUNK;
-        }
-        if (tid == 0) { cell_start[nc] = min(C, ccap); cell_chunk0[nc] = nchunks; *C_out = C; }
-    }
-    const int kept = (int)min((uint32_t)pg.P, *n_kept);          // ranks past the Gaussians with tiles hold nothing
-    const int j0 = (int)bid * PLACE_LB_RANKS;
-    if (j0 >= kept) return;                               // (uniform; every workgroup in front of one with ranks has ranks itself)
-    const int j1 = min(kept, j0 + PLACE_LB_RANKS);
-
-    // ---- sweep 1: gather the footprints (all rounds in flight), entries per cell of this block
-    uint32_t id[LB_ROUNDS];
-    uint4 rec[LB_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < LB_ROUNDS; r++) { const int j = j0 + r * LB_THREADS + tid; id[r] = j < j1 ? order[j] : 0u; }
-#pragma unroll
-    for (int r = 0; r < LB_ROUNDS; r++) { const int j = j0 + r * LB_THREADS + tid; rec[r] = j < j1 ? fpr[id[r]] : make_uint4(0u, 0u, 0u, 0u); }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < LB_ROUNDS; r++) {
-        if (j0 + r * LB_THREADS + tid < j1 && !(dbg & 4)) {
-            const Footprint fp = make_footprint(rec[r], tmask_hi, id[r]);
-            Cells4 c4;
-            if (small_cells(pg, fp, c4)) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicAdd(&s_cnt[c4.cell[k]], 1u);
-            } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
-        }
-    }
-    __syncthreads();
-
-    // ---- entries of the earlier blocks, per cell: publish, look back
-    for (int c = tid; c < nc; c += LB_THREADS) {
-        const uint32_t tot = s_cnt[c];
-        uint32_t* mine = status + (size_t)bid * nc + c;
-        __hip_atomic_store(mine, (bid == 0 ? LB_FLAG_INC : LB_FLAG_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        if (bid > 0 && !(dbg & 1)) {
-            // LOOKBACK status words per round trip (independent loads), consumed in order up to the first inclusive prefix or the first word
-            // not yet published, where the walk resumes after a short sleep
-            constexpr int LOOKBACK = 16;
-            int64_t b = (int64_t)bid - 1;
-            uint32_t spins = 0;
-            bool done = false;
-            while (!done && b >= 0) {
-                uint32_t st[LOOKBACK];
-#pragma unroll
-                for (int k = 0; k < LOOKBACK; k++)
-                    st[k] = (b - k >= 0) ? __hip_atomic_load(status + (size_t)(b - k) * nc + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_FLAG_INC;
-                int used = 0;
-#pragma unroll
-                for (int k = 0; k < LOOKBACK; k++) {
-                    if (done || used != k) continue;
-                    const uint32_t flag = st[k] & ~LB_VAL_MASK;
-                    if (flag == 0u) continue;
-                    excl += st[k] & LB_VAL_MASK;
-                    used = k + 1;
-                    if (flag == LB_FLAG_INC) done = true;
-                }
-                b -= used;
-                if (!done && used < LOOKBACK) {
-                    if (++spins > (1u << 26)) { *err = 1u; break; }      // bounded: never hang the device (the host fails the call, api.hip)
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            __hip_atomic_store(mine, LB_FLAG_INC | ((excl + tot) & LB_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_base[c] += excl;
-    }
-    __syncthreads();
-
-    // ---- sweep 2: place, a round of LB_THREADS consecutive ranks at a time (as cell_place_kernel)
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned long long* mine = s_touch + wave * nc;
-#pragma unroll
-    for (int r = 0; r < LB_ROUNDS; r++) {
-        if (j0 + r * LB_THREADS >= j1 || (dbg & 2)) break;             // uniform
-        const bool have = j0 + r * LB_THREADS + tid < j1;
-        Footprint fp; Cells4 c4; bool small = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) c4.cell[k] = -1;
-        if (have) {
-            fp = make_footprint(rec[r], tmask_hi, id[r]);
-            small = small_cells(pg, fp, c4);
-            if (small) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicOr(&mine[c4.cell[k]], 1ull << lane);
-            } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); });
-        }
-        __syncthreads();
-        auto place = [&](int cell, uint64_t m) {
-            uint32_t pos = s_base[cell] + (uint32_t)__popcll(mine[cell] & below);
-            for (int w = 0; w < wave; w++) pos += (uint32_t)__popcll(s_touch[w * nc + cell]);       // earlier waves = earlier ranks
-            if (pos < ccap) cent[pos] = make_uint4(id[r], 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
-        };
-        if (have) {
-            if (small) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) place(c4.cell[k], c4.m[k]);
-            } else for_cells(pg, fp, place);
-        }
-        __syncthreads();
-        for (int c = tid; c < nc; c += LB_THREADS) {      // next free slot of every cell; the lane words are cleared for the next round
-            uint32_t n = 0;
-#pragma unroll
-            for (int w = 0; w < LB_WAVES; w++) { n += (uint32_t)__popcll(s_touch[w * nc + c]); s_touch[w * nc + c] = 0ull; }
-            s_base[c] += n;
-        }
-        __syncthreads();
-    }
-}
-
-static int g_place_lookback = getenv("IBGS_PLACE_LOOKBACK") ? atoi(getenv("IBGS_PLACE_LOOKBACK")) : 1;
-bool place_lookback_ok(size_t P, int gx, int gy)
-{
-    const int ncells = ((gx + CB - 1) / CB) * ((gy + CB - 1) / CB);
-    return g_place_lookback != 0 && ncells <= PLACE_LB_MAX_CELLS && radix_zero_elems(P, 32) > 0;
 }
 
 // which cell owns chunk `ch` (cell_chunk0 is non-decreasing, cell_chunk0[ncells] = number of chunks)
@@ -555,7 +477,7 @@ static int place_block_ranks(int P, size_t cnt_elems, int ncells)
 
 // Part 1: everything up to the tile ranges and the counters the host reads back (R, C); part 2 (launch_binning_scatter) writes the
 // lists.  Split so that the host's read-back can be queued between them and is served while scatter + render still run.
-int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges, bool redo)
+int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges)
 {
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy, ntiles = gx * gy;
     uint32_t* counters = g.offsets + P;               // R, depth sort error flag, C: what the host reads back in ONE copy (api.hip)
@@ -563,20 +485,10 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     const uint32_t ccap = (uint32_t)b.ccap;
     PlaceGeom pg;
     pg.P = P; pg.cgx = cgx;
-    const uint32_t* order = g.sort_val[0];
-    const bool lookback = place_lookback_ok((size_t)P, gx, gy) && ccap < LB_VAL_MASK;
-    if (lookback) {
-        pg.G = PLACE_LB_RANKS; pg.nblk = (P + PLACE_LB_RANKS - 1) / PLACE_LB_RANKS; pg.c0 = 0; pg.nc = ncells;
-        uint32_t* ctrl = g.place + PLACE_MAX_CELLS;
-        // a second binning of the same frame (the hint was too small, api.hip): the cell totals stand, ticket and status rows start over
-        if (redo) IBGS_HIP(hipMemsetAsync(ctrl, 0, sizeof(uint32_t) * (PLACE_CTRL + (size_t)pg.nblk * ncells), s));
-        hipLaunchKernelGGL(cell_place_lookback_kernel, dim3((unsigned)pg.nblk), dim3(LB_THREADS), (size_t)ncells * (8u * LB_WAVES + 8u), s, pg, ccap, order, g.offsets + P + 3,
-                           g.fp, g.tmask_hi, g.place, ctrl, counters + 1, ctrl + PLACE_CTRL, b.cell_start, b.cell_chunk0, counters + 2, b.cent, getenv("IBGS_LB_DBG") ? atoi(getenv("IBGS_LB_DBG")) : 0);
-        IBGS_HIP(hipGetLastError());
-    } else {
     pg.G = place_block_ranks(P, b.cnt_elems, ncells);
     if (pg.G <= 0) { set_error("binning arena too small for the cell count matrix"); return -IBGS_ERR_ALLOC; }
     pg.nblk = (P + pg.G - 1) / pg.G;
+    const uint32_t* order = g.sort_val[0];
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
         hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.offsets + P + 3, g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
@@ -591,7 +503,6 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
         hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
                            b.cnt, b.cell_start, b.cent);
         IBGS_HIP(hipGetLastError());
-    }
     }
     const unsigned nchunks_max = (unsigned)(ccap / XCHUNK + (size_t)ncells + 1);
     hipLaunchKernelGGL(expand_count_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, b.cent, b.chunk_cnt);

@@ -54,8 +54,6 @@ struct GeomState {
                            //      together; [P+3] = Gaussians with tiles (what the depth sort keeps)
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
-    uint32_t* place;       // place_scratch_elems(P)   the look-back placement's device state (binning.hip): entries per coarse cell, ticket and
-                           //      error words, one status row per block of depth ranks -- zeroed by the preprocess kernel
     static GeomState carve(char* base, size_t P, size_t* total);
 };
 
@@ -74,19 +72,6 @@ struct ImgState {
 
 constexpr int BIN_CELL = 8;        // two-level binning (binning.hip): a coarse cell = 8 x 8 tiles
 constexpr int BIN_XCHUNK = 256;    // coarse entries per expansion chunk (one wave, four rounds)
-constexpr int PLACE_MAX_CELLS = 1024;      // cells per placement launch (LDS tables); one slice covers a 4K frame
-constexpr int PLACE_LB_MAX_CELLS = 768;    // ... of the look-back placement (72 bytes of LDS per cell, 64 KB of dynamic LDS without opting in to more)
-constexpr int PLACE_LB_RANKS = 2048;       // depth ranks per workgroup of the look-back placement
-constexpr int PLACE_CTRL = 64;             // words between the cell totals and the status rows: [0] ticket, [1] error flag
-inline size_t place_scratch_elems(size_t P) { return (size_t)PLACE_MAX_CELLS + PLACE_CTRL + ((P + PLACE_LB_RANKS - 1) / PLACE_LB_RANKS + 1) * (size_t)PLACE_MAX_CELLS; }
-// the look-back placement is used when the frame's cells fit one slice and the depth sort runs as single-launch passes (whose histogram
-// kernel counts the entries per cell); IBGS_PLACE_LOOKBACK=0 forces the four-kernel placement
-bool place_lookback_ok(size_t P, int gx, int gy);
-inline size_t place_zero_elems(size_t P, int gx, int gy)
-{
-    const size_t nc = (size_t)((gx + BIN_CELL - 1) / BIN_CELL) * (size_t)((gy + BIN_CELL - 1) / BIN_CELL);
-    return (size_t)PLACE_MAX_CELLS + PLACE_CTRL + ((P + PLACE_LB_RANKS - 1) / PLACE_LB_RANKS) * nc;
-}
 
 struct BinState {
     uint32_t* point_list;  // R     sorted Gaussian ids (final); FIRST in the arena so that its offset does not depend on the capacity
@@ -276,12 +261,8 @@ int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float*
 // device-wide primitives (scan_sort.hip)
 size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by radix_sort_pairs on n items
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
-// A job the single-launch sort's histogram kernel does on its way over the keys (index i = Gaussian): entries per coarse cell of the
-// binning (footprint.h), which do not depend on the depth order -- the placement needs them before its first entry can land.
-struct CellHistJob { const uint4* fpr; const uint64_t* tmask_hi; uint32_t* cell_total /* nc, zeroed */; int cgx; int nc; };
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
-                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false,
-                     const CellHistJob* cells = nullptr /* only honoured by the single-launch passes: radix_zero_elems(n, nbits) > 0 */);
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false);
 size_t radix_zero_elems(size_t n, int nbits);      // leading words of `hist` the sort needs zeroed (see scratch_is_zero)
 // err_dev: device word (zeroed by the caller) that the single-launch look-back passes set to 1 when their bounded spin gives up --
 //          the pass has then scattered with a partial prefix; the caller must read it back and fail the call.  With err_dev == nullptr
@@ -297,7 +278,7 @@ void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatt
 
 // per-tile lists + tile ranges from the depth-ordered Gaussians (two-level binning, binning.hip); `cap` = capacity of point_list
 // part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
-int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges, bool redo = false /* second binning of the same frame */);
+int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges);
 int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);

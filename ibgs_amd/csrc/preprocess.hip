@@ -39,7 +39,6 @@ struct PreParams {
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
     uint32_t* zero_a; uint32_t zero_a_n; uint32_t* zero_b; uint32_t zero_b_n;      // words the next stages want zeroed (the depth sort's scratch, its counters)
-    uint32_t* zero_c; uint32_t zero_c_n;                                           // ... the look-back placement's cell totals, ticket and status rows (binning.hip)
 };
 
 __device__ __forceinline__ float ndc_to_pix(float v, int S)
@@ -144,7 +143,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t z = (uint32_t)gi; z < p.zero_a_n; z += gridDim.x * blockDim.x) p.zero_a[z] = 0u;      // instead of two fill launches
     if ((uint32_t)gi < p.zero_b_n) p.zero_b[gi] = 0u;
-    for (uint32_t z = (uint32_t)gi; z < p.zero_c_n; z += gridDim.x * blockDim.x) p.zero_c[z] = 0u;
     const bool valid = gi < p.P;          // lanes past the end stay in the wave: the record transpose below is wave-wide
     const int i = valid ? gi : p.P - 1;   // (they recompute the last Gaussian and store nothing)
 
@@ -500,8 +498,6 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     const int gy = (a.H + TILE - 1) / TILE;
     p.zero_a = g.hist; p.zero_a_n = (uint32_t)radix_zero_elems((size_t)nv * a.P, 32);
     p.zero_b = g.offsets + (size_t)nv * a.P + 1; p.zero_b_n = 3;
-    const int gx_all = (a.W + TILE - 1) / TILE, gy_all = nv * gy;
-    p.zero_c = g.place; p.zero_c_n = place_lookback_ok((size_t)nv * a.P, gx_all, gy_all) ? (uint32_t)place_zero_elems((size_t)nv * a.P, gx_all, gy_all) : 0u;
     for (int v = 0; v < nv; v++) {       // batched depth passes: one launch per camera, outputs land in that view's slice
         p.inst0 = v * a.P; p.tile_row0 = v * gy;
         const Cam cam = make_cam(a.viewmatrix + 16 * v, a.projmatrix + 16 * v, a.campos + 3 * v, a.bg,

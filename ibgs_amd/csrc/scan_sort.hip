@@ -10,7 +10,6 @@
 // per-wave LDS counters; scatter is staged through LDS so that global writes are runs of
 // consecutive addresses.
 #include "common.h"
-#include "footprint.h"
 #include <cstdlib>
 
 namespace ibgs {
@@ -294,20 +293,12 @@ constexpr int OS_MAX_PASS = 4;
 constexpr int OS_HIST_THREADS = 1024;      // few, large workgroups: every workgroup ends with one global atomic per non-empty bin
 constexpr int OS_THREADS = 512, OS_WAVES = OS_THREADS / 64, OS_ITEMS = RS_CHUNK / OS_THREADS;      // same chunk as the classic passes, twice the waves: the ranking is a chain of LDS round trips per item
 
-template <bool CELLS>
 __global__ void __launch_bounds__(OS_HIST_THREADS) onesweep_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npass, int dbits,
                                                                    uint32_t* __restrict__ ghist /* npass x 256 */,
-                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept,
-                                                                   CellHistJob job)
+                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept)
 {
     __shared__ uint32_t h[OS_MAX_PASS][RS_MAX_BINS];
     __shared__ uint32_t s_kept;
-    __shared__ uint32_t s_cell[CELLS ? PLACE_MAX_CELLS : 1];
-    PlaceGeom pg;
-    if constexpr (CELLS) {
-        pg.P = 0; pg.G = 0; pg.nblk = 0; pg.cgx = job.cgx; pg.c0 = 0; pg.nc = job.nc;
-        for (int c = threadIdx.x; c < job.nc; c += OS_HIST_THREADS) s_cell[c] = 0;
-    }
     for (int k = threadIdx.x; k < OS_MAX_PASS * RS_MAX_BINS; k += OS_HIST_THREADS) (&h[0][0])[k] = 0;
     if (threadIdx.x == 0) s_kept = 0;
     __syncthreads();
@@ -319,16 +310,6 @@ __global__ void __launch_bounds__(OS_HIST_THREADS) onesweep_hist_kernel(const ui
         if (drop_max && k == 0xFFFFFFFFu) continue;
         kept++;
         for (int p = 0; p < npass; p++) atomicAdd(&h[p][(k >> (p * dbits)) & mask], 1u);
-        if constexpr (CELLS) {
-            if (k != 0xFFFFFFFFu) {          // a Gaussian with tiles: one coarse entry per cell that holds one of them (as the placement will find them)
-                const Footprint fp = make_footprint(job.fpr[i], job.tmask_hi, (uint32_t)i);
-                Cells4 c4;
-                if (small_cells(pg, fp, c4)) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) if (c4.cell[q] >= 0) atomicAdd(&s_cell[c4.cell[q]], 1u);
-                } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cell[cell], 1u); });
-            }
-        }
     }
     if (kept) atomicAdd(&s_kept, kept);
     __syncthreads();
@@ -336,9 +317,6 @@ __global__ void __launch_bounds__(OS_HIST_THREADS) onesweep_hist_kernel(const ui
     for (int k = threadIdx.x; k < npass * RS_MAX_BINS; k += OS_HIST_THREADS) {
         const uint32_t c = (&h[0][0])[k];
         if (c) atomicAdd(&ghist[k], c);
-    }
-    if constexpr (CELLS) {
-        for (int c = threadIdx.x; c < job.nc; c += OS_HIST_THREADS) { const uint32_t v = s_cell[c]; if (v) atomicAdd(&job.cell_total[c], v); }
     }
 }
 
@@ -495,8 +473,7 @@ static size_t onesweep_elems(size_t n)
 }
 
 static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
-                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero,
-                                     const CellHistJob* cells)
+                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero)
 {
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int nbins = 1 << dbits;
@@ -508,8 +485,7 @@ static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t*
     if (!scratch_is_zero) IBGS_HIP(hipMemsetAsync(scratch, 0, need * sizeof(uint32_t), s));
     const unsigned hb = (unsigned)((n + 8u * OS_HIST_THREADS - 1) / (8u * OS_HIST_THREADS));          // ~8 keys per thread (4 and 16 measured: 12.1 / 17.2 us against 12.2)
     const unsigned hblocks = hb < 256u ? (hb ? hb : 1u) : 256u;
-    if (cells) hipLaunchKernelGGL(onesweep_hist_kernel<true>, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33, *cells);
-    else hipLaunchKernelGGL(onesweep_hist_kernel<false>, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33, CellHistJob{});
+    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33);
     IBGS_HIP(hipGetLastError());
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
@@ -565,7 +541,7 @@ size_t radix_zero_elems(size_t n, int nbits_total)
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, const CellHistJob* cells)
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -574,7 +550,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
     if (want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
-        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero, cells);
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;
