@@ -85,6 +85,8 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.valid_w = c.take<float>(HW * IBGS_MAX_SRC);
     im.meta = c.take<uint32_t>(32);
     im.slot_c = c.take<uint32_t>(HW * IBGS_MAX_BUFFER_LENGTH);
+    im.tile_walked = c.take<uint32_t>(tiles);
+    im.tile_order = c.take<uint32_t>((tiles + 1023) / 1024 * 1024);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;
 }
@@ -206,7 +208,7 @@ int64_t ibgs_geom_offset(int32_t P, const char* name)
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
 {
     size_t t; ImgState im = ImgState::carve(nullptr, W, H, &t);
-    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c);
+    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order);
     return -1;
 }
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)

@@ -65,8 +65,10 @@ struct ImgState {
     uint32_t* low_high;    // HW x 2 (geo) min / max contributor of the median buffer
     int32_t* valid_idx;    // 5 x HW (geo)
     float* valid_w;        // 5 x HW (geo)
-    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass
+    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = 1 when tile_walked holds this frame
     uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
+    uint32_t* tile_walked; // tiles   how far the forward walked every tile's list (largest n_contrib of the tile) = the colour backward's work there
+    uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)
     static ImgState carve(char* base, int W, int H, size_t* total);
 };
 
@@ -127,6 +129,24 @@ __device__ __forceinline__ float ref_power_E(float dx, float dy, float a, float 
     const float power = -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy;
     return power > 0.0f ? __builtin_inff() : fmaf(-power, LOG2_E, neg_log2_opacity);          // +inf fails every E <= log2(255) test
 }
+
+// ---- diagnostic build only (-DIBGS_TRACE_WAVES, tools/wave_trace.py): where and when every wave of a blend kernel ran ----------------------
+// One stamp per workgroup: {HW_ID (wave slot, SIMD, CU, SE), XCC_ID, start, end} on the 100 MHz constant clock, which all XCDs share.  The
+// product build compiles none of this (no stamp executes in the real kernel: cdna_hip_programming.md, in-kernel stamps).
+#ifdef IBGS_TRACE_WAVES
+constexpr int IBGS_TRACE_MAX = 32768;
+#define IBGS_TRACE_BEGIN() const unsigned long long ibgs_trace_t0_ = __builtin_amdgcn_s_memrealtime()
+#define IBGS_TRACE_END(buf)                                                                                         \
+    do {                                                                                                            \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();                                            \
+        if (threadIdx.x == 0 && blockIdx.x < (unsigned)IBGS_TRACE_MAX)                                              \
+            (buf)[blockIdx.x] = make_uint4(__builtin_amdgcn_s_getreg((31 << 11) | 4), __builtin_amdgcn_s_getreg((31 << 11) | 20), \
+                                           (uint32_t)ibgs_trace_t0_, (uint32_t)t1_);                                \
+    } while (0)
+#else
+#define IBGS_TRACE_BEGIN() do { } while (0)
+#define IBGS_TRACE_END(buf) do { } while (0)
+#endif
 
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);

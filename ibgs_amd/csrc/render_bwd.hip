@@ -51,6 +51,7 @@ struct BwdParams {
     const float* dL_dcolor; const float* dL_dnormal; const float* dL_ddepth; const float* dL_dwarped;
     float* gacc;
     const uint32_t* slot_c; const uint32_t* meta; float* tab;     // geo: the forward's buffered contributor numbers (+ slot count); the window pass's table
+    const uint32_t* order;      // balanced launch order of the colour kernel: workgroup -> tile (0xFFFFFFFF: none), nullptr: the tile map decides
     float* slab;          // IBGS_FLAG_DETERMINISTIC: (R x waves per tile) x 16, one row per (list entry, wave of its tile), written instead of the atomics (else nullptr)
 };
 
@@ -106,7 +107,7 @@ __device__ __forceinline__ float fast_rcp(float x)
 //   * "k < n_contrib" costs two compares per quadrant per CHUNK when no pixel of the quadrant switches on inside the chunk
 //     (each pixel switches on once per traversal), instead of one per Gaussian.
 template <int PPL>
-__device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
+__device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const int tile, const int sub)
 {
     constexpr int CHUNK = 16;          // 16 records per round: 0.75 KB + 4 KB of per-pixel constants <= 5 KB per wave = 8 waves per SIMD, every tile of a 1080p frame resident at once
     __shared__ float4 s_rec[3][CHUNK];
@@ -116,8 +117,6 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p)
     int col = reduce12_column(lane);
     if (col >= 11) col = -1;
     constexpr int IPT = 4 / PPL;
-    int tile, sub;
-    if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
@@ -618,8 +617,96 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
 
 // One entry point per variant so that each gets its own register budget.  Large frames: one wave per tile; small frames (fewer
 // tiles than wave slots): one wave per 8x8 quadrant so that the chip fills up.
-__global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p) { render_bwd_color_body<4>(p); }
-__global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p) { render_bwd_color_body<1>(p); }
+#ifdef IBGS_TRACE_WAVES
+__device__ uint4 g_trace_bwd[IBGS_TRACE_MAX];
+#endif
+__global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p)
+{
+    IBGS_TRACE_BEGIN();
+    int tile, sub = 0;
+    bool have;
+    if (p.order) { const uint32_t t = p.order[blockIdx.x]; tile = (int)t; have = t != 0xFFFFFFFFu; }
+    else have = tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub);
+    if (have) render_bwd_color_body<4>(p, tile, sub);
+    IBGS_TRACE_END(g_trace_bwd);
+}
+
+// ---- balanced launch order for the colour kernel ----------------------------------------------------------------------------------
+// One wave per tile, all of them resident at once (8 160 tiles on 8 192 slots at 1080p): the dispatcher puts workgroups i and i + 1024 on the
+// same SIMD (measured: tools/wave_trace.py --placement; XCD = i % 8), so a SIMD's load is the sum of "its" eight tiles and the kernel ends
+// with the heaviest SIMD.  In tile order that sum varies like eight random tiles: the SIMDs end at 94 % of the span on average with C3's
+// uniform lists, at 83 % with trained-like opacities (cv of the work per tile 0.06 / 0.21) -- tools/balance_stats.py models it, the wave
+// stamps confirm it (92 % / 82 %).  The work of a tile is known: the forward wrote how far it walked every list (ImgState::tile_walked).
+// This kernel sorts the tiles by it, descending (counting sort on the top 10 bits, one workgroup), and deals the ranks out in SNAKE order
+// over the 1 024 SIMD classes: stratum r / 1024 of rank r goes to one round, class r % 1024 forwards for even strata and backwards for odd ones -- every
+// class gets one tile of each octile, heavy ones paired with light ones: heaviest SIMD / mean 1.06 -> 1.01 (uniform), 1.20 -> 1.02 (trained).
+// The tile map plays no role for this kernel (profiles/r03_tile_map.txt: every layout within 1 %).  Frames with more tiles than slots are launched
+// in plain descending order (later workgroups start as slots free up: longest first is what a queue wants).
+// A pure performance heuristic: any order gives the same gradients (the deterministic mode's slab is indexed by list position).
+constexpr int ORDER_CLASSES = 1024, ORDER_SNAKE_ROUNDS = 8;
+__global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots /* ntiles rounded up to ORDER_CLASSES */, const uint32_t* __restrict__ walked,
+                                                          const uint32_t* __restrict__ meta, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_hist[1024];
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (meta[10] != 1u) {          // the forward did not run the one-wave-per-tile variant: nothing known, tile order
+        for (int i = tid; i < nslots; i += 1024) order[i] = i < ntiles ? (uint32_t)i : 0xFFFFFFFFu;
+        return;
+    }
+    s_hist[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    for (int i = tid; i < nslots; i += 1024) order[i] = 0xFFFFFFFFu;          // every slot empty first: a backwards round that is not full leaves its holes at ITS low end
+    __syncthreads();
+    constexpr int KEEP = 16;          // tiles per thread kept in registers (frames up to 16 K tiles; more: read again)
+    uint32_t w[KEEP];
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) { const int t = tid + k * 1024; w[k] = t < ntiles ? walked[t] : 0u; m = max(m, w[k]); }
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) m = max(m, walked[t]);
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (lane == 0) atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t mx = s_max;
+    const int sh = mx >= 1024u ? (32 - __builtin_clz(mx)) - 10 : 0;
+    auto bucket = [&](uint32_t v) { return 1023u - min(v >> sh, 1023u); };          // descending
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) if (tid + k * 1024 < ntiles) atomicAdd(&s_hist[bucket(w[k])], 1u);
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) atomicAdd(&s_hist[bucket(walked[t])], 1u);
+    __syncthreads();
+    const uint32_t v = s_hist[tid];
+    uint32_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int ww = 0; ww < wave; ww++) before += s_w[ww];
+    s_hist[tid] = before + inc - v;
+    __syncthreads();
+    const uint32_t nrounds = (uint32_t)nslots / (uint32_t)ORDER_CLASSES;
+    auto put = [&](int t, uint32_t key) {
+        const uint32_t r = atomicAdd(&s_hist[bucket(key)], 1u);          // rank among the tiles, heaviest first (ties in any order)
+        const uint32_t stratum = r / ORDER_CLASSES, c = r % ORDER_CLASSES;
+        uint32_t slot = r;          // more tiles than slots: workgroups beyond the slots start as earlier ones end -- heaviest first, as a queue wants it
+        if (nrounds <= (uint32_t)ORDER_SNAKE_ROUNDS) {
+            // the first 1 024 workgroups are placed differently from the rest (their SIMD's next workgroup is i + 768 or i + 512, not i + 1 024:
+            // tools/wave_trace.py --slowest), so that round gets the LIGHTEST stratum -- where a wrong partner costs least -- and the snake runs
+            // over rounds 1 .. 7
+            const uint32_t round = (stratum + 1u) % nrounds;
+            slot = round * ORDER_CLASSES + ((stratum & 1u) ? ORDER_CLASSES - 1u - c : c);
+        }
+        order[slot] = (uint32_t)t;
+    };
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) if (tid + k * 1024 < ntiles) put(tid + k * 1024, w[k]);
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) put(t, walked[t]);
+}
+__global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p)
+{
+    int tile, sub;
+    if (tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4, tile, sub)) render_bwd_color_body<1>(p, tile, sub);
+}
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_body<4>(p); }
 __global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_geo_body<1>(p); }
 
@@ -645,7 +732,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
     p.depth_pixels = a.out_depth; p.warped_pixels = a.out_warped;
     p.dL_dcolor = a.dL_dcolor; p.dL_dnormal = a.dL_dnormal; p.dL_ddepth = a.dL_ddepth; p.dL_dwarped = a.dL_dwarped;
-    p.gacc = a.grad_acc; p.slab = slab;
+    p.gacc = a.grad_acc; p.slab = slab; p.order = nullptr;
     p.slot_c = im.slot_c; p.meta = im.meta; p.tab = geo_tab;
     const int nt = p.ntiles;
     // as the forward (render_fwd.hip): blocks of tiles per XCD; geo 8 x 4 (fetch traffic 0.73 -> 0.35 GB, clustered image 1.92 -> 1.83 ms)
@@ -668,6 +755,16 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             IBGS_HIP(hipGetLastError());
             return 0;
         }
+        static const int balanced = getenv("IBGS_BWD_BALANCED") ? atoi(getenv("IBGS_BWD_BALANCED")) : 1;
+        if (balanced) {
+            const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, im.tile_walked, im.meta, im.tile_order);
+            IBGS_HIP(hipGetLastError());
+            p.order = im.tile_order;
+            hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            IBGS_HIP(hipGetLastError());
+            return 0;
+        }
         static const int pad_lds = getenv("IBGS_BWD_PAD_LDS") ? atoi(getenv("IBGS_BWD_PAD_LDS")) : 0;      // experiments: dynamic LDS that nobody uses = fewer waves per SIMD
         hipLaunchKernelGGL(render_bwd_color_kernel, grid(1), dim3(64), pad_lds, s, p);
     }
@@ -676,3 +773,10 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
 }
 
 }  // namespace ibgs
+
+#ifdef IBGS_TRACE_WAVES
+extern "C" int ibgs_debug_trace_bwd(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ibgs::g_trace_bwd), bytes < sizeof(uint4) * ibgs::IBGS_TRACE_MAX ? bytes : sizeof(uint4) * ibgs::IBGS_TRACE_MAX, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -38,7 +38,7 @@ struct FwdParams {
     int power_skip;      // reproduce the reference's `power > 0` skip for near-singular conics (common.h)
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
-    float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta;
+    float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
     float* out_min_depth_diff; float* out_camera_ray; int32_t* out_mask;
@@ -102,9 +102,13 @@ __device__ __forceinline__ float tex_depth(const float* __restrict__ img, int W,
 
 // MAXL = compile-time capacity of the per-pixel median buffer (4 covers the reference's default
 // buffer_length = 4 with half the select chains of 8).
+#ifdef IBGS_TRACE_WAVES
+__device__ uint4 g_trace_fwd[IBGS_TRACE_MAX];
+#endif
 template <int MODE, int PPL, int MAXL>
 __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 {
+    IBGS_TRACE_BEGIN();
     constexpr bool GEO = (MODE == MODE_GEO);
     constexpr bool DEPTH = (MODE == MODE_DEPTH);
     constexpr int NQ = GEO ? 4 : 3;          // record quads staged per Gaussian
@@ -349,6 +353,18 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         if (DEPTH) p.out_depth[pix] = wd_sum[q] / (tot_w[q] + eps);
         if (GEO) { p.out_normal[pix] = Nacc[q][0]; p.out_normal[HW + pix] = Nacc[q][1]; p.out_normal[2 * HW + pix] = Nacc[q][2]; }
     }
+    // how far this tile's list was walked = what the colour backward will have to do here (it orders its launch by it, render_bwd.hip);
+    // only the variant with one wave per tile says so (meta[10]), the others say that nothing was written
+    if constexpr (MODE == MODE_COLOR && PPL == 4) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) m = max(m, inside[q] ? lastc[q] : 0u);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
+        if (lane == 0) { p.walked[tile] = m; if (blockIdx.x == 0) p.meta[10] = 1u; }
+    } else {
+        if (blockIdx.x == 0 && lane == 0) p.meta[10] = 0u;
+    }
     // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
     // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --
     // the kernel's register count is the blend loop's.
@@ -483,6 +499,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             p.out_depth[pix] = med;
         }
     }
+    IBGS_TRACE_END(g_trace_fwd);
 }
 
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
@@ -497,7 +514,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
     p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
-    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta;
+    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta; p.walked = im.tile_walked;
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;
@@ -537,3 +554,10 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
 }
 
 }  // namespace ibgs
+
+#ifdef IBGS_TRACE_WAVES
+extern "C" int ibgs_debug_trace_fwd(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ibgs::g_trace_fwd), bytes < sizeof(uint4) * ibgs::IBGS_TRACE_MAX ? bytes : sizeof(uint4) * ibgs::IBGS_TRACE_MAX, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -1,0 +1,82 @@
+"""The colour backward's balanced launch order (render_bwd.hip: tile_order_kernel): a performance heuristic that must never change what
+is computed.  Checked directly: what the forward reports as walked per tile is the tile's largest n_contrib; the order the backward
+built holds every tile exactly once, empty slots are marked, and frames with more tiles than wave slots are launched heaviest first.
+(That the gradients are right under it is what every parity test with one wave per tile checks.)"""
+import numpy as np
+import pytest
+import torch
+
+from ibgs_amd import _lib, rasterizer
+from tests import hipref
+from tests.scenes import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def img_arena(outs):
+    """The forward's image arena (a saved tensor of the autograd node): taken BEFORE backward() frees the node's references; the backward writes
+    the launch order into the same memory."""
+    return outs["color"].grad_fn.saved_tensors[-1]
+
+
+def order_state(inp, img_t):
+    lib = _lib.load()
+    W, H = int(inp["W"]), int(inp["H"])
+    img = img_t.cpu().numpy()
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    nt = gx * gy
+    nslots = (nt + 1023) // 1024 * 1024
+
+    def view(name, count):
+        off = lib.ibgs_img_offset(W, H, name.encode())
+        assert off >= 0, name
+        return np.frombuffer(img.tobytes()[off:off + 4 * count], dtype=np.uint32).copy()
+    return nt, nslots, view("meta", 32), view("tile_walked", nt), view("tile_order", nslots), view("n_contrib", W * H).reshape(H, W), (gx, gy)
+
+
+@pytest.mark.parametrize("W,H,P", [(1920, 1088, 30000), (208, 144, 2000), (2560, 1456, 30000)])
+def test_every_tile_once_and_walked_is_the_largest_n_contrib(W, H, P):
+    old = rasterizer.WAVE_SHAPE
+    rasterizer.WAVE_SHAPE = "tile"
+    try:
+        inp = scene(P=P, W=W, H=H, deg=1, seed=11, opacity="trained", scale_mul=1.0 if W > 1000 else 3.0)
+        outs, lv, _ = hipref.run_forward(inp)
+        g = torch.randn(3, H, W, device="cuda")
+        img = img_arena(outs)
+        (outs["color"] * g).sum().backward()
+        torch.cuda.synchronize()
+        nt, nslots, meta, walked, order, nc, (gx, gy) = order_state(inp, img)
+    finally:
+        rasterizer.WAVE_SHAPE = old
+    assert meta[10] == 1
+    pad = np.zeros((gy * 16, gx * 16), np.uint32); pad[:H, :W] = nc
+    assert np.array_equal(walked, pad.reshape(gy, 16, gx, 16).max(axis=(1, 3)).reshape(-1))
+    tiles = order[order != 0xFFFFFFFF]
+    assert tiles.size == nt and np.array_equal(np.sort(tiles), np.arange(nt, dtype=np.uint32)), "every tile exactly once"
+    assert (order == 0xFFFFFFFF).sum() == nslots - nt
+    if nslots // 1024 > 8:          # more tiles than wave slots: plain descending order of the sort's key (the top 10 bits of the walked length)
+        assert np.array_equal(np.nonzero(order != 0xFFFFFFFF)[0], np.arange(nt))
+        sh = max(0, int(walked.max()).bit_length() - 10)
+        key = walked[order[:nt]] >> sh
+        assert (np.diff(key.astype(np.int64)) <= 0).all()
+    else:                          # stratum s (1 024 ranks) sits in round (s + 1) % rounds: the heaviest tiles are not in the first 1 024 workgroups
+        r = nslots // 1024
+        if r > 1 and walked.max() > 0:
+            first = order[:1024]; first = first[first != 0xFFFFFFFF]
+            assert walked[first].astype(np.float64).mean() <= walked.astype(np.float64).mean()
+
+
+def test_quadrant_waves_leave_the_order_alone():
+    """Small frames run one wave per 8 x 8 quadrant: the forward says that nothing was recorded (meta[10] = 0)."""
+    old = rasterizer.WAVE_SHAPE
+    rasterizer.WAVE_SHAPE = "quadrant"
+    try:
+        inp = scene(P=1500, W=208, H=144, deg=1, seed=12, opacity="trained", scale_mul=3.0)
+        outs, lv, _ = hipref.run_forward(inp)
+        img = img_arena(outs)
+        (outs["color"] * torch.randn(3, 144, 208, device="cuda")).sum().backward()
+        torch.cuda.synchronize()
+        meta = order_state(inp, img)[2]
+    finally:
+        rasterizer.WAVE_SHAPE = old
+    assert meta[10] == 0

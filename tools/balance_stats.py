@@ -1,0 +1,88 @@
+"""How evenly does the colour backward's work fall on the 1 024 SIMDs?  
+One wave per tile, every tile resident at once (8 160 waves on 8 192 slots at 1080p): the kernel ends when the most loaded SIMD is done.
+Per-tile work from the deterministic backward's slab (which list entries were PROCESSED, = reduced and added) and from the forward's
+n_contrib (how far each tile's list is WALKED): cost model 230 instructions per processed entry, 60 per walked-only entry (ISA counts).
+Placement models: workgroup i -> XCD i % 8, then round-robin over that XCD's 128 SIMDs; and a random placement.  Prints max / mean load."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ibgs_amd import rasterizer, synthetic as syn
+from tests import hipref
+
+args = sys.argv[1:] or ["init", "trained"]
+for opacity in args:
+    c = syn.CONFIGS["C3"]
+    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity)
+    rasterizer.DETERMINISTIC = True; rasterizer.KEEP_DET_SCRATCH = True
+    outs, lv, _ = hipref.run_forward(inp)
+    ist = hipref.internal_state(outs, inp)
+    g = torch.randn(3, c["H"], c["W"], device="cuda")
+    (outs["color"] * g).sum().backward()
+    torch.cuda.synchronize()
+    R = ist["R"]
+    det = rasterizer._CModule.last_det
+    slab = det[: R * 64].view(torch.float32).view(R, 16)
+    processed = (slab != 0).any(dim=1)
+    ranges = ist["ranges"].astype(np.int64)
+    W, H = c["W"], c["H"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    counts = ranges[:, 1] - ranges[:, 0]
+    tile_of = np.repeat(np.arange(ranges.shape[0]), counts)
+    proc = np.bincount(tile_of[processed.cpu().numpy()], minlength=gx * gy).astype(np.float64)
+    nc = np.zeros((gy * 16, gx * 16), np.int64); nc[:H, :W] = ist["n_contrib"].reshape(H, W)
+    top = np.minimum(nc.reshape(gy, 16, gx, 16).max(axis=(1, 3)).reshape(-1), counts).astype(np.float64)
+    work = 230.0 * proc + 60.0 * (top - proc)
+    nt = gx * gy
+    # launch order of the tiles: blocks of 8 x 8 tiles, row-major inside a block, blocks row-major (TMAP_BLOCK; the XCD round-robin goes over consecutive workgroups)
+    order = []
+    for by in range(0, gy, 8):
+        for bx in range(0, gx, 8):
+            for ty in range(by, min(by + 8, gy)):
+                for tx in range(bx, min(bx + 8, gx)):
+                    order.append(ty * gx + tx)
+    order = np.array(order)
+    w_launch = work[order]
+    nsimd = 1024
+    mean = work.sum() / nsimd
+    load_rr = np.zeros(nsimd)
+    for i, w in enumerate(w_launch):
+        xcd = i % 8; k = i // 8
+        load_rr[xcd * 128 + k % 128] += w
+    rng = np.random.default_rng(0)
+    load_rand = np.zeros(nsimd); np.add.at(load_rand, rng.integers(0, nsimd, nt), w_launch)
+    # greedy, longest first (what a work queue sorted by list length approaches)
+    import heapq
+    h = [0.0] * nsimd; heapq.heapify(h)
+    for w in np.sort(work)[::-1]:
+        heapq.heappush(h, heapq.heappop(h) + w)
+    lpt = max(h)
+    # greedy in launch order (a work queue without sorting)
+    h = [0.0] * nsimd; heapq.heapify(h)
+    for w in w_launch:
+        heapq.heappush(h, heapq.heappop(h) + w)
+    fifo = max(h)
+    # the placement as measured (tools/wave_trace.py --placement): workgroups i and i + 1024 share a SIMD when every workgroup is one wave and all are
+    # resident.  Today: launch order = tile order (rr map).  Snake: tiles sorted by a key, rank r -> round r // 1024, class r % 1024 (reversed in odd rounds)
+    def classes(perm):          # perm[i] = tile launched as workgroup i
+        load = np.zeros(1024); np.add.at(load, np.arange(len(perm)) % 1024, work[perm]); return load.max() / (work.sum() / 1024)
+    def snake(key):
+        r = np.argsort(-key, kind="stable"); perm = np.empty(len(r), np.int64)
+        for k in range((len(r) + 1023) // 1024):
+            seg = r[k * 1024:(k + 1) * 1024]
+            perm[k * 1024:k * 1024 + len(seg)] = seg if k % 2 == 0 else np.concatenate([seg[::-1], []]).astype(np.int64) if len(seg) == 1024 else seg[::-1]
+        return perm
+    def snake_classes(key):          # odd rounds run the classes backwards (a short last round still starts at the far end)
+        r = np.argsort(-key, kind="stable"); load = np.zeros(1024)
+        for i, t in enumerate(r):
+            k, c = divmod(i, 1024)
+            load[c if k % 2 == 0 else 1023 - c] += work[t]
+        return load.max() / (work.sum() / 1024)
+    print("   measured placement model (workgroup %% 1024): tile order %.3f (mean / max = %.3f); snake by true work %.3f; snake by list length %.3f; snake by walked length %.3f"
+          % (classes(np.arange(nt)), 1.0 / classes(np.arange(nt)), snake_classes(work), snake_classes(counts.astype(np.float64)), snake_classes(top)))
+    print("C3 opacity=%s: tiles %d, walked entries %.2f M, processed %.2f M; work per tile: mean %.0f, cv %.2f, max %.0f (%.1f x mean)"
+          % (opacity, nt, top.sum() / 1e6, proc.sum() / 1e6, work.mean(), work.std() / work.mean(), work.max(), work.max() / work.mean()))
+    print("   per-SIMD load, max / mean: round-robin placement %.2f, random placement %.2f, work queue in launch order %.2f, work queue longest first %.2f"
+          % (load_rr.max() / mean, load_rand.max() / mean, fifo / mean, lpt / mean))
+    rasterizer.DETERMINISTIC = False; rasterizer.KEEP_DET_SCRATCH = False
+    del outs, lv, det, slab
+    torch.cuda.empty_cache()
