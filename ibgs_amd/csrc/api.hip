@@ -85,7 +85,7 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.valid_w = c.take<float>(HW * IBGS_MAX_SRC);
     im.meta = c.take<uint32_t>(32);
     im.slot_c = c.take<uint32_t>(HW * IBGS_MAX_BUFFER_LENGTH);
-    im.tile_walked = c.take<uint32_t>(tiles);
+    im.tile_walked = c.take<uint32_t>(tiles * 4);
     im.tile_order = c.take<uint32_t>((tiles + 1023) / 1024 * 1024);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;

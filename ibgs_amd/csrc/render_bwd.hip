@@ -441,7 +441,8 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
     if (col >= 15) col = -1;
     constexpr int IPT = 4 / PPL;
     int tile, sub;
-    if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, IPT, tile, sub)) return;
+    if (PPL == 4 && p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)t; sub = 0; }
+    else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
@@ -644,17 +645,19 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p)
 // in plain descending order (later workgroups start as slots free up: longest first is what a queue wants).
 // A pure performance heuristic: any order gives the same gradients (the deterministic mode's slab is indexed by list position).
 constexpr int ORDER_CLASSES = 1024, ORDER_SNAKE_ROUNDS = 8;
-__global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots /* ntiles rounded up to ORDER_CLASSES */, const uint32_t* __restrict__ walked,
-                                                          const uint32_t* __restrict__ meta, uint32_t* __restrict__ order)
+__global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots /* ntiles rounded up to ORDER_CLASSES */, int slot_rounds /* waves per SIMD of the kernel that follows */,
+                                                          const uint32_t* __restrict__ walked_waves, const uint32_t* __restrict__ meta, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t s_hist[1024];
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (meta[10] != 1u) {          // the forward did not run the one-wave-per-tile variant: nothing known, tile order
+    const uint32_t ipt = meta[10];          // waves per tile of the forward variant that ran (1, 2 or 4): a tile was walked as far as its farthest wave
+    if (ipt != 1u && ipt != 2u && ipt != 4u) {          // (an arena no forward of this library wrote)
         for (int i = tid; i < nslots; i += 1024) order[i] = i < ntiles ? (uint32_t)i : 0xFFFFFFFFu;
         return;
     }
+    auto walked_of = [&](int t) { uint32_t v = walked_waves[(size_t)t * ipt]; for (uint32_t k = 1; k < ipt; k++) v = max(v, walked_waves[(size_t)t * ipt + k]); return v; };
     s_hist[tid] = 0u;
     if (tid == 0) s_max = 0u;
     for (int i = tid; i < nslots; i += 1024) order[i] = 0xFFFFFFFFu;          // every slot empty first: a backwards round that is not full leaves its holes at ITS low end
@@ -663,8 +666,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
     uint32_t w[KEEP];
     uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const int t = tid + k * 1024; w[k] = t < ntiles ? walked[t] : 0u; m = max(m, w[k]); }
-    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) m = max(m, walked[t]);
+    for (int k = 0; k < KEEP; k++) { const int t = tid + k * 1024; w[k] = t < ntiles ? walked_of(t) : 0u; m = max(m, w[k]); }
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) m = max(m, walked_of(t));
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     if (lane == 0) atomicMax(&s_max, m);
     __syncthreads();
@@ -673,7 +676,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
     auto bucket = [&](uint32_t v) { return 1023u - min(v >> sh, 1023u); };          // descending
 #pragma unroll
     for (int k = 0; k < KEEP; k++) if (tid + k * 1024 < ntiles) atomicAdd(&s_hist[bucket(w[k])], 1u);
-    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) atomicAdd(&s_hist[bucket(walked[t])], 1u);
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) atomicAdd(&s_hist[bucket(walked_of(t))], 1u);
     __syncthreads();
     const uint32_t v = s_hist[tid];
     uint32_t inc = v;
@@ -689,7 +692,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
         const uint32_t r = atomicAdd(&s_hist[bucket(key)], 1u);          // rank among the tiles, heaviest first (ties in any order)
         const uint32_t stratum = r / ORDER_CLASSES, c = r % ORDER_CLASSES;
         uint32_t slot = r;          // more tiles than slots: workgroups beyond the slots start as earlier ones end -- heaviest first, as a queue wants it
-        if (nrounds <= (uint32_t)ORDER_SNAKE_ROUNDS) {
+        if (nrounds <= (uint32_t)slot_rounds) {
             // the first 1 024 workgroups are placed differently from the rest (their SIMD's next workgroup is i + 768 or i + 512, not i + 1 024:
             // tools/wave_trace.py --slowest), so that round gets the LIGHTEST stratum -- where a wrong partner costs least -- and the snake runs
             // over rounds 1 .. 7
@@ -700,7 +703,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
     };
 #pragma unroll
     for (int k = 0; k < KEEP; k++) if (tid + k * 1024 < ntiles) put(tid + k * 1024, w[k]);
-    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) put(t, walked[t]);
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) put(t, walked_of(t));
 }
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p)
 {
@@ -747,6 +750,17 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         if (!geo_tab) { set_error("geo backward needs the window table scratch"); return -IBGS_ERR_INVALID; }
         hipLaunchKernelGGL(geo_window_kernel, dim3((unsigned)(((size_t)a.W * a.H + 255) / 256)), dim3(256), 0, s, p);
         IBGS_HIP(hipGetLastError());
+        // the geo kernel holds four waves per SIMD: 4 096 slots for a 1080p frame's 8 160 tiles, so the second half of the launch starts as slots
+        // free up -- a queue, which wants the heaviest tiles first (plain descending order; slot_rounds = 4 makes the order kernel choose it).  That
+        // gives up the 8 x 4 block map's L2 locality and still wins everywhere: C3-geo 1.497 -> 1.452 ms, trained 0.600 -> 0.570, half of the
+        // Gaussians in one blob 1.764 -> 1.464 ms (-17 %).  IBGS_BWD_GEO_BALANCED=0: the tile map's order
+        static const int geo_balanced = getenv("IBGS_BWD_GEO_BALANCED") ? atoi(getenv("IBGS_BWD_GEO_BALANCED")) : 1;
+        if (big && geo_balanced) {
+            const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order);
+            p.order = im.tile_order;
+            hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+        } else
         if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, grid(1), dim3(64), 0, s, p);
         else hipLaunchKernelGGL(render_bwd_geo_kernel, grid(4), dim3(64), 0, s, p);
     } else {
@@ -758,7 +772,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         static const int balanced = getenv("IBGS_BWD_BALANCED") ? atoi(getenv("IBGS_BWD_BALANCED")) : 1;
         if (balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, im.tile_walked, im.meta, im.tile_order);
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order);
             IBGS_HIP(hipGetLastError());
             p.order = im.tile_order;
             hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);

@@ -353,17 +353,15 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         if (DEPTH) p.out_depth[pix] = wd_sum[q] / (tot_w[q] + eps);
         if (GEO) { p.out_normal[pix] = Nacc[q][0]; p.out_normal[HW + pix] = Nacc[q][1]; p.out_normal[2 * HW + pix] = Nacc[q][2]; }
     }
-    // how far this tile's list was walked = what the colour backward will have to do here (it orders its launch by it, render_bwd.hip);
-    // only the variant with one wave per tile says so (meta[10]), the others say that nothing was written
-    if constexpr (MODE == MODE_COLOR && PPL == 4) {
+    // how far this wave walked the tile's list = what the backward will have to do here (it orders its launch by it, render_bwd.hip): one word
+    // per (tile, wave of the tile); meta[10] says how many waves a tile has in this variant
+    {
         uint32_t m = 0;
 #pragma unroll
         for (int q = 0; q < PPL; q++) m = max(m, inside[q] ? lastc[q] : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
-        if (lane == 0) { p.walked[tile] = m; if (blockIdx.x == 0) p.meta[10] = 1u; }
-    } else {
-        if (blockIdx.x == 0 && lane == 0) p.meta[10] = 0u;
+        if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (blockIdx.x == 0) p.meta[10] = (uint32_t)IPT; }
     }
     // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
     // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --

@@ -66,17 +66,24 @@ def test_every_tile_once_and_walked_is_the_largest_n_contrib(W, H, P):
             assert walked[first].astype(np.float64).mean() <= walked.astype(np.float64).mean()
 
 
-def test_quadrant_waves_leave_the_order_alone():
-    """Small frames run one wave per 8 x 8 quadrant: the forward says that nothing was recorded (meta[10] = 0)."""
+def test_quadrant_waves_record_per_wave():
+    """Small frames run one wave per 8 x 8 quadrant: four words per tile, meta[10] = 4 (the backward of that shape does not reorder anything)."""
     old = rasterizer.WAVE_SHAPE
     rasterizer.WAVE_SHAPE = "quadrant"
     try:
-        inp = scene(P=1500, W=208, H=144, deg=1, seed=12, opacity="trained", scale_mul=3.0)
+        W, H = 208, 144
+        inp = scene(P=1500, W=W, H=H, deg=1, seed=12, opacity="trained", scale_mul=3.0)
         outs, lv, _ = hipref.run_forward(inp)
         img = img_arena(outs)
-        (outs["color"] * torch.randn(3, 144, 208, device="cuda")).sum().backward()
+        (outs["color"] * torch.randn(3, H, W, device="cuda")).sum().backward()
         torch.cuda.synchronize()
-        meta = order_state(inp, img)[2]
+        nt, nslots, meta, _, _, nc, (gx, gy) = order_state(inp, img)
+        lib = _lib.load()
+        off = lib.ibgs_img_offset(W, H, b"tile_walked")
+        walked = np.frombuffer(img.cpu().numpy().tobytes()[off:off + 16 * nt], dtype=np.uint32).reshape(nt, 4)
     finally:
         rasterizer.WAVE_SHAPE = old
-    assert meta[10] == 0
+    assert meta[10] == 4
+    pad = np.zeros((gy * 16, gx * 16), np.uint32); pad[:H, :W] = nc
+    q = pad.reshape(gy, 2, 8, gx, 2, 8).max(axis=(2, 5))          # [ty, qy, tx, qx]
+    assert np.array_equal(walked, q.transpose(0, 2, 1, 3).reshape(nt, 4))          # wave of the tile = 2 * qy + qx
