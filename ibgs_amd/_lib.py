@@ -54,6 +54,7 @@ class ForwardArgs(ctypes.Structure):
         ("rendered_hint", ctypes.c_int64),
         ("plane_normal", c_float_p), ("plane_offset", c_float_p), ("plane_mode", ctypes.c_int32),
         ("n_views", ctypes.c_int32), ("view_tanfovx", ctypes.c_float * 8), ("view_tanfovy", ctypes.c_float * 8),
+        ("tile_order_hint", ctypes.c_void_p),
     ]
 
 
@@ -98,12 +99,13 @@ class BackwardArgs(ctypes.Structure):
         ("geo_table", ctypes.c_void_p), ("geo_table_bytes", ctypes.c_size_t),
         ("det_scratch", ctypes.c_void_p), ("det_scratch_bytes", ctypes.c_size_t),
         ("buffer_length", ctypes.c_int32),
+        ("tile_order_out", ctypes.c_void_p),
     ]
 
 
 # every symbol include/ibgs_rast.h declares
 EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "ibgs_required_tex",
-           "ibgs_forward", "ibgs_backward", "ibgs_mark_visible",
+           "ibgs_forward", "ibgs_backward", "ibgs_mark_visible", "ibgs_tile_order_slots",
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
@@ -166,6 +168,8 @@ def load():
     lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     lib.ibgs_adam_step.restype = ctypes.c_int32
     lib.ibgs_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.ibgs_tile_order_slots.restype = ctypes.c_size_t
+    lib.ibgs_tile_order_slots.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.ibgs_required_l1.restype = ctypes.c_size_t
     lib.ibgs_required_l1.argtypes = []
     lib.ibgs_l1_loss.restype = ctypes.c_int32

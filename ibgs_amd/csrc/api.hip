@@ -86,7 +86,7 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.meta = c.take<uint32_t>(32);
     im.slot_c = c.take<uint32_t>(HW * IBGS_MAX_BUFFER_LENGTH);
     im.tile_walked = c.take<uint32_t>(tiles * 4);
-    im.tile_order = c.take<uint32_t>((tiles + 1023) / 1024 * 1024);
+    im.tile_order = c.take<uint32_t>((tiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;
 }
@@ -204,6 +204,11 @@ int64_t ibgs_geom_offset(int32_t P, const char* name)
     if (!strcmp(name, "order")) return (int64_t)((char*)g.sort_val[0] - (char*)nullptr);
     if (!strcmp(name, "sorted_depth_keys")) return (int64_t)((char*)g.sort_key[0] - (char*)nullptr);
     return -1;
+}
+size_t ibgs_tile_order_slots(int32_t W, int32_t H)
+{
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    return (tiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
 }
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
 {
@@ -338,7 +343,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, Hn), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta))) return rc; }
         if (read_back) {
             // R as the binning counted it, the depth sort's error flag, the coarse slots in use: adjacent words, one copy, queued
             // HERE so that the host is served while the list scatter and the render still run

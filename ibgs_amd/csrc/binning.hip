@@ -350,10 +350,41 @@ __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint3
 // Per-tile totals -> tile starts (exclusive scan, in place; [ntiles] = R) -> ranges, ONE workgroup: a strip of consecutive tiles per
 // thread, the 1024 strip sums scanned through LDS.  Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after
 // its memset).
+constexpr int HINT_MAX_TILES = 65536;          // tile order hints are checked against a bitmap in LDS (8 KB)
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
-                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
+                                                           const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
 {
     __shared__ uint32_t s_wave[16];
+    // The caller's launch order hint for the blend kernel (ibgs_forward_args::tile_order_hint): used only when it holds every tile exactly
+    // once -- whatever else the buffer may contain must not be able to change the image.  This workgroup has the time (it is one wave
+    // deep in memory latency anyway): a bitmap of the tiles in LDS, one atomic OR per word of the hint.
+    if (meta) {
+        __shared__ uint32_t s_seen[HINT_MAX_TILES / 32];
+        int ok = 0;
+        if (order_hint && ntiles <= HINT_MAX_TILES) {
+            const int nslots = (ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+            for (int w = threadIdx.x; w < (ntiles + 31) / 32; w += 1024) s_seen[w] = 0u;
+            __syncthreads();
+            int bad = 0, mine = 0;
+            for (int i = threadIdx.x; i < nslots; i += 1024) {
+                const uint32_t t = order_hint[i];
+                if (t == 0xFFFFFFFFu) continue;
+                if (t >= (uint32_t)ntiles) { bad = 1; continue; }
+                const uint32_t bit = 1u << (t & 31u);
+                if (atomicOr(&s_seen[t >> 5], bit) & bit) bad = 1;
+                mine++;
+            }
+            const int any_bad = __syncthreads_or(bad);
+            __shared__ uint32_t s_cnt;
+            if (threadIdx.x == 0) s_cnt = 0u;
+            __syncthreads();
+            if (mine) atomicAdd(&s_cnt, (uint32_t)mine);
+            __syncthreads();
+            ok = (!any_bad && s_cnt == (uint32_t)ntiles) ? 1 : 0;
+        }
+        if (threadIdx.x == 0) meta[11] = (uint32_t)ok;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (ntiles + 1023) / 1024;
     const int t0 = min(ntiles, tid * per), t1 = min(ntiles, t0 + per);
@@ -477,11 +508,16 @@ static int place_block_ranks(int P, size_t cnt_elems, int ncells)
 
 // Part 1: everything up to the tile ranges and the counters the host reads back (R, C); part 2 (launch_binning_scatter) writes the
 // lists.  Split so that the host's read-back can be queued between them and is served while scatter + render still run.
-int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges)
+int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
+                   const uint32_t* order_hint, uint32_t* meta)
 {
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy, ntiles = gx * gy;
     uint32_t* counters = g.offsets + P;               // R, depth sort error flag, C: what the host reads back in ONE copy (api.hip)
-    if (cap <= 0) { IBGS_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles, s)); return 0; }      // R = 0 (synchronous sizing)
+    if (cap <= 0) {      // R = 0 (synchronous sizing): empty ranges, and no hint was looked at
+        IBGS_HIP(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles, s));
+        if (meta) IBGS_HIP(hipMemsetAsync(meta + 11, 0, sizeof(uint32_t), s));
+        return 0;
+    }
     const uint32_t ccap = (uint32_t)b.ccap;
     PlaceGeom pg;
     pg.P = P; pg.cgx = cgx;
@@ -510,7 +546,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
-                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll));
+                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), order_hint, meta);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -65,7 +65,7 @@ struct ImgState {
     uint32_t* low_high;    // HW x 2 (geo) min / max contributor of the median buffer
     int32_t* valid_idx;    // 5 x HW (geo)
     float* valid_w;        // 5 x HW (geo)
-    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = waves per tile of the forward variant that wrote tile_walked
+    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = waves per tile of the forward variant that wrote tile_walked, [11] = 1 when the caller's tile_order_hint holds a valid order
     uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
     uint32_t* tile_walked; // tiles x 4   how far the forward walked every tile's list (largest n_contrib), per wave of the tile ([tile * waves + wave]) = the backward's work there
     uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)
@@ -298,7 +298,9 @@ void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatt
 
 // per-tile lists + tile ranges from the depth-ordered Gaussians (two-level binning, binning.hip); `cap` = capacity of point_list
 // part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
-int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges);
+int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
+                   const uint32_t* order_hint = nullptr, uint32_t* meta = nullptr /* meta[11] = 1 when the hint is a valid tile order */);
+constexpr int ORDER_CLASSES = 1024;          // SIMDs of the chip = classes of the balanced launch order (render_bwd.hip)
 int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);

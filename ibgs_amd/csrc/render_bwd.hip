@@ -644,9 +644,10 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p)
 // The tile map plays no role for this kernel (profiles/r03_tile_map.txt: every layout within 1 %).  Frames with more tiles than slots are launched
 // in plain descending order (later workgroups start as slots free up: longest first is what a queue wants).
 // A pure performance heuristic: any order gives the same gradients (the deterministic mode's slab is indexed by list position).
-constexpr int ORDER_CLASSES = 1024, ORDER_SNAKE_ROUNDS = 8;
+constexpr int ORDER_SNAKE_ROUNDS = 8;
 __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots /* ntiles rounded up to ORDER_CLASSES */, int slot_rounds /* waves per SIMD of the kernel that follows */,
-                                                          const uint32_t* __restrict__ walked_waves, const uint32_t* __restrict__ meta, uint32_t* __restrict__ order)
+                                                          const uint32_t* __restrict__ walked_waves, const uint32_t* __restrict__ meta, uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ order_out /* the caller's copy (ibgs_backward_args::tile_order_out) or nullptr */)
 {
     __shared__ uint32_t s_hist[1024];
     __shared__ uint32_t s_w[16];
@@ -654,13 +655,13 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ipt = meta[10];          // waves per tile of the forward variant that ran (1, 2 or 4): a tile was walked as far as its farthest wave
     if (ipt != 1u && ipt != 2u && ipt != 4u) {          // (an arena no forward of this library wrote)
-        for (int i = tid; i < nslots; i += 1024) order[i] = i < ntiles ? (uint32_t)i : 0xFFFFFFFFu;
+        for (int i = tid; i < nslots; i += 1024) { const uint32_t v = i < ntiles ? (uint32_t)i : 0xFFFFFFFFu; order[i] = v; if (order_out) order_out[i] = v; }
         return;
     }
     auto walked_of = [&](int t) { uint32_t v = walked_waves[(size_t)t * ipt]; for (uint32_t k = 1; k < ipt; k++) v = max(v, walked_waves[(size_t)t * ipt + k]); return v; };
     s_hist[tid] = 0u;
     if (tid == 0) s_max = 0u;
-    for (int i = tid; i < nslots; i += 1024) order[i] = 0xFFFFFFFFu;          // every slot empty first: a backwards round that is not full leaves its holes at ITS low end
+    for (int i = tid; i < nslots; i += 1024) { order[i] = 0xFFFFFFFFu; if (order_out) order_out[i] = 0xFFFFFFFFu; }          // every slot empty first: a backwards round that is not full leaves its holes at ITS low end
     __syncthreads();
     constexpr int KEEP = 16;          // tiles per thread kept in registers (frames up to 16 K tiles; more: read again)
     uint32_t w[KEEP];
@@ -700,6 +701,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
             slot = round * ORDER_CLASSES + ((stratum & 1u) ? ORDER_CLASSES - 1u - c : c);
         }
         order[slot] = (uint32_t)t;
+        if (order_out) order_out[slot] = (uint32_t)t;
     };
 #pragma unroll
     for (int k = 0; k < KEEP; k++) if (tid + k * 1024 < ntiles) put(tid + k * 1024, w[k]);
@@ -757,7 +759,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         static const int geo_balanced = getenv("IBGS_BWD_GEO_BALANCED") ? atoi(getenv("IBGS_BWD_GEO_BALANCED")) : 1;
         if (big && geo_balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order);
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, (uint32_t*)nullptr);
             p.order = im.tile_order;
             hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
         } else
@@ -772,7 +774,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         static const int balanced = getenv("IBGS_BWD_BALANCED") ? atoi(getenv("IBGS_BWD_BALANCED")) : 1;
         if (balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order);
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order, a.tile_order_out);
             IBGS_HIP(hipGetLastError());
             p.order = im.tile_order;
             hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);

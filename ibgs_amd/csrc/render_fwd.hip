@@ -39,6 +39,7 @@ struct FwdParams {
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
+    const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by tile_ranges_kernel: meta[11]; nullptr: the tile map
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
     float* out_min_depth_diff; float* out_camera_ray; int32_t* out_mask;
@@ -122,7 +123,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const int lane = threadIdx.x;
     constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
     int tile, sub;
-    if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.ntiles / p.cam.gx, IPT, tile, sub)) return;
+    if (MODE == MODE_COLOR && PPL == 4 && p.order) {
+        // launched over the slots of a tile order (ibgs_forward_args::tile_order_hint): the hinted tile when the hint was found valid, else tile = workgroup
+        uint32_t t = blockIdx.x;
+        if (p.meta[11] == 1u) t = p.order[blockIdx.x];
+        if (t >= (uint32_t)p.ntiles) return;          // (0xFFFFFFFF: an empty slot)
+        tile = (int)t; sub = 0;
+    } else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.ntiles / p.cam.gx, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
     int trow = tile / p.cam.gx, view = 0;
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         for (int q = 0; q < PPL; q++) m = max(m, inside[q] ? lastc[q] : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
-        if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (blockIdx.x == 0) p.meta[10] = (uint32_t)IPT; }
+        if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
     }
     // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
     // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --
@@ -512,7 +519,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
     p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
-    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta; p.walked = im.tile_walked;
+    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta; p.walked = im.tile_walked; p.order = nullptr;
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;
@@ -545,6 +552,10 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
         // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).
         const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096);
         if (small) hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 1, 4>), grid(4), dim3(64), 0, s, p);
+        else if (a.tile_order_hint && p.n_views <= 1) {
+            p.order = a.tile_order_hint;
+            hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), dim3((unsigned)((p.ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES)), dim3(64), 0, s, p);
+        }
         else hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), grid(1), dim3(64), 0, s, p);
     }
     IBGS_HIP(hipGetLastError());

@@ -99,6 +99,24 @@ _last_rendered = {}           # key -> R of the last call, or a list of recent R
 LAST_NUM_RENDERED = 0         # diagnostic: R of the most recent forward
 LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent forward carved its binning arena for
 
+# Launch order hints for the colour forward (include/ibgs_rast.h: ibgs_forward_args.tile_order_hint).  The backward of a colour pass leaves the
+# balanced order it launched its tiles in inside the image arena; a copy is kept per camera and handed to that camera's next forward, whose
+# lists saturate where they did before.  The camera is recognised by its view matrix: the tensor's address when it lives on the device (the
+# reference keeps `world_view_transform` per camera), its 64 bytes otherwise.  A wrong or stale hint costs performance only (the library
+# checks the words and ignores anything that is not a tile order).  ORDER_HINT = False: never pass one.
+ORDER_HINT = True
+ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p)
+_order_hints = {}
+
+
+def _camera_key(viewmatrix, device, W, H):
+    if not torch.is_tensor(viewmatrix):
+        return None
+    if viewmatrix.is_cuda:
+        return (device.index, W, H, "p", viewmatrix.data_ptr())
+    return (device.index, W, H, "b", viewmatrix.detach().float().contiguous().numpy().tobytes())
+
+
 _tex_scratch = {}
 _gacc_scratch = {}   # (device index, stream, P) -> [zeroed P x 16 tensor, dirty flag]; ibgs_backward re-zeroes what it consumed
 
@@ -321,6 +339,10 @@ class _CModule:
                     a.out_mask = out_mask.data_ptr()
                 elif render_depth_only:
                     a.out_depth = out_depth.data_ptr()
+                if ORDER_HINT and not render_geo and not render_depth_only and not debug:
+                    oh = _order_hints.get(_camera_key(viewmatrix, device, W, H))
+                    if oh is not None:
+                        a.tile_order_hint = oh.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
                 hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
                 prev = (max(hist) if isinstance(hist, list) else int(hist)) if hist else 0
@@ -457,6 +479,17 @@ class _CModule:
                         _CModule.last_det = det          # tools/pairing_stats.py reads the slab: which (list entry, wave) rows the backward wrote
                     a.det_scratch = det.data_ptr(); a.det_scratch_bytes = det.numel()
                     a.flags |= _lib.FLAG_DETERMINISTIC
+                if ORDER_HINT and not render_geo and not debug:
+                    # the order this backward launches its tiles in (render_bwd.hip) = the hint for this camera's next forward, written straight into
+                    # the camera's buffer.  (Small frames build no order: the buffer keeps what it had, which the forward checks before use.)
+                    ckey = _camera_key(viewmatrix, device, W, H)
+                    if ckey is not None:
+                        oh = _order_hints.get(ckey)
+                        if oh is None:
+                            if len(_order_hints) >= ORDER_HINT_MAX:
+                                _order_hints.clear()
+                            oh = _order_hints[ckey] = torch.full((int(lib.ibgs_tile_order_slots(W, H)),), -1, dtype=torch.int32, device=device)
+                        a.tile_order_out = oh.data_ptr()
                 rc = lib.ibgs_backward(ctypes.byref(a))
                 if rc < 0:
                     raise RuntimeError("ibgs_backward failed (%d): %s" % (rc, _lib.last_error()))

@@ -169,6 +169,14 @@ typedef struct ibgs_forward_args {
     int32_t n_views;
     float view_tanfovx[8];
     float view_tanfovy[8];
+    /* Launch order hint for the colour blend kernel (optional, may be NULL; device pointer to ibgs_tile_order_slots(W, H) words).
+     * ibgs_backward of a colour pass leaves the order in which it launched its tiles -- balanced over the SIMDs by how far the forward
+     * walked every tile's list -- at img + ibgs_img_offset(W, H, "tile_order") and in ibgs_backward_args.tile_order_out.  Handed to a later ibgs_forward of the SAME
+     * camera (whose lists saturate where they did before), lets the forward launch balanced too; the forward cannot know its own work
+     * in advance.  Performance only: the words are checked on the device (every tile exactly once, 0xFFFFFFFF = empty slot) and anything
+     * else -- a stale buffer, another resolution, garbage -- is ignored.  Used by the variant with one wave per tile (large frames),
+     * neither by render_geo nor by render_depth_only. */
+    const uint32_t* tile_order_hint;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {
@@ -238,6 +246,9 @@ typedef struct ibgs_backward_args {
     /* the forward's buffer_length (0 = not stated).  When stated, geo_table only needs ibgs_required_geo_table_for(W, H, buffer_length)
      * bytes and det_scratch ibgs_required_deterministic_for(R, P, W, H, render_geo, flags) */
     int32_t buffer_length;
+    /* optional (may be NULL): ibgs_tile_order_slots(W, H) words that receive the order in which a colour backward launched its tiles, i.e.
+     * what ibgs_forward_args.tile_order_hint of the same camera's next forward wants (the same words also land in the image arena) */
+    uint32_t* tile_order_out;
 } ibgs_backward_args;
 
 size_t ibgs_required_deterministic(int64_t R, int32_t P);          /* any frame, any flags: four rows per list entry */
@@ -250,6 +261,8 @@ size_t ibgs_required_img(int32_t W, int32_t H);
 size_t ibgs_required_binning(int64_t R, int32_t W, int32_t H);
 size_t ibgs_required_tex(int32_t n_src, int32_t W, int32_t H);
 
+/* words of a tile order (the tiles of the frame rounded up to a multiple of 1024) */
+size_t ibgs_tile_order_slots(int32_t W, int32_t H);
 int64_t ibgs_forward(const ibgs_forward_args* args);
 /* diagnostics of the calling thread's last ibgs_forward: out[0] = R, out[1] = coarse binning entries (-1 unless rendered_hint was used),
  * out[2] = 1 when the hint was too small and binning + render ran a second time with the exact size */

@@ -8,6 +8,7 @@ import torch
 
 from ibgs_amd import _lib, rasterizer
 from tests import hipref
+from tests.metrics import rel_l2
 from tests.scenes import scene
 
 pytestmark = pytest.mark.gpu
@@ -87,3 +88,53 @@ def test_quadrant_waves_record_per_wave():
     pad = np.zeros((gy * 16, gx * 16), np.uint32); pad[:H, :W] = nc
     q = pad.reshape(gy, 2, 8, gx, 2, 8).max(axis=(2, 5))          # [ty, qy, tx, qx]
     assert np.array_equal(walked, q.transpose(0, 2, 1, 3).reshape(nt, 4))          # wave of the tile = 2 * qy + qx
+
+
+def _step(inp, lv_from=None):
+    outs, lv, _ = hipref.run_forward(inp)
+    img = img_arena(outs)
+    color = outs["color"].detach().clone()
+    (outs["color"] * torch.ones(3, int(inp["H"]), int(inp["W"]), device="cuda")).sum().backward()
+    torch.cuda.synchronize()
+    return color, img, lv
+
+
+def test_forward_order_hint_changes_nothing_and_bad_hints_are_ignored(monkeypatch):
+    """The backward's launch order comes back as a hint to the same camera's next forward (rasterizer._order_hints): the image, the
+    per-pixel state and the gradients are those of a forward without it, bit for bit; a hint that is not a tile order (a duplicated
+    tile, a tile out of range) is recognised on the device (meta[11] = 0) and ignored."""
+    old = rasterizer.WAVE_SHAPE
+    rasterizer.WAVE_SHAPE = "tile"
+    rasterizer._order_hints.clear()
+    try:
+        W, H = 1920, 1088
+        inp = scene(P=20000, W=W, H=H, deg=1, seed=21, opacity="trained")
+        # one persistent device tensor for the view matrix, as the reference keeps per camera: that is what the cache keys on
+        inp = dict(inp); vm = torch.as_tensor(np.ascontiguousarray(inp["viewmatrix"]), dtype=torch.float32, device="cuda")
+        monkeypatch.setattr(hipref, "settings_from", (lambda f: (lambda i, dev, debug: _with_vm(f(i, dev, debug), vm)))(hipref.settings_from))
+        c0, img0, lv0 = _step(inp)
+        assert order_state(inp, img0)[2][11] == 0 and len(rasterizer._order_hints) == 1          # first frame: no hint yet; the backward left one
+        c1, img1, lv1 = _step(inp)
+        st1 = order_state(inp, img1)
+        assert st1[2][11] == 1, "the second forward of the camera runs under the first backward's order"
+        assert torch.equal(c0, c1)
+        assert np.array_equal(order_state(inp, img0)[5], st1[5])          # n_contrib
+        for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+            assert rel_l2(lv1[k].grad.cpu().numpy(), lv0[k].grad.cpu().numpy()) < 1e-5, k          # (the atomics land in another order on every launch)
+        hint = next(iter(rasterizer._order_hints.values())).view(torch.int32)
+        good = hint.clone()
+        for breakage in ("duplicate", "range"):
+            hint.copy_(good)
+            idx = int((good != -1).nonzero()[5])
+            hint[idx] = good[(good != -1).nonzero()[6]] if breakage == "duplicate" else 10 ** 6
+            outs, lv, _ = hipref.run_forward(inp)
+            torch.cuda.synchronize()
+            assert order_state(inp, img_arena(outs))[2][11] == 0, breakage
+            assert torch.equal(outs["color"].detach(), c0), breakage
+    finally:
+        rasterizer.WAVE_SHAPE = old
+        rasterizer._order_hints.clear()
+
+
+def _with_vm(settings, vm):
+    return settings._replace(viewmatrix=vm)
