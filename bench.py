@@ -548,6 +548,17 @@ def main():
         fence(1)
         extras["ms_per_step_with_torch_l1"] = (time.perf_counter() - t0) / a.steps * 1e3
         Workload.torch_l1 = False
+        # the timed loop renders ONE camera again and again, so the forward's launch order hint (the previous backward's balanced order for this
+        # camera, rasterizer.ORDER_HINT) is always fresh; a trainer revisits a camera only every few hundred steps.  The same step without it:
+        _r.ORDER_HINT = False
+        for _ in range(3):
+            wl.local_step()
+        fence(1); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            wl.local_step()
+        fence(1)
+        extras["ms_per_step_without_forward_order_hint"] = (time.perf_counter() - t0) / a.steps * 1e3
+        _r.ORDER_HINT = True
         # (d) fraction of HBM peak on the bytes THIS design moves (its sort is P-sized; SURVEY's model charges the reference's R-sized one)
         wl.local_step(); torch.cuda.synchronize()
         R_, C_, _m = _lib.last_forward_stats()
