@@ -759,7 +759,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         static const int geo_balanced = getenv("IBGS_BWD_GEO_BALANCED") ? atoi(getenv("IBGS_BWD_GEO_BALANCED")) : 1;
         if (big && geo_balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out);
             p.order = im.tile_order;
             hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
         } else

@@ -123,12 +123,13 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
     const int lane = threadIdx.x;
     constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
     int tile, sub;
-    if (MODE == MODE_COLOR && PPL == 4 && p.order) {
-        // launched over the slots of a tile order (ibgs_forward_args::tile_order_hint): the hinted tile when the hint was found valid, else tile = workgroup
-        uint32_t t = blockIdx.x;
-        if (p.meta[11] == 1u) t = p.order[blockIdx.x];
+    if (((MODE == MODE_COLOR && PPL == 4) || (MODE == MODE_GEO && PPL == 2)) && p.order) {
+        // launched over the slots of a tile order (ibgs_forward_args::tile_order_hint), IPT consecutive workgroups per slot: the hinted tile when the
+        // hint was found valid, else tile = slot
+        uint32_t t = blockIdx.x / IPT;
+        if (p.meta[11] == 1u) t = p.order[t];
         if (t >= (uint32_t)p.ntiles) return;          // (0xFFFFFFFF: an empty slot)
-        tile = (int)t; sub = 0;
+        tile = (int)t; sub = (int)(blockIdx.x % IPT);
     } else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.ntiles / p.cam.gx, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
@@ -544,7 +545,11 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     } else if (a.render_geo) {
         // geo: half tiles (two quadrants per lane) on large frames, single quadrants on small ones; IBGS_FLAG_*_WAVES force either
         const bool half = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
-        if (half && a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), grid(2), dim3(64), 0, s, p);
+        if (half && a.buffer_length <= 4 && a.tile_order_hint) {
+            p.order = a.tile_order_hint;
+            hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), dim3(2u * (unsigned)((p.ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES)), dim3(64), 0, s, p);
+        }
+        else if (half && a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), grid(2), dim3(64), 0, s, p);
         else if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), grid(4), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), grid(4), dim3(64), 0, s, p);
     } else {

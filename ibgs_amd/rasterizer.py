@@ -105,16 +105,21 @@ LAST_BINNING_CAPACITY = 0     # diagnostic: the size (in pairs) the most recent 
 # reference keeps `world_view_transform` per camera), its 64 bytes otherwise.  A wrong or stale hint costs performance only (the library
 # checks the words and ignores anything that is not a tile order).  ORDER_HINT = False: never pass one.
 ORDER_HINT = True
+# ... for geo passes as well: their forward runs two waves per tile behind a queue and would take the heaviest tile first.  Off by default: that
+# forward lives on the 8 x 8 block map's L2 locality (source texels), and giving it up costs more than the balance brings on even scenes
+# (C3-geo forward 0.668 -> 0.716 ms, trained 0.375 -> 0.398 ms; half of the Gaussians in one blob: 0.751 -> 0.677 ms)
+ORDER_HINT_GEO = False
 ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p)
 _order_hints = {}
 
 
-def _camera_key(viewmatrix, device, W, H):
+def _camera_key(viewmatrix, device, W, H, geo):
+    """(a colour pass and a geo pass of one camera keep separate orders: their kernels hold different numbers of waves per SIMD)"""
     if not torch.is_tensor(viewmatrix):
         return None
     if viewmatrix.is_cuda:
-        return (device.index, W, H, "p", viewmatrix.data_ptr())
-    return (device.index, W, H, "b", viewmatrix.detach().float().contiguous().numpy().tobytes())
+        return (device.index, W, H, bool(geo), "p", viewmatrix.data_ptr())
+    return (device.index, W, H, bool(geo), "b", viewmatrix.detach().float().contiguous().numpy().tobytes())
 
 
 _tex_scratch = {}
@@ -339,8 +344,8 @@ class _CModule:
                     a.out_mask = out_mask.data_ptr()
                 elif render_depth_only:
                     a.out_depth = out_depth.data_ptr()
-                if ORDER_HINT and not render_geo and not render_depth_only and not debug:
-                    oh = _order_hints.get(_camera_key(viewmatrix, device, W, H))
+                if ORDER_HINT and (ORDER_HINT_GEO or not render_geo) and not render_depth_only and not debug:
+                    oh = _order_hints.get(_camera_key(viewmatrix, device, W, H, render_geo))
                     if oh is not None:
                         a.tile_order_hint = oh.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
@@ -479,10 +484,10 @@ class _CModule:
                         _CModule.last_det = det          # tools/pairing_stats.py reads the slab: which (list entry, wave) rows the backward wrote
                     a.det_scratch = det.data_ptr(); a.det_scratch_bytes = det.numel()
                     a.flags |= _lib.FLAG_DETERMINISTIC
-                if ORDER_HINT and not render_geo and not debug:
+                if ORDER_HINT and (ORDER_HINT_GEO or not render_geo) and not debug:
                     # the order this backward launches its tiles in (render_bwd.hip) = the hint for this camera's next forward, written straight into
                     # the camera's buffer.  (Small frames build no order: the buffer keeps what it had, which the forward checks before use.)
-                    ckey = _camera_key(viewmatrix, device, W, H)
+                    ckey = _camera_key(viewmatrix, device, W, H, render_geo)
                     if ckey is not None:
                         oh = _order_hints.get(ckey)
                         if oh is None:

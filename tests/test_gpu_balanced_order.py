@@ -138,3 +138,32 @@ def test_forward_order_hint_changes_nothing_and_bad_hints_are_ignored(monkeypatc
 
 def _with_vm(settings, vm):
     return settings._replace(viewmatrix=vm)
+
+
+def test_geo_forward_under_an_order_hint(monkeypatch):
+    """rasterizer.ORDER_HINT_GEO (off by default): the geo forward launched over the geo backward's order, two workgroups per slot -- every
+    output plane bit-identical to the forward without a hint."""
+    from tests.scenes import add_sources
+    old = (rasterizer.WAVE_SHAPE, rasterizer.ORDER_HINT_GEO)
+    rasterizer.WAVE_SHAPE = "tile"; rasterizer.ORDER_HINT_GEO = True
+    rasterizer._order_hints.clear()
+    try:
+        W, H = 1920, 1088
+        inp = add_sources(scene(P=15000, W=W, H=H, deg=1, seed=23, opacity="trained", planes=True), n_src=2, seed=3)
+        vm = torch.as_tensor(np.ascontiguousarray(inp["viewmatrix"]), dtype=torch.float32, device="cuda")
+        monkeypatch.setattr(hipref, "settings_from", (lambda f: (lambda i, dev, debug: _with_vm(f(i, dev, debug), vm)))(hipref.settings_from))
+        res = []
+        for it in range(2):
+            outs, lv, _ = hipref.run_forward(inp)
+            img = img_arena(outs)
+            keep = {k: v.detach().clone() for k, v in outs.items() if torch.is_tensor(v)}
+            loss = sum((v.float() * 0.5).sum() for k, v in outs.items() if torch.is_tensor(v) and v.requires_grad)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((keep, order_state(inp, img)[2][11]))
+        assert res[0][1] == 0 and res[1][1] == 1
+        for k in res[0][0]:
+            assert torch.equal(res[0][0][k], res[1][0][k]), k
+    finally:
+        rasterizer.WAVE_SHAPE, rasterizer.ORDER_HINT_GEO = old
+        rasterizer._order_hints.clear()
