@@ -222,16 +222,55 @@ __global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const ui
     for (int c = c0; c < c1; c++) { cell_chunk0[c] = run; run += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK; }
 }
 
+// The caller's launch order hint for the blend kernel (ibgs_forward_args::tile_order_hint) is used only when it holds every tile exactly once
+// -- whatever else the buffer may contain must not be able to change the image.  Checked against a bitmap of the tiles in LDS, one atomic OR per
+// word of the hint, by ONE EXTRA workgroup of the place kernel: beside the placement's thousands of workgroups it costs no time (inside the
+// one-workgroup tile_ranges_kernel, where it was first, it added 8 us to the forward).  meta[11] = 1: valid.
+constexpr int HINT_MAX_TILES = 65536;
+__device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
+{
+    __shared__ uint32_t s_seen[HINT_MAX_TILES / 32];
+    __shared__ uint32_t s_cnt;
+    int ok = 0;
+    if (order_hint && ntiles <= HINT_MAX_TILES) {
+        const int nslots = (ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+        for (int w = threadIdx.x; w < (ntiles + 31) / 32; w += PLACE_THREADS) s_seen[w] = 0u;
+        if (threadIdx.x == 0) s_cnt = 0u;
+        __syncthreads();
+        int bad = 0, mine = 0;
+        constexpr int BATCH = 16;          // loads in flight per thread before the LDS atomics (one by one the 32 round trips of a 1080p order made this workgroup the kernel's straggler)
+        for (int i0 = 0; i0 < nslots; i0 += BATCH * PLACE_THREADS) {
+            uint32_t t[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) { const int i = i0 + k * PLACE_THREADS + (int)threadIdx.x; t[k] = i < nslots ? order_hint[i] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                if (t[k] == 0xFFFFFFFFu) continue;
+                if (t[k] >= (uint32_t)ntiles) { bad = 1; continue; }
+                const uint32_t bit = 1u << (t[k] & 31u);
+                if (atomicOr(&s_seen[t[k] >> 5], bit) & bit) bad = 1;
+                mine++;
+            }
+        }
+        if (mine) atomicAdd(&s_cnt, (uint32_t)mine);
+        const int any_bad = __syncthreads_or(bad);          // (also orders the adds to s_cnt before the read)
+        ok = (!any_bad && s_cnt == (uint32_t)ntiles) ? 1 : 0;
+    }
+    if (threadIdx.x == 0) meta[11] = (uint32_t)ok;
+}
+
 __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi,
                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
-                                                                   uint4* __restrict__ cent)
+                                                                   uint4* __restrict__ cent, int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
 {
+    // the extra workgroup (first slice only) is workgroup 0: dispatched first, it runs beside the placement instead of after it
+    if (meta) { if (blockIdx.x == 0) { check_order_hint(ntiles, order_hint, meta); return; } }
     extern __shared__ unsigned long long s_place[];        // 4 x nc lane words (one table per wave), then nc next-free slots
     const int nc = pg.nc;
     unsigned long long* s_touch = s_place;
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + 4 * nc);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x - (meta ? 1 : 0);
     for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start[pg.c0 + c] + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
     const unsigned long long below = (1ull << lane) - 1ull;
     const int j1 = min((int)min((uint32_t)pg.P, *n_kept), (blk + 1) * pg.G);
@@ -350,41 +389,10 @@ __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint3
 // Per-tile totals -> tile starts (exclusive scan, in place; [ntiles] = R) -> ranges, ONE workgroup: a strip of consecutive tiles per
 // thread, the 1024 strip sums scanned through LDS.  Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after
 // its memset).
-constexpr int HINT_MAX_TILES = 65536;          // tile order hints are checked against a bitmap in LDS (8 KB)
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
-                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
-                                                           const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
 {
     __shared__ uint32_t s_wave[16];
-    // The caller's launch order hint for the blend kernel (ibgs_forward_args::tile_order_hint): used only when it holds every tile exactly
-    // once -- whatever else the buffer may contain must not be able to change the image.  This workgroup has the time (it is one wave
-    // deep in memory latency anyway): a bitmap of the tiles in LDS, one atomic OR per word of the hint.
-    if (meta) {
-        __shared__ uint32_t s_seen[HINT_MAX_TILES / 32];
-        int ok = 0;
-        if (order_hint && ntiles <= HINT_MAX_TILES) {
-            const int nslots = (ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            for (int w = threadIdx.x; w < (ntiles + 31) / 32; w += 1024) s_seen[w] = 0u;
-            __syncthreads();
-            int bad = 0, mine = 0;
-            for (int i = threadIdx.x; i < nslots; i += 1024) {
-                const uint32_t t = order_hint[i];
-                if (t == 0xFFFFFFFFu) continue;
-                if (t >= (uint32_t)ntiles) { bad = 1; continue; }
-                const uint32_t bit = 1u << (t & 31u);
-                if (atomicOr(&s_seen[t >> 5], bit) & bit) bad = 1;
-                mine++;
-            }
-            const int any_bad = __syncthreads_or(bad);
-            __shared__ uint32_t s_cnt;
-            if (threadIdx.x == 0) s_cnt = 0u;
-            __syncthreads();
-            if (mine) atomicAdd(&s_cnt, (uint32_t)mine);
-            __syncthreads();
-            ok = (!any_bad && s_cnt == (uint32_t)ntiles) ? 1 : 0;
-        }
-        if (threadIdx.x == 0) meta[11] = (uint32_t)ok;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (ntiles + 1023) / 1024;
     const int t0 = min(ntiles, tid * per), t1 = min(ntiles, t0 + per);
@@ -536,8 +544,9 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     IBGS_HIP(hipGetLastError());
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
-        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
-                           b.cnt, b.cell_start, b.cent);
+        const bool check = meta != nullptr && pg.c0 == 0;
+        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
+                           b.cnt, b.cell_start, b.cent, ntiles, order_hint, check ? meta : nullptr);
         IBGS_HIP(hipGetLastError());
     }
     const unsigned nchunks_max = (unsigned)(ccap / XCHUNK + (size_t)ncells + 1);
@@ -546,7 +555,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
-                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), order_hint, meta);
+                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll));
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -39,7 +39,7 @@ struct FwdParams {
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
-    const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by tile_ranges_kernel: meta[11]; nullptr: the tile map
+    const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by an extra workgroup of cell_place_kernel: meta[11]; nullptr: the tile map
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
     float* out_min_depth_diff; float* out_camera_ray; int32_t* out_mask;
