@@ -61,9 +61,10 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.fp_sorted = c.take<uint4>(P);
     g.clamped = c.take<uint8_t>(P);
     g.alive64 = c.take<uint64_t>((P + 63) / 64);
+    g.tile_partial = c.take<uint32_t>((P + 63) / 64 + IBGS_MAX_VIEWS + 1);
     g.sort_key[0] = c.take<uint32_t>(P); g.sort_key[1] = c.take<uint32_t>(P);
     g.sort_val[0] = c.take<uint32_t>(P); g.sort_val[1] = c.take<uint32_t>(P);
-    g.offsets = c.take<uint32_t>(P + 4);
+    g.offsets = c.take<uint32_t>(P + 5);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
@@ -226,7 +227,11 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
 
 // Pinned host words + event for the R read-back, one per calling thread AND device (created on first use, never freed): an event
 // belongs to the device that was current when it was created, so a thread that drives several GPUs needs one per device.
-struct RSlot { uint32_t* host; hipEvent_t ev; };
+struct RSlot {
+    uint32_t* host; hipEvent_t ev;
+    uint32_t* part; size_t part_cap;          // deferred sizing: the preprocess kernel's per-wave tile sums + the depth sort's error flag (pinned, grown on demand)
+    uint32_t* stats; hipEvent_t ev_stats; bool stats_pending;          // R as the binning counted it, -, C: diagnostics, read when somebody asks (ibgs_last_forward_stats)
+};
 static RSlot* rslot()
 {
     constexpr int MAX_DEV = 32;
@@ -238,15 +243,36 @@ static RSlot* rslot()
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
         if (hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
+        if (hipEventCreateWithFlags(&slot.ev_stats, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
         slot.host = static_cast<uint32_t*>(p);
+        slot.stats = slot.host + 8;
     }
     return &slot;
+}
+static int rslot_reserve_part(RSlot* rs, size_t words)
+{
+    if (rs->part_cap >= words) return 0;
+    if (rs->part) (void)hipHostFree(rs->part);
+    rs->part = nullptr; rs->part_cap = 0;
+    void* p = nullptr;
+    const size_t cap = words + words / 4 + 1024;
+    if (hipHostMalloc(&p, cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the tile sums failed"); return -IBGS_ERR_HIP; }
+    rs->part = static_cast<uint32_t*>(p); rs->part_cap = cap;
+    return 0;
 }
 
 // what the last ibgs_forward of this thread saw (bench / tests): R, coarse binning entries C (deferred sizing only, else -1), whether the
 // rendered_hint was too small and binning + render ran twice
 static thread_local int64_t g_last_stats[3] = {0, -1, 0};
-void ibgs_last_forward_stats(int64_t* out) { out[0] = g_last_stats[0]; out[1] = g_last_stats[1]; out[2] = g_last_stats[2]; }
+static thread_local RSlot* g_stats_slot = nullptr;
+void ibgs_last_forward_stats(int64_t* out)
+{
+    if (g_stats_slot && g_stats_slot->stats_pending) {          // the coarse count travelled back on its own; nobody waited for it
+        if (hipEventSynchronize(g_stats_slot->ev_stats) == hipSuccess) g_last_stats[1] = (int64_t)g_stats_slot->stats[2];
+        g_stats_slot->stats_pending = false;
+    }
+    out[0] = g_last_stats[0]; out[1] = g_last_stats[1]; out[2] = g_last_stats[2];
+}
 
 int64_t ibgs_forward(const ibgs_forward_args* ap)
 {
@@ -309,23 +335,33 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
 
     { StageTimer t(s, IBGS_STAGE_PREPROCESS); if ((rc = launch_preprocess(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess"))) return rc;
+    const bool deferred = a.rendered_hint > 0 && !debug;
+    const size_t nwaves = (size_t)nv * (((size_t)a.P + 63) / 64);          // words of per-wave tile sums the preprocess kernel wrote; the depth sort's error flag follows them
     { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
-      // (the preprocess kernel has zeroed the sort's scratch, the look-back error flag [Pn + 1] that travels back with R, and [Pn + 3])
+      // (the preprocess kernel has zeroed the sort's scratch, its look-back error flag -- [Pn + 1], or the word behind the tile sums when R is
+      // sized from a hint: that one travels back together with them --, and [Pn + 3], [Pn + 4])
       // Gaussians without tiles (key 0xFFFFFFFF) are not carried through the sort; [Pn + 3] = how many others there are
-      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.offsets + Pn + 1, g.offsets + Pn + 3, true))) return rc; }
+      if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, deferred ? g.tile_partial + nwaves : g.offsets + Pn + 1,
+                                 g.offsets + Pn + 3, true, g.offsets + Pn + 4))) return rc; }
     if ((rc = stage_check(s, debug, "depth sort"))) return rc;
     // R = total number of (Gaussian, tile) pairs.  The binning arena is sized from it, and it is only known on the device.
     //  * no hint (first call of a shape, or debug): the tiles-touched counts are scanned, R travels to the host through a pinned
     //    word + event and the host waits for it here, as the reference does (rasterizer_impl.cu:430);
-    //  * with args->rendered_hint the arena is carved for the hint at once, every remaining stage is enqueued, and R falls out of
-    //    the binning itself (the scan over the per-tile totals) -- the host reads it, the coarse slot count and the depth sort's
-    //    error flag only after everything is queued: the GPU never idles on the round trip and one scan less runs.
-    const bool deferred = a.rendered_hint > 0 && !debug;
+    //  * with args->rendered_hint the arena is carved for the hint at once and every remaining stage is enqueued; R = the sum of the tiles touched,
+    //    which the preprocess kernel left as one partial sum per wave: those words and the depth sort's error flag are copied to the host right
+    //    HERE, behind the sort, and the host adds them up only after everything is queued -- the GPU never idles on the round trip, no scan runs,
+    //    and the host is released while binning, list scatter and render are still ahead of the GPU (when it waited for the binning's own count,
+    //    a trained-opacity frame left it 0.13 ms to queue the loss and the backward, which takes it 0.16 ms: the GPU idled).
     { StageTimer t(s, IBGS_STAGE_SCAN);
       // (the total does not depend on the order: the per-Gaussian counts are scanned as they lie)
       if (!deferred && (rc = exclusive_scan_u32(s, g.tiles, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
+    if (deferred) {
+        if ((rc = rslot_reserve_part(rs, nwaves + 1))) return rc;
+        IBGS_HIP(hipMemcpyAsync(rs->part, g.tile_partial, (nwaves + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        IBGS_HIP(hipEventRecord(rs->ev, s));
+    }
     auto exact_R = [&](int64_t* R_out) -> int {       // synchronous path: R from the scanned tile counts
         IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
         IBGS_HIP(hipEventRecord(rs->ev, s));
@@ -345,10 +381,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
         { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta))) return rc; }
         if (read_back) {
-            // R as the binning counted it, the depth sort's error flag, the coarse slots in use: adjacent words, one copy, queued
-            // HERE so that the host is served while the list scatter and the render still run
-            IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            IBGS_HIP(hipEventRecord(rs->ev, s));
+            // diagnostics nobody waits for (ibgs_last_forward_stats): R as the binning counted it, -, the coarse slots in use
+            IBGS_HIP(hipMemcpyAsync(rs->stats, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            IBGS_HIP(hipEventRecord(rs->ev_stats, s));
         }
         { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b))) return rc; }
         if ((rc = stage_check(s, debug, "binning"))) return rc;
@@ -363,24 +398,21 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     };
     if ((rc = tail(cap, deferred))) return rc;
     g_last_stats[1] = -1; g_last_stats[2] = 0;
+    g_stats_slot = rs; rs->stats_pending = false;
     if (deferred) {
         IBGS_HIP(hipEventSynchronize(rs->ev));
-        if (rs->host[1]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
-        R = (int64_t)rs->host[0];
-        const bool coarse_overflow = (int64_t)rs->host[2] > cap;      // Gaussians were dropped: the binning's own R is incomplete too
-        g_last_stats[1] = (int64_t)rs->host[2];
-        if (R > cap || coarse_overflow) {
+        if (rs->part[nwaves]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
+        uint64_t sum = 0;
+        for (size_t w = 0; w < nwaves; w++) sum += rs->part[w];
+        R = (int64_t)sum;          // exact, whatever the binning could fit (a coarse entry stands for at least one pair: C <= R, so R <= cap means nothing was dropped)
+        if (R > cap) {
             g_last_stats[2] = 1;
             // The hint was too small: the lists above are truncated.  Drain the stream (the first arena may be released by the
             // second callback) and redo binning + render with the exact size (every output element is rewritten).  Same results
             // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
-            if (coarse_overflow) {
-                if ((rc = exclusive_scan_u32(s, g.tiles, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc;
-                if ((rc = exact_R(&R))) return rc;
-            }
             if ((rc = tail(R, false))) return rc;
-        }
+        } else rs->stats_pending = true;
     }
     g_last_stats[0] = R;
     return R;

@@ -141,12 +141,14 @@ __device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& 
         }
 }
 
-__global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
+__global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order0, const uint32_t* __restrict__ order1 /* where the depth order lies: n_kept[1] */,
+                                                                   const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi,
                                                                    uint4* __restrict__ fp_sorted /* the footprints in depth order, for the place kernel */,
                                                                    uint32_t* __restrict__ cnt /* ncells x nblk */)
 {
     extern __shared__ uint32_t s_cnt[];
+    const uint32_t* __restrict__ order = n_kept[1] ? order1 : order0;          // (the depth sort's last pass may have left the result in its input buffer, scan_sort.hip)
     const int tid = threadIdx.x, blk = blockIdx.x;
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) s_cnt[c] = 0u;
     __syncthreads();
@@ -259,7 +261,7 @@ __device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __r
     if (threadIdx.x == 0) meta[11] = (uint32_t)ok;
 }
 
-__global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_kept,
+__global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order0, const uint32_t* __restrict__ order1, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi,
                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
                                                                    uint4* __restrict__ cent, int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
@@ -270,6 +272,7 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
     const int nc = pg.nc;
     unsigned long long* s_touch = s_place;
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + 4 * nc);
+    const uint32_t* __restrict__ order = n_kept[1] ? order1 : order0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x - (meta ? 1 : 0);
     for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start[pg.c0 + c] + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -535,7 +538,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     const uint32_t* order = g.sort_val[0];
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
-        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.offsets + P + 3, g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_val[1], g.offsets + P + 3, g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
         IBGS_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total);
@@ -545,7 +548,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
         const bool check = meta != nullptr && pg.c0 == 0;
-        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
+        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.sort_val[1], g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
                            b.cnt, b.cell_start, b.cent, ntiles, order_hint, check ? meta : nullptr);
         IBGS_HIP(hipGetLastError());
     }

@@ -48,10 +48,12 @@ struct GeomState {
     uint4* fp_sorted;      // P   the footprints in depth order (written by the binning's count pass, read by its place pass)
     uint8_t* clamped;      // P   bit ch set when SH colour channel was clamped
     uint64_t* alive64;     // ceil(P / 64)  lane mask per wave of the preprocess kernel: Gaussians that reach a tile list (what sh_color_kernel evaluates)
+    uint32_t* tile_partial; // ceil(P / 64) + IBGS_MAX_VIEWS + 1   tiles touched, summed per wave of the preprocess kernel; the word behind the last wave's is the depth
+                           //      sort's error flag in deferred sizing: ONE copy hands the host R (it adds the words up) and the flag right after the sort
     uint32_t* sort_key[2]; // P   depth keys (ping-pong)
     uint32_t* sort_val[2]; // P   Gaussian ids (ping-pong); sort_val[0] ends up depth ordered
-    uint32_t* offsets;     // P+4: exclusive scan of the tiles touched (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back
-                           //      together; [P+3] = Gaussians with tiles (what the depth sort keeps)
+    uint32_t* offsets;     // P+5: exclusive scan of the tiles touched (synchronous sizing only); [P] = R, [P+1] = depth sort error flag, [P+2] = C: read back
+                           //      together; [P+3] = Gaussians with tiles (what the depth sort keeps); [P+4] = 1 when the depth order lies in sort_val[1]
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
     static GeomState carve(char* base, size_t P, size_t* total);
@@ -282,7 +284,10 @@ int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float*
 size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by radix_sort_pairs on n items
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
-                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false);
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false,
+                     uint32_t* result_alt = nullptr);
+// result_alt: device word (zeroed by the caller).  When given (32-bit keys, single-launch passes), a LAST pass in which every key carries the same digit --
+//          the top byte of depths within [2, 8), say -- moves nothing and sets *result_alt = 1: the result is then in keys[1] / vals[1] (else, as always, in [0])
 size_t radix_zero_elems(size_t n, int nbits);      // leading words of `hist` the sort needs zeroed (see scratch_is_zero)
 // err_dev: device word (zeroed by the caller) that the single-launch look-back passes set to 1 when their bounded spin gives up --
 //          the pass has then scattered with a partial prefix; the caller must read it back and fail the call.  With err_dev == nullptr

@@ -39,6 +39,7 @@ struct PreParams {
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
     uint32_t* zero_a; uint32_t zero_a_n; uint32_t* zero_b; uint32_t zero_b_n;      // words the next stages want zeroed (the depth sort's scratch, its counters)
+    uint32_t* tile_partial; int partial0; int partial_err;      // tiles touched per wave: this launch's first word; the word that follows ALL waves' words (the depth sort's error flag, zeroed here)
 };
 
 __device__ __forceinline__ float ndc_to_pix(float v, int S)
@@ -343,6 +344,13 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
         const uint64_t am = __ballot(valid && alive && ntiles > 0);
         if ((threadIdx.x & 63) == 0) p.alive64[gi >> 6] = am;
     }
+    {   // tiles touched by this wave's Gaussians: the host adds the waves' words up and has R right after the depth sort (api.hip), without a scan
+        uint32_t tsum = valid ? ntiles : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tsum += (uint32_t)__shfl_xor((int)tsum, d, 64);
+        if ((threadIdx.x & 63) == 0) p.tile_partial[p.partial0 + (gi >> 6)] = tsum;
+        if (gi == 0) p.tile_partial[p.partial_err] = 0u;
+    }
     if (!valid) return;
 
     const int o = p.inst0 + i;            // instance slot (= i for a single view)
@@ -497,9 +505,10 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     const int nv = a.n_views > 1 ? a.n_views : 1;
     const int gy = (a.H + TILE - 1) / TILE;
     p.zero_a = g.hist; p.zero_a_n = (uint32_t)radix_zero_elems((size_t)nv * a.P, 32);
-    p.zero_b = g.offsets + (size_t)nv * a.P + 1; p.zero_b_n = 3;
+    p.zero_b = g.offsets + (size_t)nv * a.P + 1; p.zero_b_n = 4;          // error flag, C, kept, "the order lies in sort_val[1]"
     for (int v = 0; v < nv; v++) {       // batched depth passes: one launch per camera, outputs land in that view's slice
         p.inst0 = v * a.P; p.tile_row0 = v * gy;
+        p.tile_partial = g.tile_partial; p.partial0 = v * ((a.P + 63) / 64); p.partial_err = nv * ((a.P + 63) / 64);
         const Cam cam = make_cam(a.viewmatrix + 16 * v, a.projmatrix + 16 * v, a.campos + 3 * v, a.bg,
                                  nv > 1 ? a.view_tanfovx[v] : a.tanfovx, nv > 1 ? a.view_tanfovy[v] : a.tanfovy, a.W, a.H);
         // SH coefficients: geometry first (few registers, every Gaussian), then the colours of the Gaussians that reach a tile

@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
                                                                    uint32_t* __restrict__ status /* nblocks x 256, zeroed */,
                                                                    uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                                    int drop_here /* first pass of a sort that drops the 0xFFFFFFFF keys */,
-                                                                   const uint32_t* __restrict__ n_kept /* items that take part (device) */)
+                                                                   const uint32_t* __restrict__ n_kept /* items that take part (device) */,
+                                                                   uint32_t* __restrict__ stays /* last pass only, or nullptr: a pass that would move nothing may leave its input where it is and say so */)
 {
     __shared__ uint32_t wcnt[OS_WAVES][RS_MAX_BINS];
     __shared__ unsigned long long ptab[OS_WAVES][RS_MAX_BINS];      // match-any slots (wave_rank)
@@ -352,6 +353,7 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
     // comes from the global histogram, so every workgroup takes it alike; a pass that also has to drop keys always runs.
     const int all_one_bin = __syncthreads_or((int)(threadIdx.x < (unsigned)nbins && kept != 0u && ghist[threadIdx.x] == kept));
     if (all_one_bin && (!drop_here || (size_t)kept == n)) {
+        if (stays) { if (bid == 0 && threadIdx.x == 0) *stays = 1u; return; }          // the caller reads the result from this pass's INPUT buffers
 #pragma unroll
         for (int k = 0; k < OS_ITEMS; k++) {
             const size_t idx = base + (size_t)k * OS_THREADS + threadIdx.x;
@@ -473,7 +475,7 @@ static size_t onesweep_elems(size_t n)
 }
 
 static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
-                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero)
+                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt)
 {
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int nbins = 1 << dbits;
@@ -491,7 +493,8 @@ static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t*
     for (int pass = 0; pass < npass; pass++) {
         hipLaunchKernelGGL(onesweep_pass_kernel, dim3(nblocks), dim3(OS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
                            n, pass * dbits, dbits, nbins, ghist + pass * RS_MAX_BINS, status + (size_t)pass * nblocks * RS_MAX_BINS,
-                           tickets + pass, err_dev ? err_dev : tickets + 32, (kept_dev && pass == 0) ? 1 : 0, kept_dev ? kept_dev : tickets + 33);
+                           tickets + pass, err_dev ? err_dev : tickets + 32, (kept_dev && pass == 0) ? 1 : 0, kept_dev ? kept_dev : tickets + 33,
+                           (result_alt && npass == 4 && pass == 3) ? result_alt : (uint32_t*)nullptr);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
@@ -541,7 +544,7 @@ size_t radix_zero_elems(size_t n, int nbits_total)
 }
 
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero)
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -550,7 +553,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
     if (want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
-        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero);
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero, result_alt);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;
