@@ -48,6 +48,11 @@ for which in ("fwd", "bwd"):
     assert rc == 0
     nt = ((c["W"] + 15) // 16) * ((c["H"] + 15) // 16)
     used = buf[(buf[:, 3] != 0)]
+    # the buffer is indexed by workgroup and survives launches: keep the stamps of the LAST launch only (earlier launches of another grid size leave theirs behind)
+    last = used[:, 3].astype(np.int64).max()
+    keep = used[:, 2].astype(np.int64) >= last - 200000          # started within 2 ms of the last end (100 MHz ticks)
+    buf = np.where(((buf[:, 3] != 0) & (buf[:, 2].astype(np.int64) >= last - 200000))[:, None], buf, 0)
+    used = used[keep]
     hw, xcc, t0, t1 = used[:, 0], used[:, 1] & 0xF, used[:, 2].astype(np.int64), used[:, 3].astype(np.int64)
     # HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe [7:6], cu_id [11:8], sh_id [12], se_id [15:13]
     simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
