@@ -79,6 +79,32 @@ for opacity in args:
         return load.max() / (work.sum() / 1024)
     print("   measured placement model (workgroup %% 1024): tile order %.3f (mean / max = %.3f); snake by true work %.3f; snake by list length %.3f; snake by walked length %.3f"
           % (classes(np.arange(nt)), 1.0 / classes(np.arange(nt)), snake_classes(work), snake_classes(counts.astype(np.float64)), snake_classes(top)))
+    # ... and with the ISSUE RATE in the model: the waves of a SIMD share its VALU (processor sharing); two or more waves together issue an instruction
+    # every 2.65 cycles, a single wave only every 5.1 (profiles/r02_probe_xlane.txt) -- so the stretch the heaviest tile of a SIMD runs ALONE costs double
+    def finish(weights):          # weights of the tiles of one SIMD -> time (in units of work at the shared rate)
+        w = np.sort(np.asarray(weights, np.float64))
+        if len(w) == 0: return 0.0
+        if len(w) == 1: return w[0] * 5.1 / 2.65
+        return w[:-1].sum() + w[-2] + (w[-1] - w[-2]) * 5.1 / 2.65          # everything is shared until the second heaviest is done, the rest runs alone
+    def span(assign):          # assign[c] = list of tiles of class c
+        return max(finish(work[a]) for a in assign)
+    r = np.argsort(-top, kind="stable")
+    def arrange(dirs, pairs=False):
+        cls = [[] for _ in range(1024)]
+        if pairs:          # the two heaviest of a class adjacent in rank: ranks 2k, 2k + 1 -> class k; the remaining strata by `dirs`
+            for k in range(1024):
+                cls[k] += [r[2 * k], r[2 * k + 1]] if 2 * k + 1 < len(r) else []
+            rest = r[2048:]; base = 0
+        else:
+            rest = r; base = 0
+        for i, t in enumerate(rest):
+            k, c = divmod(i, 1024)
+            cls[c if dirs[k % len(dirs)] == "F" else 1023 - c].append(t)
+        return cls
+    ideal = work.sum() / 1024
+    tile_order_cls = [list(range(c, nt, 1024)) for c in range(1024)]
+    print("   with the single-wave issue rate in the model, span / (total work / 1024): tile order %.3f; snake %.3f; adjacent pairs + snake of the rest %.3f; pairs + rest 'RFRFRF' %.3f; pairs + 'RRFFRF' %.3f"
+          % (span(tile_order_cls) / ideal, span(arrange("FR")) / ideal, span(arrange("FR", True)) / ideal, span(arrange("RF", True)) / ideal, span(arrange("RRFFRF", True)) / ideal))
     print("C3 opacity=%s: tiles %d, walked entries %.2f M, processed %.2f M; work per tile: mean %.0f, cv %.2f, max %.0f (%.1f x mean)"
           % (opacity, nt, top.sum() / 1e6, proc.sum() / 1e6, work.mean(), work.std() / work.mean(), work.max(), work.max() / work.mean()))
     print("   per-SIMD load, max / mean: round-robin placement %.2f, random placement %.2f, work queue in launch order %.2f, work queue longest first %.2f"
