@@ -35,7 +35,7 @@ def order_state(inp, img_t):
     return nt, nslots, view("meta", 32), view("tile_walked", nt), view("tile_order", nslots), view("n_contrib", W * H).reshape(H, W), (gx, gy)
 
 
-@pytest.mark.parametrize("W,H,P", [(1920, 1088, 30000), (208, 144, 2000), (2560, 1456, 30000)])
+@pytest.mark.parametrize("W,H,P", [(1920, 1088, 30000), (208, 144, 2000), (2560, 1456, 30000), (3840, 2160, 20000)])          # the last: more than 16 K tiles (the order kernel reads its keys twice)
 def test_every_tile_once_and_walked_is_the_largest_n_contrib(W, H, P):
     old = rasterizer.WAVE_SHAPE
     rasterizer.WAVE_SHAPE = "tile"
@@ -99,7 +99,8 @@ def _step(inp, lv_from=None):
     return color, img, lv
 
 
-def test_forward_order_hint_changes_nothing_and_bad_hints_are_ignored(monkeypatch):
+@pytest.mark.parametrize("W,H", [(1920, 1088), (3840, 2160)])          # all tiles resident (snake order) / four times the slots (heaviest first)
+def test_forward_order_hint_changes_nothing_and_bad_hints_are_ignored(monkeypatch, W, H):
     """The backward's launch order comes back as a hint to the same camera's next forward (rasterizer._order_hints): the image, the
     per-pixel state and the gradients are those of a forward without it, bit for bit; a hint that is not a tile order (a duplicated
     tile, a tile out of range) is recognised on the device (meta[11] = 0) and ignored."""
@@ -107,7 +108,6 @@ def test_forward_order_hint_changes_nothing_and_bad_hints_are_ignored(monkeypatc
     rasterizer.WAVE_SHAPE = "tile"
     rasterizer._order_hints.clear()
     try:
-        W, H = 1920, 1088
         inp = scene(P=20000, W=W, H=H, deg=1, seed=21, opacity="trained")
         # one persistent device tensor for the view matrix, as the reference keeps per camera: that is what the cache keys on
         inp = dict(inp); vm = torch.as_tensor(np.ascontiguousarray(inp["viewmatrix"]), dtype=torch.float32, device="cuda")
