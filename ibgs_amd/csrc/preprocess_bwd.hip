@@ -442,7 +442,8 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) sh_grad_from_views_kernel(i
     } else if (i < P) {
         float* gsh = dL_dsh + (size_t)i * M * 3;
         const int nact = min(M, 16);
-        for (int k = 0; k < nact; k++) { gsh[3 * k] = acc[3 * k]; gsh[3 * k + 1] = acc[3 * k + 1]; gsh[3 * k + 2] = acc[3 * k + 2]; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (k < nact) { gsh[3 * k] = acc[3 * k]; gsh[3 * k + 1] = acc[3 * k + 1]; gsh[3 * k + 2] = acc[3 * k + 2]; }          // (static indices: a run-time one sends acc[] to scratch memory)
         for (int k = 3 * nact; k < 3 * M; k++) gsh[k] = 0.f;
     }
 }
