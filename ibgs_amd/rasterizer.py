@@ -113,13 +113,14 @@ ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p)
 _order_hints = {}
 
 
-def _camera_key(viewmatrix, device, W, H, geo):
-    """(a colour pass and a geo pass of one camera keep separate orders: their kernels hold different numbers of waves per SIMD)"""
+def _camera_key(viewmatrix, device, W, H, geo, stream):
+    """(a colour pass and a geo pass of one camera keep separate orders: their kernels hold different numbers of waves per SIMD; and one buffer
+    per stream, like the other cached scratch: the backward that writes it and the forward that reads it are then ordered by the stream)"""
     if not torch.is_tensor(viewmatrix):
         return None
     if viewmatrix.is_cuda:
-        return (device.index, W, H, bool(geo), "p", viewmatrix.data_ptr())
-    return (device.index, W, H, bool(geo), "b", viewmatrix.detach().float().contiguous().numpy().tobytes())
+        return (device.index, stream, W, H, bool(geo), "p", viewmatrix.data_ptr())
+    return (device.index, stream, W, H, bool(geo), "b", viewmatrix.detach().float().contiguous().numpy().tobytes())
 
 
 _tex_scratch = {}
@@ -345,7 +346,7 @@ class _CModule:
                 elif render_depth_only:
                     a.out_depth = out_depth.data_ptr()
                 if ORDER_HINT and (ORDER_HINT_GEO or not render_geo) and not render_depth_only and not debug:
-                    oh = _order_hints.get(_camera_key(viewmatrix, device, W, H, render_geo))
+                    oh = _order_hints.get(_camera_key(viewmatrix, device, W, H, render_geo, stream))
                     if oh is not None:
                         a.tile_order_hint = oh.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
@@ -487,7 +488,7 @@ class _CModule:
                 if ORDER_HINT and (ORDER_HINT_GEO or not render_geo) and not debug:
                     # the order this backward launches its tiles in (render_bwd.hip) = the hint for this camera's next forward, written straight into
                     # the camera's buffer.  (Small frames build no order: the buffer keeps what it had, which the forward checks before use.)
-                    ckey = _camera_key(viewmatrix, device, W, H, render_geo)
+                    ckey = _camera_key(viewmatrix, device, W, H, render_geo, stream)
                     if ckey is not None:
                         oh = _order_hints.get(ckey)
                         if oh is None:

@@ -9,10 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ibgs_amd import rasterizer, synthetic as syn
 from tests import hipref
 
-args = sys.argv[1:] or ["init", "trained"]
+cluster = float(sys.argv[sys.argv.index("--cluster") + 1]) if "--cluster" in sys.argv else 0.0
+args = [a for a in sys.argv[1:] if a in ("init", "trained")] or ["init", "trained"]
 for opacity in args:
     c = syn.CONFIGS["C3"]
     inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity)
+    if cluster > 0:          # as bench.py --cluster
+        k = int(cluster * c["P"])
+        inp["means3D"] = inp["means3D"].copy(); inp["means3D"][:k] = inp["means3D"][:k] * 0.3 + np.array([0.5, 0.25, 0.0], np.float32)
     rasterizer.DETERMINISTIC = True; rasterizer.KEEP_DET_SCRATCH = True
     outs, lv, _ = hipref.run_forward(inp)
     ist = hipref.internal_state(outs, inp)
@@ -105,6 +109,7 @@ for opacity in args:
     tile_order_cls = [list(range(c, nt, 1024)) for c in range(1024)]
     print("   with the single-wave issue rate in the model, span / (total work / 1024): tile order %.3f; snake %.3f; adjacent pairs + snake of the rest %.3f; pairs + rest 'RFRFRF' %.3f; pairs + 'RRFFRF' %.3f"
           % (span(tile_order_cls) / ideal, span(arrange("FR")) / ideal, span(arrange("FR", True)) / ideal, span(arrange("RF", True)) / ideal, span(arrange("RRFFRF", True)) / ideal))
+    print("   walked length per tile: mean %.1f, cv %.3f, max / mean %.2f%s" % (top.mean(), top.std() / top.mean(), top.max() / top.mean(), ("  (cluster %g)" % cluster) if cluster else ""))
     print("C3 opacity=%s: tiles %d, walked entries %.2f M, processed %.2f M; work per tile: mean %.0f, cv %.2f, max %.0f (%.1f x mean)"
           % (opacity, nt, top.sum() / 1e6, proc.sum() / 1e6, work.mean(), work.std() / work.mean(), work.max(), work.max() / work.mean()))
     print("   per-SIMD load, max / mean: round-robin placement %.2f, random placement %.2f, work queue in launch order %.2f, work queue longest first %.2f"
