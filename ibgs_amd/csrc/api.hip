@@ -8,6 +8,7 @@
 // Everything is enqueued on the caller's stream; no device-wide synchronisation, no allocation
 // (arenas are caller-owned), no persistent library state.
 #include "common.h"
+#include <cstdlib>
 #include <stdlib.h>
 #include <stdio.h>
 #include <cstdarg>
@@ -231,6 +232,8 @@ struct RSlot {
     uint32_t* host; hipEvent_t ev;
     uint32_t* part; size_t part_cap;          // deferred sizing: the preprocess kernel's per-wave tile sums + the depth sort's error flag (pinned, grown on demand)
     uint32_t* stats; hipEvent_t ev_stats; bool stats_pending;          // R as the binning counted it, -, C: diagnostics, read when somebody asks (ibgs_last_forward_stats)
+    hipStream_t copy_stream; hipEvent_t ev_mark;          // the read-backs run on a stream of their own, behind a marker of the caller's stream: a copy queued INTO the
+                                                          // caller's stream is a blit kernel between two barriers there (~25 us of the step)
 };
 static RSlot* rslot()
 {
@@ -244,6 +247,9 @@ static RSlot* rslot()
         if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
         if (hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
         if (hipEventCreateWithFlags(&slot.ev_stats, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
+        if (hipEventCreateWithFlags(&slot.ev_mark, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&slot.copy_stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipHostFree(p); set_error("hipStreamCreate for the read-backs failed"); return nullptr;
+        }
         slot.host = static_cast<uint32_t*>(p);
         slot.stats = slot.host + 8;
     }
@@ -359,8 +365,10 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if (!rs) return -IBGS_ERR_HIP;
     if (deferred) {
         if ((rc = rslot_reserve_part(rs, nwaves + 1))) return rc;
-        IBGS_HIP(hipMemcpyAsync(rs->part, g.tile_partial, (nwaves + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        IBGS_HIP(hipEventRecord(rs->ev, s));
+        IBGS_HIP(hipEventRecord(rs->ev_mark, s));
+        IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
+        IBGS_HIP(hipMemcpyAsync(rs->part, g.tile_partial, (nwaves + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
+        IBGS_HIP(hipEventRecord(rs->ev, rs->copy_stream));
     }
     auto exact_R = [&](int64_t* R_out) -> int {       // synchronous path: R from the scanned tile counts
         IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
@@ -382,8 +390,10 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta))) return rc; }
         if (read_back) {
             // diagnostics nobody waits for (ibgs_last_forward_stats): R as the binning counted it, -, the coarse slots in use
-            IBGS_HIP(hipMemcpyAsync(rs->stats, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            IBGS_HIP(hipEventRecord(rs->ev_stats, s));
+            IBGS_HIP(hipEventRecord(rs->ev_mark, s));
+            IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
+            IBGS_HIP(hipMemcpyAsync(rs->stats, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
+            IBGS_HIP(hipEventRecord(rs->ev_stats, rs->copy_stream));
         }
         { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b))) return rc; }
         if ((rc = stage_check(s, debug, "binning"))) return rc;
