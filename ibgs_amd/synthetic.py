@@ -166,6 +166,10 @@ CONFIGS = {
     # not a BASELINE config: C3's Gaussians on a 720p frame (3 600 tiles: one resident round of the blend kernels even at 4 waves per SIMD);
     # used by occupancy experiments (bench.py --config C3_720p --wave-shape tile)
     "C3_720p": dict(P=1_000_000, W=1280, H=720, sh_degree=3, seed=3),
+    # not a BASELINE config either: C3's Gaussians on the frame of the reference's `garden -r 4` recipe (1297 x 840 = 4 346 tiles, just above the
+    # 4 096 tiles from which the blend kernels run one wave per tile) -- where the two wave shapes cross over
+    "C3_800": dict(P=1_000_000, W=800, H=800, sh_degree=3, seed=3),          # (C2's frame with C3's Gaussians: 2 500 tiles)
+    "C3_garden4": dict(P=1_000_000, W=1297, H=840, sh_degree=3, seed=3),
 }
 
 
