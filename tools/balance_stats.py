@@ -110,6 +110,19 @@ for opacity in args:
     print("   with the single-wave issue rate in the model, span / (total work / 1024): tile order %.3f; snake %.3f; adjacent pairs + snake of the rest %.3f; pairs + rest 'RFRFRF' %.3f; pairs + 'RRFFRF' %.3f"
           % (span(tile_order_cls) / ideal, span(arrange("FR")) / ideal, span(arrange("FR", True)) / ideal, span(arrange("RF", True)) / ideal, span(arrange("RRFFRF", True)) / ideal))
     print("   walked length per tile: mean %.1f, cv %.3f, max / mean %.2f%s" % (top.mean(), top.std() / top.mean(), top.max() / top.mean(), ("  (cluster %g)" % cluster) if cluster else ""))
+    # hybrid decomposition (not built): tiles heavier than thr x the mean as four quadrant waves of `f` x the tile wave's cost each, everything dealt out in snake order
+    def hybrid(thr, f=0.36):
+        wts = []
+        for t in range(nt):
+            if work[t] > thr * work.mean(): wts += [work[t] * f] * 4
+            else: wts.append(work[t])
+        wts = np.sort(np.asarray(wts))[::-1]
+        cls = [[] for _ in range(1024)]
+        for i, wgt in enumerate(wts):
+            k, c = divmod(i, 1024)
+            cls[c if k % 2 == 0 else 1023 - c].append(wgt)
+        return max(finish(a) for a in cls) / (work.sum() / 1024), len(wts) - nt
+    print("   hybrid (model): " + "; ".join("tiles > %.2f x mean split: span %.3f (+%d waves)" % ((thr,) + hybrid(thr)) for thr in (1.05, 1.15, 1.3, 1.6)))
     print("C3 opacity=%s: tiles %d, walked entries %.2f M, processed %.2f M; work per tile: mean %.0f, cv %.2f, max %.0f (%.1f x mean)"
           % (opacity, nt, top.sum() / 1e6, proc.sum() / 1e6, work.mean(), work.std() / work.mean(), work.max(), work.max() / work.mean()))
     print("   per-SIMD load, max / mean: round-robin placement %.2f, random placement %.2f, work queue in launch order %.2f, work queue longest first %.2f"
