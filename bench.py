@@ -101,17 +101,27 @@ def profile_counters(kernel_substr, workload_tag):
     return None, "kernel %s not in the profile summary" % kernel_substr
 
 
+def workload_tag(cfg, geo, forward_only, opacity, cluster=0.0, anisotropy=None, scale_sigma=0.0):
+    """Names a workload in profiles/*_counters.json (profiles/summarize.py stamps the same string)."""
+    return "%s%s%s opacity=%s%s%s%s" % (cfg, " geo" if geo else "", " forward-only" if forward_only else "", opacity,
+                                        (" cluster=%g" % cluster) if cluster > 0 else "", (" anisotropy=%s" % anisotropy) if anisotropy else "",
+                                        (" scale_sigma=%g" % scale_sigma) if scale_sigma > 0 else "")
+
+
 class Workload:
     """One view of one BASELINE config resident on `dev`: leaves, settings, the step closure."""
-    CLUSTER = 0.0
+    CLUSTER = 0.0          # defaults of the scene shape (--cluster / --anisotropy / --scale-sigma); a Workload may be given its own
+    ANISOTROPY = None
+    SCALE_SIGMA = 0.0
     torch_l1 = False
 
-    def __init__(self, cfg, view, dev, opacity, geo, forward_only, target_seed):
+    def __init__(self, cfg, view, dev, opacity, geo, forward_only, target_seed, cluster=None, anisotropy="default", scale_sigma=None):
         c = syn.CONFIGS[cfg]
-        inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"], view=view, opacity=opacity)
-        if Workload.CLUSTER > 0:
-            k = int(Workload.CLUSTER * c["P"])
-            inp["means3D"] = inp["means3D"].copy(); inp["means3D"][:k] = inp["means3D"][:k] * 0.3 + np.array([0.5, 0.25, 0.0], np.float32)
+        self.cluster = Workload.CLUSTER if cluster is None else cluster
+        self.anisotropy = Workload.ANISOTROPY if anisotropy == "default" else anisotropy
+        self.scale_sigma = Workload.SCALE_SIGMA if scale_sigma is None else scale_sigma
+        inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["sh_degree"], seed=c["seed"], view=view, opacity=opacity,
+                             anisotropy=self.anisotropy, scale_sigma=self.scale_sigma, cluster=self.cluster)
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
         P, H, W = c["P"], c["H"], c["W"]
         self.c, self.cfg, self.inp, self.geo, self.forward_only, self.dev = c, cfg, inp, geo, forward_only, dev
@@ -207,9 +217,12 @@ class Workload:
 
     def describe(self, opacity, world, exchange):
         c = self.c
+        shape = ((", %g of the Gaussians in one blob" % self.cluster) if self.cluster > 0 else "") \
+            + ((", anisotropy=%s" % self.anisotropy) if self.anisotropy else "") \
+            + ((", log-normal sizes sigma=%g" % self.scale_sigma) if self.scale_sigma > 0 else "")
         return "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, opacity=%s%s, one view per GPU%s" % (
             self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target (ibgs_amd.losses.l1_loss: value + gradient in one pass)",
-            opacity + ((", %g of the Gaussians in one blob" % Workload.CLUSTER) if Workload.CLUSTER > 0 else ""),
+            opacity + shape,
             ", render_geo n_src=4 L=4" if self.geo else "", (", RCCL gradient exchange (%s)" % exchange) if world > 1 else "")
 
 
@@ -447,6 +460,11 @@ def main():
     ap.add_argument("--cluster", type=float, default=0.0,
                     help="NOT the BASELINE workload: move this fraction of the Gaussians into one blob (a non-uniform image: what the tile -> XCD "
                          "mapping and the binning must cope with in real scenes)")
+    ap.add_argument("--anisotropy", default=None, choices=["plane", "needle", "mixed"],
+                    help="NOT the BASELINE workload: shape of the Gaussians (synthetic.make_gaussians): plane = what IBGS / PGSR train towards")
+    ap.add_argument("--scale-sigma", type=float, default=0.0,
+                    help="NOT the BASELINE workload: log-normal spread of the Gaussian sizes (a heavy tail of large ones, as densification leaves it)")
+    ap.add_argument("--no-trained-geo-line", action="store_true", help="skip the `trained_geo` object (the trainer's steady-state workload) of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="factored", choices=["factored", "dense"],
                     help="N > 1: factored = all-gather 3-float dL/dRGB per view + local SH expansion (default); dense = all-reduce of every gradient")
@@ -482,7 +500,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     _lib.load()
 
-    Workload.CLUSTER = a.cluster
+    Workload.CLUSTER, Workload.ANISOTROPY, Workload.SCALE_SIGMA = a.cluster, a.anisotropy, a.scale_sigma
     if a.wave_shape:
         from ibgs_amd import rasterizer as _rz
         _rz.WAVE_SHAPE = a.wave_shape
@@ -585,25 +603,34 @@ def main():
                                   "note": "same Gaussians, 8 orbit cameras round-robin, fwd+bwd; R differs per camera"}
         wl.hop_to(rank % 8)
 
-    geo_line = None
+    def geo_object(gwl, opacity, gsteps):
+        gm = measure(gwl, gwl.local_step, gsteps, 10, 1, n_fwd=5)
+        grf = roofline(gwl, gm, workload_tag(a.config, True, False, opacity, gwl.cluster, gwl.anisotropy, gwl.scale_sigma))
+        with torch.no_grad():
+            radii = gwl._call()[1]
+            big = int((radii > 128).sum().item()); vis = int((radii > 0).sum().item())
+        return {"workload": gwl.describe(opacity, 1, a.exchange), "steps": gsteps, "ms_per_step": gm["ms_step"],
+                "median_ms_hipevent": gm["median_ms"], "max_ms_hipevent": gm["max_ms"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
+                "num_rendered": int(gwl.R), "gaussians_in_frustum": vis, "gaussians_radius_gt_128px": big, "stages_ms": gm["stages"], "roofline": grf}
+
+    geo_line = trained_geo = None
     if world == 1 and not (a.geo or a.forward_only or a.no_geo_line):
         # second line of SURVEY 8(d) under the same clock: C3 + render_geo, n_src 4, L 4 (extra key; never part of `value`)
         del step
         gwl = Workload(a.config, rank % 8, dev, a.opacity, True, False, 1234 + rank)
-        gsteps = max(5, min(20, a.steps))
-        gm = measure(gwl, gwl.local_step, gsteps, 10, 1, n_fwd=5)
-        grf = roofline(gwl, gm, "%s geo opacity=%s" % (a.config, a.opacity))
-        geo_line = {"workload": gwl.describe(a.opacity, 1, a.exchange), "steps": gsteps, "ms_per_step": gm["ms_step"],
-                    "median_ms_hipevent": gm["median_ms"], "max_ms_hipevent": gm["max_ms"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
-                    "num_rendered": int(gwl.R), "stages_ms": gm["stages"], "roofline": grf}
+        geo_line = geo_object(gwl, a.opacity, max(5, min(20, a.steps)))
         del gwl
+    if world == 1 and not (a.geo or a.forward_only or a.no_trained_geo_line):
+        # what train.py:289-292 runs for ~77 % of its iterations: render_geo on TRAINED Gaussians -- plane-like (scene/gaussian_model.py:156-173),
+        # a heavy tail of sizes (densification, :580-604), an uneven image (30 % of them in one blob), trained-like opacities.  Extra key; never `value`
+        twl = Workload(a.config, rank % 8, dev, "trained", True, False, 1234 + rank, cluster=0.3, anisotropy="plane", scale_sigma=1.0)
+        trained_geo = geo_object(twl, "trained", max(5, min(20, a.steps)))
+        del twl
 
     if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
         extras["test_frame"] = test_frame(dev, wl.c)
     if rank == 0:
-        tag = "%s%s%s opacity=%s%s" % (a.config, " geo" if a.geo else "", " forward-only" if a.forward_only else "", a.opacity,
-                                       (" cluster=%g" % a.cluster) if a.cluster > 0 else "")
-        rf = roofline(wl, m, tag)
+        rf = roofline(wl, m, workload_tag(a.config, a.geo, a.forward_only, a.opacity, a.cluster, a.anisotropy, a.scale_sigma))
         out = {
             "metric": ("forward render fps " + a.config) if a.forward_only else
                       ("train-step fps (fwd+bwd raster) @1080p, 1M Gaussians" if a.config == "C3" else "train-step fps (fwd+bwd raster) " + a.config),
@@ -621,6 +648,8 @@ def main():
             out["rccl"] = rccl
         if geo_line is not None:
             out["geo"] = geo_line
+        if trained_geo is not None:
+            out["trained_geo"] = trained_geo
         out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl.inp, a.config)

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libibgs_rast.so")
+# IBGS_LIB: another build of the same ABI (A/B runs of two builds on ONE box: tools/ab_lib.sh); never a fallback -- a path that does not load raises
+LIB_PATH = os.environ.get("IBGS_LIB") or os.path.join(_HERE, "libibgs_rast.so")
 
 MAX_SRC = 5
 MAX_BUFFER_LENGTH = 8
@@ -206,7 +207,7 @@ def load():
 # "binning" = coarse entries placed per cell + per-tile counts + ranges, "list_scatter" = the ids to their slots (two-level binning,
 # csrc/binning.hip); "ranges" has no kernel of its own any more (always 0)
 STAGES = ["preprocess", "depth_sort", "scan", "binning", "list_scatter", "ranges", "render_fwd", "render_bwd",
-          "preprocess_bwd"]
+          "preprocess_bwd", "geo_window", "tile_order"]
 
 
 def timing_enable(stages):

@@ -133,17 +133,14 @@ static hipEvent_t get_event()
     return e;
 }
 
-struct StageTimer {   // RAII: records an event pair around one stage when that stage is selected
-    hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int stage; bool on;
-    StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), on((g_time_mask >> stage_) & 1u)
-    {
-        if (on) { a = get_event(); b = get_event(); (void)hipEventRecord(a, s); }
-    }
-    ~StageTimer()
-    {
-        if (on) { (void)hipEventRecord(b, s); g_pairs.push_back({a, b, stage}); }
-    }
-};
+StageTimer::StageTimer(hipStream_t s_, int stage_) : s(s_), stage(stage_), on((g_time_mask >> stage_) & 1u)
+{
+    if (on) { a = get_event(); b = get_event(); (void)hipEventRecord(a, s); }
+}
+StageTimer::~StageTimer()
+{
+    if (on) { (void)hipEventRecord(b, s); g_pairs.push_back({a, b, stage}); }
+}
 
 static int stage_check(hipStream_t s, bool debug, const char* what)
 {
@@ -387,7 +384,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, Hn), a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta, nv))) return rc; }
         if (read_back) {
             // diagnostics nobody waits for (ibgs_last_forward_stats): R as the binning counted it, -, the coarse slots in use
             IBGS_HIP(hipEventRecord(rs->ev_mark, s));
@@ -479,9 +476,9 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
             ds = DetState::carve(a.det_scratch, (size_t)a.R * ipt, (size_t)a.P, nullptr);
             if ((rc = launch_det_prepare(s, ds, (size_t)a.R * ipt))) return rc;
         }
-        { StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-          if ((rc = launch_render_backward(s, a, g, b, im, rgba, det ? ds.slab : nullptr, geo_tab))) return rc;
-          if (det && (rc = launch_det_reduce(s, ds, b.point_list, (size_t)a.R, ipt, a.P, a.grad_acc))) return rc; }
+        // (launch_render_backward brackets its kernels itself: IBGS_STAGE_GEO_WINDOW, IBGS_STAGE_TILE_ORDER, IBGS_STAGE_RENDER_BWD = the blend kernel alone)
+        if ((rc = launch_render_backward(s, a, g, b, im, rgba, det ? ds.slab : nullptr, geo_tab))) return rc;
+        if (det) { StageTimer t(s, IBGS_STAGE_TILE_ORDER); if ((rc = launch_det_reduce(s, ds, b.point_list, (size_t)a.R, ipt, a.P, a.grad_acc))) return rc; }
         if ((rc = stage_check(s, debug, "render backward"))) return rc;
     }
     { StageTimer t(s, IBGS_STAGE_PREPROCESS_BWD); if ((rc = launch_preprocess_backward(s, a, g))) return rc; }

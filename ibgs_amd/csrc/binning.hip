@@ -34,15 +34,19 @@ struct RectU { uint32_t x0, x1, y0, y1; };
 // (the mask words are four scalars, not an array: selecting a word by a run-time index must stay a chain of register selects -- with an array
 // the compiler turns the chain into an indexed load, the whole footprint moves to scratch memory and every row of a large rectangle pays a
 // store -> load round trip.  2 % of C3's Gaussians take that path, a third of the waves hold one: cell_count 31 -> 23 us, cell_place 38 -> 28 us)
-struct Footprint { RectU r; uint64_t m0, m1, m2, m3; bool masked; };
+// masked: the rectangle's tiles are the set bits of the mask (<= IBGS_CULL_MAX_TILES tiles); else rows: the runs of cull_row_run (common.h) are
+// recomputed from the Gaussian's record -- rectangles of ANY size are culled exactly --; else every tile of the rectangle (near-singular
+// conics, IBGS_FLAG_NO_TILE_CULL: the reference's AABB lists)
+struct Footprint { RectU r; uint64_t m0, m1, m2, m3; bool masked, rows; };
 static_assert(IBGS_CULL_WORDS == 4, "four mask words");
 __device__ __forceinline__ Footprint make_footprint(const uint4 rr, const uint64_t* __restrict__ tmask_hi, uint32_t id)
 {
     Footprint f;
     f.r = RectU{rr.x & 0xFFFFu, rr.x >> 16, rr.y & 0xFFFFu, rr.y >> 16};
     const uint32_t area = (f.r.x1 - f.r.x0) * (f.r.y1 - f.r.y0);
-    f.masked = area <= (uint32_t)IBGS_CULL_MAX_TILES;            // larger rectangles keep every tile (preprocess.hip)
+    f.masked = area <= (uint32_t)IBGS_CULL_MAX_TILES;
     f.m0 = ((uint64_t)rr.w << 32) | rr.z;
+    f.rows = !f.masked && f.m0 == 0ull;                          // (preprocess.hip leaves the mask words of a row-culled large rectangle zero)
     const uint64_t* mw = tmask_hi + (size_t)id * (IBGS_CULL_WORDS - 1);
     f.m1 = (f.masked && area > 64u) ? mw[0] : 0ull;
     f.m2 = (f.masked && area > 128u) ? mw[1] : 0ull;
@@ -93,7 +97,8 @@ __device__ __forceinline__ uint64_t cell_mask(const Footprint& f, uint32_t ccx, 
 constexpr int PLACE_THREADS = 256;       // four waves, one batch of 64 consecutive depth ranks each per round
 constexpr int PLACE_MAX_CELLS = 1024;
 
-struct PlaceGeom { int P, G, nblk, cgx; int c0, nc; };            // G = depth ranks per block (a multiple of 256); cells [c0, c0 + nc) in this launch
+struct PlaceGeom { int P, G, nblk, cgx; int c0, nc; int Pv, gyv; };            // G = depth ranks per block (a multiple of 256); cells [c0, c0 + nc) in this launch;
+                                                                               // batched views: instances per view, tile rows per view (one view: P, gy)
 
 // The common case: a rectangle of at most 8 x 8 tiles reaches at most 2 x 2 cells and its whole mask is word 0.  The rows are spread
 // to a stride of 8 once; the part inside a cell is that image shifted by the rectangle's offset from the cell, columns that wrap
@@ -141,28 +146,119 @@ __device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& 
         }
 }
 
+// ---- large rectangles: the whole wave walks one Gaussian's cells ---------------------------------------------------------------------------
+// A lane that walks the 20 .. 135 cells of a large rectangle on its own keeps the other 63 lanes of its batch waiting, and on a trained scene
+// (a heavy tail of sizes) nearly every batch of 64 depth ranks holds such a Gaussian: cell_count 23 -> 78 us, cell_place 28 -> 165 us on the
+// bench's trained scene.  Rectangles of more than COOP_MIN_CELLS cells (and every row-culled one) are therefore taken out of the per-lane
+// path: their owners raise a ballot, and Gaussian after Gaussian the wave loads the footprint again -- wave-uniform addresses, lines the owner
+// has just touched -- and gives every lane one cell.  Row-culled rectangles: lane l first computes the run of tile row (strip of 64 rows) + l
+// and parks it in LDS; a cell's mask is assembled from its eight rows' runs.
+constexpr uint32_t COOP_MIN_CELLS = 9;
+__device__ __forceinline__ bool wants_coop(const Footprint& f)
+{
+    const RectU& r = f.r;
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return false;
+    const uint32_t cw = (r.x1 - 1) / CB - r.x0 / CB + 1, chh = (r.y1 - 1) / CB - r.y0 / CB + 1;
+    return f.rows || cw * chh > COOP_MIN_CELLS;
+}
+// the job of a row-culled Gaussian from its record (quads 0, 1: x, y, opacity; conic) -- what preprocess.hip's cull_setup built
+__device__ __forceinline__ CullRows rows_job(const PlaceGeom& pg, const Footprint& f, const float4* __restrict__ rec, uint32_t id, int& row_off)
+{
+    const float4 q0 = rec[(size_t)id * 4], q1 = rec[(size_t)id * 4 + 1];
+    CullRows j;
+    cull_rows_setup(j, q0.x, q0.y, q1.x, q1.y, q1.z, q1.x * q1.z - q1.y * q1.y, cull_qmax(q0.z), (int)f.r.x0, (int)f.r.x1);
+    row_off = (int)(id / (uint32_t)pg.Pv) * pg.gyv;          // batched views: the record's y is the view's own, the rectangle's rows are the stacked grid's
+    return j;
+}
+// All 64 lanes call this with the same (wave-uniform) footprint; f(cell, mask) runs on the lane that owns the cell.
+template <typename F>
+__device__ __forceinline__ void wave_for_cells(const PlaceGeom& pg, const Footprint& fp, const float4* __restrict__ rec, uint32_t id, int lane,
+                                               uint32_t* __restrict__ s_runs /* 64 words of this wave */, F f)
+{
+    const RectU& r = fp.r;
+    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
+    const uint32_t cw = c1x - c0x + 1;
+    if (!fp.rows) {
+        const uint32_t ncell = cw * (c1y - c0y + 1);
+        for (uint32_t idx = (uint32_t)lane; idx < ncell; idx += 64u) {
+            const uint32_t cy = c0y + idx / cw, cx = c0x + idx % cw;
+            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+            if (cell < 0 || cell >= pg.nc) continue;
+            const uint64_t m = cell_mask(fp, cx, cy);
+            if (m != 0ull) f(cell, m);
+        }
+        return;
+    }
+    int row_off;
+    const CullRows j = rows_job(pg, fp, rec, id, row_off);
+    for (uint32_t sy = c0y; sy <= c1y; sy += 8u) {          // strips of eight cell rows = 64 tile rows
+        const int ty = (int)(sy * CB) + lane;
+        int t0 = 1, t1 = 0;
+        if (ty >= (int)r.y0 && ty < (int)r.y1) { if (!cull_row_run(j, ty - row_off, t0, t1)) { t0 = 1; t1 = 0; } }
+        __builtin_amdgcn_wave_barrier();
+        s_runs[lane] = (uint32_t)t0 | ((uint32_t)t1 << 16);          // (LDS operations of one wave execute in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nrow = min(8u, c1y - sy + 1u);
+        for (uint32_t idx = (uint32_t)lane; idx < nrow * cw; idx += 64u) {
+            const uint32_t dy = idx / cw, cy = sy + dy, cx = c0x + idx % cw;
+            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+            if (cell < 0 || cell >= pg.nc) continue;
+            const int cx0 = (int)(cx * CB);
+            uint64_t m = 0ull;
+#pragma unroll
+            for (int rr = 0; rr < CB; rr++) {
+                const uint32_t run = s_runs[dy * CB + rr];
+                const int lo = max((int)(run & 0xFFFFu), cx0), hi = min((int)(run >> 16), cx0 + CB - 1);
+                if (lo <= hi) m |= (uint64_t)((1u << (hi - lo + 1)) - 1u) << (rr * CB + (lo - cx0));
+            }
+            if (m != 0ull) f(cell, m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg, const uint32_t* __restrict__ order0, const uint32_t* __restrict__ order1 /* where the depth order lies: n_kept[1] */,
                                                                    const uint32_t* __restrict__ n_kept,
-                                                                   const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi,
+                                                                   const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi, const float4* __restrict__ rec,
                                                                    uint4* __restrict__ fp_sorted /* the footprints in depth order, for the place kernel */,
                                                                    uint32_t* __restrict__ cnt /* ncells x nblk */)
 {
     extern __shared__ uint32_t s_cnt[];
+    __shared__ uint32_t s_runs[PLACE_THREADS / 64][64];
     const uint32_t* __restrict__ order = n_kept[1] ? order1 : order0;          // (the depth sort's last pass may have left the result in its input buffer, scan_sort.hip)
-    const int tid = threadIdx.x, blk = blockIdx.x;
+    const int tid = threadIdx.x, blk = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) s_cnt[c] = 0u;
     __syncthreads();
     const int j1 = min((int)min((uint32_t)pg.P, *n_kept), (blk + 1) * pg.G);          // ranks past the Gaussians with tiles hold nothing
-    for (int j = blk * pg.G + tid; j < j1; j += PLACE_THREADS) {
-        const uint32_t id = order[j];
-        const uint4 rec = fpr[id];                             // the one random 16-byte gather per Gaussian of the binning stage
-        if (pg.c0 == 0) fp_sorted[j] = rec;
-        const Footprint fp = make_footprint(rec, tmask_hi, id);
-        Cells4 c4;
-        if (small_cells(pg, fp, c4)) {
+    for (int j0 = blk * pg.G + wave * 64; j0 < j1; j0 += PLACE_THREADS) {          // wave-uniform: a batch of 64 consecutive ranks per wave
+        const int j = j0 + lane;
+        const bool have = j < j1;
+        bool coop = false;
+        uint32_t id = 0u;
+        if (have) {
+            id = order[j];
+            const uint4 rr = fpr[id];                             // the one random 16-byte gather per Gaussian of the binning stage
+            if (pg.c0 == 0) fp_sorted[j] = rr;
+            const Footprint fp = make_footprint(rr, tmask_hi, id);
+            coop = wants_coop(fp);
+            if (!coop) {
+                Cells4 c4;
+                if (small_cells(pg, fp, c4)) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicAdd(&s_cnt[c4.cell[k]], 1u);
-        } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+                    for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicAdd(&s_cnt[c4.cell[k]], 1u);
+                } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+            }
+        }
+        uint64_t todo = __ballot(coop);
+        while (todo != 0ull) {          // wave-uniform: the large rectangles of this batch, one after the other, a cell per lane
+            const int g = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, g);
+            const Footprint fp = make_footprint(fpr[gid], tmask_hi, gid);
+            wave_for_cells(pg, fp, rec, gid, lane, s_runs[wave], [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+        }
     }
     __syncthreads();
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) cnt[(size_t)(pg.c0 + c) * pg.nblk + blk] = s_cnt[c];
@@ -229,9 +325,11 @@ __global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const ui
 // word of the hint, by ONE EXTRA workgroup of the place kernel: beside the placement's thousands of workgroups it costs no time (inside the
 // one-workgroup tile_ranges_kernel, where it was first, it added 8 us to the forward).  meta[11] = 1: valid.
 constexpr int HINT_MAX_TILES = 65536;
-__device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
+__device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta, uint32_t* __restrict__ s_dyn)
 {
-    __shared__ uint32_t s_seen[HINT_MAX_TILES / 32];
+    // the bitmap lives in the kernel's DYNAMIC LDS (the placement workgroups' tables; the launcher sizes it for whichever is larger): a static
+    // 8 KB array would be charged to every workgroup of the kernel for the sake of this one
+    uint32_t* s_seen = s_dyn;          // (ntiles + 31) / 32 words
     __shared__ uint32_t s_cnt;
     int ok = 0;
     if (order_hint && ntiles <= HINT_MAX_TILES) {
@@ -262,20 +360,20 @@ __device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __r
 }
 
 __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order0, const uint32_t* __restrict__ order1, const uint32_t* __restrict__ n_kept,
-                                                                   const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi,
+                                                                   const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi, const float4* __restrict__ rec,
                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
                                                                    uint4* __restrict__ cent, int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
 {
     // the extra workgroup (first slice only) is workgroup 0: dispatched first, it runs beside the placement instead of after it
-    if (meta) { if (blockIdx.x == 0) { check_order_hint(ntiles, order_hint, meta); return; } }
     extern __shared__ unsigned long long s_place[];        // 4 x nc lane words (one table per wave), then nc next-free slots
+    if (meta) { if (blockIdx.x == 0) { check_order_hint(ntiles, order_hint, meta, reinterpret_cast<uint32_t*>(s_place)); return; } }
+    __shared__ uint32_t s_runs[PLACE_THREADS / 64][64];
     const int nc = pg.nc;
     unsigned long long* s_touch = s_place;
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + 4 * nc);
     const uint32_t* __restrict__ order = n_kept[1] ? order1 : order0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x - (meta ? 1 : 0);
     for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start[pg.c0 + c] + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
-    const unsigned long long below = (1ull << lane) - 1ull;
     const int j1 = min((int)min((uint32_t)pg.P, *n_kept), (blk + 1) * pg.G);
     for (int j0 = blk * pg.G; j0 < j1; j0 += PLACE_THREADS) {          // uniform over the workgroup
         for (int c = tid; c < 4 * nc; c += PLACE_THREADS) s_touch[c] = 0ull;
@@ -284,28 +382,48 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
         const bool have = j < j1;
         const uint32_t id = have ? order[j] : 0u;
         unsigned long long* mine = s_touch + wave * nc;
-        Footprint fp; Cells4 c4; bool small = true;
+        Footprint fp; Cells4 c4; bool small = true, coop = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) c4.cell[k] = -1;
         if (have) {
             fp = make_footprint(fp_sorted[j], tmask_hi, id);
-            small = small_cells(pg, fp, c4);
-            if (small) {
+            coop = wants_coop(fp);
+            if (!coop) {
+                small = small_cells(pg, fp, c4);
+                if (small) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicOr(&mine[c4.cell[k]], 1ull << lane);
-            } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); });
+                    for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicOr(&mine[c4.cell[k]], 1ull << lane);
+                } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); });
+            }
+        }
+        // the large rectangles of this wave's batch, one after the other, a cell per lane (wave_for_cells): first who touches which cell ...
+        const uint64_t coopm = __ballot(coop);
+        const int jw = j0 + wave * 64;          // this wave's first rank
+        for (uint64_t todo = coopm; todo != 0ull; todo &= todo - 1ull) {
+            const int g = __builtin_ctzll(todo);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, g);
+            const Footprint fg = make_footprint(fp_sorted[jw + g], tmask_hi, gid);
+            wave_for_cells(pg, fg, rec, gid, lane, s_runs[wave], [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << g); });
         }
         __syncthreads();
-        auto place = [&](int cell, uint64_t m) {
-            uint32_t pos = s_base[cell] + (uint32_t)__popcll(mine[cell] & below);
+        auto place_as = [&](int cell, uint64_t m, uint32_t gid, int g) {          // entry of the batch's rank g
+            uint32_t pos = s_base[cell] + (uint32_t)__popcll(mine[cell] & ((1ull << g) - 1ull));
             for (int w = 0; w < wave; w++) pos += (uint32_t)__popcll(s_touch[w * nc + cell]);       // earlier waves = earlier ranks
-            if (pos < ccap) cent[pos] = make_uint4(id, 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
+            if (pos < ccap) cent[pos] = make_uint4(gid, 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
         };
-        if (have) {
+        auto place = [&](int cell, uint64_t m) { place_as(cell, m, id, lane); };
+        if (have && !coop) {
             if (small) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) place(c4.cell[k], c4.m[k]);
             } else for_cells(pg, fp, place);
+        }
+        // ... then the entries themselves
+        for (uint64_t todo = coopm; todo != 0ull; todo &= todo - 1ull) {
+            const int g = __builtin_ctzll(todo);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, g);
+            const Footprint fg = make_footprint(fp_sorted[jw + g], tmask_hi, gid);
+            wave_for_cells(pg, fg, rec, gid, lane, s_runs[wave], [&](int cell, uint64_t m) { place_as(cell, m, gid, g); });
         }
         __syncthreads();
         for (int c = tid; c < nc; c += PLACE_THREADS)
@@ -528,7 +646,7 @@ static int place_block_ranks(int P, size_t cnt_elems, int ncells)
 // Part 1: everything up to the tile ranges and the counters the host reads back (R, C); part 2 (launch_binning_scatter) writes the
 // lists.  Split so that the host's read-back can be queued between them and is served while scatter + render still run.
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
-                   const uint32_t* order_hint, uint32_t* meta)
+                   const uint32_t* order_hint, uint32_t* meta, int n_views)
 {
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy, ntiles = gx * gy;
     uint32_t* counters = g.offsets + P;               // R, depth sort error flag, C: what the host reads back in ONE copy (api.hip)
@@ -540,13 +658,15 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     const uint32_t ccap = (uint32_t)b.ccap;
     PlaceGeom pg;
     pg.P = P; pg.cgx = cgx;
+    pg.Pv = P / (n_views > 1 ? n_views : 1); pg.gyv = gy / (n_views > 1 ? n_views : 1);
+    const float4* rec = reinterpret_cast<const float4*>(g.rec);
     pg.G = place_block_ranks(P, b.cnt_elems, ncells);
     if (pg.G <= 0) { set_error("binning arena too small for the cell count matrix"); return -IBGS_ERR_ALLOC; }
     pg.nblk = (P + pg.G - 1) / pg.G;
     const uint32_t* order = g.sort_val[0];
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
-        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_val[1], g.offsets + P + 3, g.fp, g.tmask_hi, g.fp_sorted, b.cnt);
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_val[1], g.offsets + P + 3, g.fp, g.tmask_hi, rec, g.fp_sorted, b.cnt);
         IBGS_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total);
@@ -556,7 +676,9 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
         const bool check = meta != nullptr && pg.c0 == 0;
-        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), 36u * (size_t)pg.nc, s, pg, ccap, order, g.sort_val[1], g.offsets + P + 3, g.fp_sorted, g.tmask_hi,
+        size_t lds = 36u * (size_t)pg.nc;
+        if (check && order_hint && ntiles <= HINT_MAX_TILES) lds = max(lds, sizeof(uint32_t) * (size_t)((ntiles + 31) / 32));
+        hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), lds, s, pg, ccap, order, g.sort_val[1], g.offsets + P + 3, g.fp_sorted, g.tmask_hi, rec,
                            b.cnt, b.cell_start, b.cent, ntiles, order_hint, check ? meta : nullptr);
         IBGS_HIP(hipGetLastError());
     }

@@ -132,6 +132,53 @@ __device__ __forceinline__ float ref_power_E(float dx, float dy, float a, float 
     return power > 0.0f ? __builtin_inff() : fmaf(-power, LOG2_E, neg_log2_opacity);          // +inf fails every E <= log2(255) test
 }
 
+// ---- exact tile cull, row by row (preprocess.hip counts / masks with it, binning.hip recomputes it for rectangles too large for a mask) ----------
+// A Gaussian passes the blend's alpha >= 1/255 test only where q = a dx^2 + 2b dx dy + c dy^2 <= qmax = 2 ln(255 o) (+ 0.1 % + 1e-3).  Inside the
+// band of pixel centres of one tile row that ellipse is convex, so the tiles it reaches there are ONE run of consecutive tiles, bounded by the
+// ellipse's x-range over the band, whose ends sit at y* = -B sqrt(qmax / (C det)) (upper end) and -y* (lower end) clamped into the band.
+// Same operations in the same order as oracle/ibgs_oracle.c (cull_rows_setup / cull_row_run / cull_qmax): basic IEEE operations only and no
+// contraction, whatever the translation unit's flags, so that every caller and the oracle get the same runs bit for bit.
+__device__ __forceinline__ float ln_portable(float x)
+{
+#pragma clang fp contract(off)
+    uint32_t u = __float_as_uint(x);
+    const int e = (int)(u >> 23) - 127;
+    u = (u & 0x007FFFFFu) | 0x3F800000u;
+    const float m = __uint_as_float(u);
+    const float s = (m - 1.0f) / (m + 1.0f), z = s * s;
+    const float poly = 1.0f + z * (0.33333334f + z * (0.2f + z * (0.14285715f + z * 0.11111111f)));
+    return (float)e * 0.6931472f + 2.0f * s * poly;
+}
+__device__ __forceinline__ float cull_qmax(float o)
+{
+#pragma clang fp contract(off)
+    return 2.0f * ln_portable(255.0f * o) * 1.001f + 0.001f;
+}
+struct CullRows { float px, py, B, det, invA, aq, ymax, ystar; int x0, x1; };          // x0, x1: the tightened rectangle's columns
+__device__ __forceinline__ void cull_rows_setup(CullRows& j, float px, float py, float A, float B, float C, float det, float qmax, int x0, int x1)
+{
+#pragma clang fp contract(off)
+    j.px = px; j.py = py; j.B = B; j.det = det; j.x0 = x0; j.x1 = x1;
+    j.invA = 1.0f / A; j.aq = A * qmax;
+    j.ymax = sqrtf(j.aq / det); j.ystar = -B * sqrtf(qmax / (C * det));
+}
+// tiles [t0, t1] of tile row ty; false when the row holds none.  (median of (v, lo, hi) == the oracle's v < lo ? lo : (v > hi ? hi : v) for
+// lo <= hi and finite v: a pure selection, one v_med3_f32)
+__device__ __forceinline__ bool cull_row_run(const CullRows& j, int ty, int& t0, int& t1)
+{
+#pragma clang fp contract(off)
+    const float Y0 = (float)(ty * 16) - j.py, Y1 = Y0 + 15.0f;
+    const float yb0 = Y0 > -j.ymax ? Y0 : -j.ymax, yb1 = Y1 < j.ymax ? Y1 : j.ymax;
+    if (yb0 > yb1) return false;
+    const float yu = __builtin_amdgcn_fmed3f(j.ystar, yb0, yb1), yl = __builtin_amdgcn_fmed3f(-j.ystar, yb0, yb1);
+    const float eu = j.aq - j.det * yu * yu, el = j.aq - j.det * yl * yl;
+    const float du = eu > 0.0f ? eu : 0.0f, dl = el > 0.0f ? el : 0.0f;
+    const float xhi = (-j.B * yu + sqrtf(du)) * j.invA, xlo = (-j.B * yl - sqrtf(dl)) * j.invA;
+    t0 = (int)ceilf((xlo - 0.01f + j.px - 15.0f) / 16.0f); t1 = (int)floorf((xhi + 0.01f + j.px) / 16.0f);
+    t0 = max(t0, j.x0); t1 = min(t1, j.x1 - 1);
+    return t1 >= t0;
+}
+
 // ---- diagnostic build only (-DIBGS_TRACE_WAVES, tools/wave_trace.py): where and when every wave of a blend kernel ran ----------------------
 // One stamp per workgroup: {HW_ID (wave slot, SIMD, CU, SE), XCC_ID, start, end} on the 100 MHz constant clock, which all XCDs share.  The
 // product build compiles none of this (no stamp executes in the real kernel: cdna_hip_programming.md, in-kernel stamps).
@@ -160,6 +207,13 @@ void set_error(const char* fmt, ...);
             return -IBGS_ERR_HIP;                                                         \
         }                                                                                 \
     } while (0)
+
+// ---- optional stage timing (api.hip; include/ibgs_rast.h: ibgs_timing_enable) ---------------------------------------------------
+struct StageTimer {   // RAII: records an event pair around one stage (or one kernel of it) when that stage is selected
+    hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int stage; bool on;
+    StageTimer(hipStream_t s_, int stage_);
+    ~StageTimer();
+};
 
 // ---- host launchers (one per stage) ---------------------------------------------------------
 struct Cam {          // camera block handed to kernels by value; matrices stay in device memory
@@ -304,7 +358,8 @@ void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatt
 // per-tile lists + tile ranges from the depth-ordered Gaussians (two-level binning, binning.hip); `cap` = capacity of point_list
 // part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
-                   const uint32_t* order_hint = nullptr, uint32_t* meta = nullptr /* meta[11] = 1 when the hint is a valid tile order */);
+                   const uint32_t* order_hint = nullptr, uint32_t* meta = nullptr /* meta[11] = 1 when the hint is a valid tile order */,
+                   int n_views = 1 /* batched depth views: P = n_views x instances, gy = n_views x rows */);
 constexpr int ORDER_CLASSES = 1024;          // SIMDs of the chip = classes of the balanced launch order (render_bwd.hip)
 int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
 

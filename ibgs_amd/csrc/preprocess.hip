@@ -54,46 +54,33 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(hi, ma
 // 2 ln(255 o).  Tiles of the reference rectangle whose pixel-centre box lies outside that ellipse
 // (0.1 % + 1e-3 margin, orders of magnitude above the fp32 rounding of `power` in the blend) are
 // never emitted: shorter lists, identical images and gradients.  Same arithmetic as
-// oracle/ibgs_oracle.c:tile_cull (basic IEEE ops only, so the masks agree bit for bit).
-__device__ __forceinline__ float ln_portable(float x)
-{
-    uint32_t u = __float_as_uint(x);
-    const int e = (int)(u >> 23) - 127;
-    u = (u & 0x007FFFFFu) | 0x3F800000u;
-    const float m = __uint_as_float(u);
-    const float s = (m - 1.0f) / (m + 1.0f), z = s * s;
-    const float poly = 1.0f + z * (0.33333334f + z * (0.2f + z * (0.14285715f + z * 0.11111111f)));
-    return (float)e * 0.6931472f + 2.0f * s * poly;
-}
-
-// median of (v, lo, hi) == the oracle's v < lo ? lo : (v > hi ? hi : v) for lo <= hi and finite v: a pure selection, so the
-// values (and the masks) stay bit-identical; one v_med3_f32 instead of two compare + select pairs
-__device__ __forceinline__ float clampf_(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
-
-// What the row loop of one Gaussian needs (oracle/ibgs_oracle.c: tile_cull, same operations in the same order).
-struct CullJob { float px, py, A, B, C, det, qmax; int x0, y0, w, h; };
+// oracle/ibgs_oracle.c:tile_cull (basic IEEE ops only, so the masks agree bit for bit); the row-wise
+// test itself lives in common.h (cull_rows_setup / cull_row_run) because the binning recomputes it for
+// rectangles that are too large for a mask.
+struct CullJob { CullRows rows; int y0, w, h; };
 enum { CULL_NONE = 0, CULL_AABB = 1, CULL_ROWS = 2 };
 
 // Tightens the rectangle to the ellipse's extent and decides how its tiles are tested: CULL_NONE (nothing can pass: no tiles),
-// CULL_AABB (more than IBGS_CULL_MAX_TILES tiles, or a degenerate / near-singular conic: keep the whole rectangle), CULL_ROWS (the owning
-// lane walks the tile rows).
+// CULL_AABB (a degenerate / near-singular conic: keep the whole rectangle), CULL_ROWS (the tile rows are walked: by the owning lane when
+// there are few, by the whole wave when there are many; rectangles of more than IBGS_CULL_MAX_TILES tiles only count their tiles
+// here -- mask words all zero -- and the binning recomputes the runs).
 __device__ __forceinline__ int cull_setup(float px, float py, float sxx, float syy, float A, float B, float C, float o,
                                           int& x0, int& y0, int& x1, int& y1, CullJob& j)
 {
     if (conic_is_risky(A, B, C)) return CULL_AABB;          // near-singular conic: the margin below is not sized for its rounding (common.h); keep the reference rectangle
     const float x255 = 255.0f * o;
     if (!(x255 >= 1.0f)) { x1 = x0; y1 = y0; return CULL_NONE; }
-    const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
+    const float qmax = cull_qmax(o);
     const float hx = sqrtf(qmax * sxx), hy = sqrtf(qmax * syy);
     int tx0 = (int)ceilf((px - hx - 15.0f) / 16.0f), tx1 = (int)floorf((px + hx) / 16.0f) + 1;
     int ty0 = (int)ceilf((py - hy - 15.0f) / 16.0f), ty1 = (int)floorf((py + hy) / 16.0f) + 1;
     tx0 = max(tx0, x0); tx1 = min(tx1, x1); ty0 = max(ty0, y0); ty1 = min(ty1, y1);
     if (tx1 <= tx0 || ty1 <= ty0) { x1 = x0; y1 = y0; return CULL_NONE; }
     x0 = tx0; x1 = tx1; y0 = ty0; y1 = ty1;
-    const int w = tx1 - tx0, h = ty1 - ty0;
     const float det = A * C - B * B;
-    if (w * h > IBGS_CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return CULL_AABB;
-    j.px = px; j.py = py; j.A = A; j.B = B; j.C = C; j.det = det; j.qmax = qmax; j.x0 = tx0; j.y0 = ty0; j.w = w; j.h = h;
+    if (!(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return CULL_AABB;
+    cull_rows_setup(j.rows, px, py, A, B, C, det, qmax, tx0, tx1);
+    j.y0 = ty0; j.w = tx1 - tx0; j.h = ty1 - ty0;
     return CULL_ROWS;
 }
 
@@ -107,30 +94,20 @@ __device__ __forceinline__ void set_run(uint64_t (&m)[IBGS_CULL_WORDS], int star
     }
 }
 
-// Row by row (see the oracle for the derivation): inside the band of pixel centres of one tile row the ellipse q <= qmax is convex, so
-// the tiles it reaches there are one run of consecutive tiles, bounded by the x-range of the ellipse over the band -- whose ends sit at
-// y* = -B sqrt(qmax / (C det)) (upper) and -y* (lower), clamped into the band.  ~30 operations per row instead of ~50 per tile.
+// The owning lane walks the rows (few rows): tile count, and the mask unless the rectangle is too large for one.
 __device__ __forceinline__ uint32_t cull_rows(const CullJob& j, uint64_t (&m)[IBGS_CULL_WORDS])
 {
-    const float A = j.A, B = j.B, C = j.C, det = j.det, qmax = j.qmax;
-    const float invA = 1.0f / A, aq = A * qmax;
-    const float ymax = sqrtf(aq / det), ystar = -B * sqrtf(qmax / (C * det));
+    const bool masked = j.w * j.h <= IBGS_CULL_MAX_TILES;
     uint32_t cnt = 0;
     for (int r = 0; r < j.h; r++) {
-        const int ty = j.y0 + r;
-        const float Y0 = (float)(ty * 16) - j.py, Y1 = Y0 + 15.0f;
-        const float yb0 = Y0 > -ymax ? Y0 : -ymax, yb1 = Y1 < ymax ? Y1 : ymax;
-        if (yb0 > yb1) continue;
-        const float yu = clampf_(ystar, yb0, yb1), yl = clampf_(-ystar, yb0, yb1);
-        const float eu = aq - det * yu * yu, el = aq - det * yl * yl;
-        const float du = eu > 0.0f ? eu : 0.0f, dl = el > 0.0f ? el : 0.0f;
-        const float xhi = (-B * yu + sqrtf(du)) * invA, xlo = (-B * yl - sqrtf(dl)) * invA;
-        int t0 = (int)ceilf((xlo - 0.01f + j.px - 15.0f) / 16.0f), t1 = (int)floorf((xhi + 0.01f + j.px) / 16.0f);
-        t0 = max(t0, j.x0); t1 = min(t1, j.x0 + j.w - 1);
-        if (t1 >= t0) { set_run(m, r * j.w + (t0 - j.x0), t1 - t0 + 1); cnt += (uint32_t)(t1 - t0 + 1); }
+        int t0, t1;
+        if (!cull_row_run(j.rows, j.y0 + r, t0, t1)) continue;
+        if (masked) set_run(m, r * j.w + (t0 - j.rows.x0), t1 - t0 + 1);
+        cnt += (uint32_t)(t1 - t0 + 1);
     }
     return cnt;
 }
+constexpr int CULL_COOP_ROWS = 16;          // rectangles taller than this are walked by the whole wave, one row per lane
 
 // One thread per Gaussian. The AoS inputs (12..192 B per Gaussian) are read with plain per-lane
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
@@ -153,7 +130,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     int radius = 0; uint32_t ntiles = 0; uint32_t rx = 0, ry = 0; float depth = 0.f; uint8_t clampbits = 0;
     uint64_t tmask[IBGS_CULL_WORDS] = {0, 0, 0, 0};
-    CullJob job; int cull_mode = CULL_NONE; bool big_rect = false;
+    bool tall = false, big_rect = false;
     float c6loc[6] = {0, 0, 0, 0, 0, 0};
 
     const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
@@ -234,15 +211,17 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
 #pragma unroll
                 for (int k = 0; k < IBGS_CULL_WORDS; k++) tmask[k] = ~0ull;
                 if (p.cull) {
-                    cull_mode = cull_setup(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, job);
+                    CullJob job;
+                    const int cull_mode = cull_setup(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, job);
                     if (cull_mode == CULL_NONE) { ntiles = 0; tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull; }
                     else if (cull_mode == CULL_AABB) ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-                    else {          // CULL_ROWS
+                    else {          // CULL_ROWS (tall rectangles: the whole wave walks them, below)
                         tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull;
-                        ntiles = cull_rows(job, tmask);
+                        tall = job.h > CULL_COOP_ROWS;
+                        if (!tall) ntiles = cull_rows(job, tmask);
                     }
                 }
-                big_rect = (x1 - x0) * (y1 - y0) > 64;
+                big_rect = (x1 - x0) * (y1 - y0) > 64 && (x1 - x0) * (y1 - y0) <= IBGS_CULL_MAX_TILES;          // mask words 1..3 in use
                 rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
                 depth = zview;
                 rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
@@ -325,7 +304,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
 #pragma unroll
         for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
     }
-
     {   // the 64-byte records leave through LDS: a lane storing its own record spreads every store instruction over 64 lines; transposed, the
         // wave writes its 4 KB as four fully coalesced 1 KB stores
         const int lane = threadIdx.x & 63;
@@ -340,6 +318,51 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
             if (row < nrow) out[q] = s_stage[row * 5 + (q & 3)];
         }
     }
+    // Tall rectangles (more than CULL_COOP_ROWS tile rows: the heavy tail of a trained scene, a per cent or two of its Gaussians) are walked by
+    // the WHOLE WAVE, one row per lane, Gaussian after Gaussian: a lane walking 68 rows on its own keeps the other 63 waiting (~150
+    // instructions per row with IEEE square roots and divisions).  Same runs, same masks: cull_row_run does not know who calls it.
+    {
+        const int lane = threadIdx.x & 63;
+        uint64_t todo = __ballot(valid && alive && tall);
+        while (todo != 0ull) {          // wave-uniform
+            const int g = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            // the job is rebuilt from the owner's record and rectangle (values that are live anyway; the same operations on the same numbers
+            // as in cull_setup) instead of being carried in eleven registers through the rest of the kernel; the record itself is dead by now
+            const float4 gq0 = s_stage[g * 5], gq1 = s_stage[g * 5 + 1];          // the owner's record, still parked in LDS from the transpose above
+            const float gpx = gq0.x, gpy = gq0.y, go = gq0.z, gA = gq1.x, gB = gq1.y, gC = gq1.z;
+            const uint32_t grx = (uint32_t)__builtin_amdgcn_readlane((int)rx, g), gry = (uint32_t)__builtin_amdgcn_readlane((int)ry, g);
+            CullJob u;
+            cull_rows_setup(u.rows, gpx, gpy, gA, gB, gC, gA * gC - gB * gB, cull_qmax(go), (int)(grx & 0xFFFFu), (int)(grx >> 16));
+            u.y0 = (int)(gry & 0xFFFFu) - p.tile_row0; u.w = (int)(grx >> 16) - (int)(grx & 0xFFFFu); u.h = (int)(gry >> 16) - (int)(gry & 0xFFFFu);
+            const bool masked = u.w * u.h <= IBGS_CULL_MAX_TILES;
+            uint64_t m[IBGS_CULL_WORDS] = {0, 0, 0, 0};
+            uint32_t cnt = 0;
+            for (int r = lane; r < u.h; r += 64) {
+                int t0, t1;
+                if (!cull_row_run(u.rows, u.y0 + r, t0, t1)) continue;
+                if (masked) set_run(m, r * u.w + (t0 - u.rows.x0), t1 - t0 + 1);
+                cnt += (uint32_t)(t1 - t0 + 1);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
+            if (masked) {          // wave-uniform
+#pragma unroll
+                for (int k = 0; k < IBGS_CULL_WORDS; k++) {
+                    uint32_t lo = (uint32_t)m[k], hi = (uint32_t)(m[k] >> 32);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d, 64); hi |= (uint32_t)__shfl_xor((int)hi, d, 64); }
+                    m[k] = ((uint64_t)hi << 32) | lo;
+                }
+            }
+            if (lane == g) {
+                ntiles = cnt;
+#pragma unroll
+                for (int k = 0; k < IBGS_CULL_WORDS; k++) tmask[k] = m[k];
+            }
+        }
+    }
+
     if (p.alive64) {          // (a full-wave ballot: lanes past the end are still here)
         const uint64_t am = __ballot(valid && alive && ntiles > 0);
         if ((threadIdx.x & 63) == 0) p.alive64[gi >> 6] = am;

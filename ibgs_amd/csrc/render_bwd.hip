@@ -750,7 +750,8 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         // 8x8 quadrant on small ones
         const bool big = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
         if (!geo_tab) { set_error("geo backward needs the window table scratch"); return -IBGS_ERR_INVALID; }
-        hipLaunchKernelGGL(geo_window_kernel, dim3((unsigned)(((size_t)a.W * a.H + 255) / 256)), dim3(256), 0, s, p);
+        { StageTimer t(s, IBGS_STAGE_GEO_WINDOW);
+          hipLaunchKernelGGL(geo_window_kernel, dim3((unsigned)(((size_t)a.W * a.H + 255) / 256)), dim3(256), 0, s, p); }
         IBGS_HIP(hipGetLastError());
         // the geo kernel holds four waves per SIMD: 4 096 slots for a 1080p frame's 8 160 tiles, so the second half of the launch starts as slots
         // free up -- a queue, which wants the heaviest tiles first (plain descending order; slot_rounds = 4 makes the order kernel choose it).  That
@@ -759,14 +760,19 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         static const int geo_balanced = getenv("IBGS_BWD_GEO_BALANCED") ? atoi(getenv("IBGS_BWD_GEO_BALANCED")) : 1;
         if (big && geo_balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out);
+            { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
+              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
             p.order = im.tile_order;
+            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
-        } else
-        if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, grid(1), dim3(64), 0, s, p);
-        else hipLaunchKernelGGL(render_bwd_geo_kernel, grid(4), dim3(64), 0, s, p);
+        } else {
+            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
+            if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, grid(1), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(render_bwd_geo_kernel, grid(4), dim3(64), 0, s, p);
+        }
     } else {
         if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {
+            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             hipLaunchKernelGGL(render_bwd_color_small_kernel, grid(4), dim3(64), 0, s, p);
             IBGS_HIP(hipGetLastError());
             return 0;
@@ -774,14 +780,17 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         static const int balanced = getenv("IBGS_BWD_BALANCED") ? atoi(getenv("IBGS_BWD_BALANCED")) : 1;
         if (balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order, a.tile_order_out);
+            { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
+              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
             IBGS_HIP(hipGetLastError());
             p.order = im.tile_order;
+            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
             IBGS_HIP(hipGetLastError());
             return 0;
         }
         static const int pad_lds = getenv("IBGS_BWD_PAD_LDS") ? atoi(getenv("IBGS_BWD_PAD_LDS")) : 0;      // experiments: dynamic LDS that nobody uses = fewer waves per SIMD
+        StageTimer t(s, IBGS_STAGE_RENDER_BWD);
         hipLaunchKernelGGL(render_bwd_color_kernel, grid(1), dim3(64), pad_lds, s, p);
     }
     IBGS_HIP(hipGetLastError());

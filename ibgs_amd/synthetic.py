@@ -79,7 +79,7 @@ def quat_to_rotmat(q):
     return Rm
 
 
-def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1.3, anisotropy=None):
+def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1.3, anisotropy=None, scale_sigma=0.0, cluster=0.0):
     """Random-init Gaussians.  Returns fp32 arrays: xyz (P,3), shs (P,Mc,3), scales (P,3) [activated],
     rotations (P,4) [normalised], opacities (P,1) [activated].
 
@@ -89,7 +89,13 @@ def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1
                  footprints stay comparable -- seen edge-on these project to ellipses of aspect up to ~100:1;
       "needle" = one random axis stretched 30x, the other two shrunk 3x (long thin splats);
       "mixed"  = a third of each.
-    The extra draws come from their own generator, so the other arrays do not depend on the mode."""
+    scale_sigma: > 0 = a heavy tail of sizes, what densification leaves behind (scene/gaussian_model.py:580-604 clones / splits by gradient
+      and prunes by size only every few hundred steps): every Gaussian's three scales are multiplied by exp(N(0, sigma^2) - 1.5 sigma^2), a
+      log-normal factor -- most Gaussians shrink (median factor e^(-1.5 sigma^2) = 0.22 at sigma = 1; the mean footprint area falls by
+      e^(-sigma^2)), a per cent or two grow several-fold and cover hundreds of tiles.  At sigma = 1 the C3-sized plane scene keeps about as
+      many (Gaussian, tile) pairs as the near-isotropic one has (10.7 M against 12.4 M), a third of them from 0.8 % of the Gaussians;
+    cluster: > 0 = this fraction of the Gaussians (the first ones) moved into one blob of 0.3 x the extent around (0.5, 0.25, 0) -- an uneven image.
+    The extra draws come from their own generators, so the other arrays do not depend on the mode."""
     rng = np.random.default_rng(seed)
     xyz = rng.uniform(-extent, extent, size=(P, 3)).astype(np.float32)
     rgb = rng.uniform(0.0, 1.0, size=(P, 3)).astype(np.float32)
@@ -110,6 +116,12 @@ def make_gaussians(P, seed, sh_degree=3, max_coeffs=16, opacity="init", extent=1
         f[pl] = 1.6; f[rows[pl], axis[pl]] = flat[pl]
         f[nd] = 1.0 / 3.0; f[rows[nd], axis[nd]] = 30.0
         scales = (scales * f).astype(np.float32)
+    if scale_sigma > 0:
+        srng = np.random.default_rng(2_000_003 + seed)
+        scales = (scales * np.exp(srng.normal(0.0, scale_sigma, size=(P, 1)) - 1.5 * scale_sigma * scale_sigma)).astype(np.float32)
+    if cluster > 0:
+        k = int(cluster * P)
+        xyz[:k] = xyz[:k] * 0.3 + np.array([0.5, 0.25, 0.0], np.float32)
     q = rng.normal(0.0, 1.0, size=(P, 4))
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
     if opacity == "init":
@@ -173,9 +185,9 @@ CONFIGS = {
 }
 
 
-def make_scene(P, W, H, sh_degree=3, seed=1, view=0, opacity="init", with_planes=False, anisotropy=None):
+def make_scene(P, W, H, sh_degree=3, seed=1, view=0, opacity="init", with_planes=False, anisotropy=None, scale_sigma=0.0, cluster=0.0):
     """Oracle-style input dict for one view (colour path; see make_geo_inputs for the geo path)."""
-    g = make_gaussians(P, seed, sh_degree=sh_degree, opacity=opacity, anisotropy=anisotropy)
+    g = make_gaussians(P, seed, sh_degree=sh_degree, opacity=opacity, anisotropy=anisotropy, scale_sigma=scale_sigma, cluster=cluster)
     cam = make_camera(W, H, azimuth_deg=45.0 * view)
     inp = dict(g)
     inp.update({

@@ -347,9 +347,11 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name);
 #define IBGS_STAGE_TILE_SORT 4    /* two-level binning, part 2: Gaussian ids to their list slots */
 #define IBGS_STAGE_RANGES 5       /* (no kernel of its own any more) */
 #define IBGS_STAGE_RENDER_FWD 6
-#define IBGS_STAGE_RENDER_BWD 7
+#define IBGS_STAGE_RENDER_BWD 7    /* the backward's blend kernel alone (render_bwd_color_kernel / render_bwd_geo*_kernel) */
 #define IBGS_STAGE_PREPROCESS_BWD 8
-#define IBGS_NUM_STAGES 9
+#define IBGS_STAGE_GEO_WINDOW 9    /* render_geo backward: the pixel-parallel window pass in front of the blend kernel */
+#define IBGS_STAGE_TILE_ORDER 10   /* the backward's launch-order kernel (+ the deterministic mode's slab reduction) */
+#define IBGS_NUM_STAGES 11
 void ibgs_timing_enable(uint32_t stage_mask);   /* bit i = time stage i; 0 disables */
 int32_t ibgs_timing_collect(float* ms /* IBGS_NUM_STAGES */, int32_t* launches /* IBGS_NUM_STAGES */);
 

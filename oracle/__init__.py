@@ -174,7 +174,8 @@ def forward(inp, tex_quant=False, cull=False):
                      _p(st["conic_opacity"]), _p(st["tiles_touched"]), _p(st["clamped"]), _p(st["rect4"]), _p(st["tmask"]))
     R = int(L.orc_bin_count(_ci(P), _p(st["tiles_touched"])))
     st["keys"] = np.zeros(R, np.uint64); st["point_list"] = np.zeros(R, np.uint32)
-    rc = L.orc_bin(_ci(P), ctypes.c_int64(R), _p(st["radii"]), _p(st["rect4"]), _p(st["tmask"]), _p(st["depths"]), _ci(W), _ci(H),
+    rc = L.orc_bin(_ci(P), ctypes.c_int64(R), _p(st["radii"]), _p(st["rect4"]), _p(st["tmask"]), _p(st["depths"]),
+                   _p(st["means2D"]), _p(st["conic_opacity"]), _ci(W), _ci(H),
                    _p(st["keys"]), _p(st["point_list"]), _p(st["ranges"]))
     assert rc == 0, "oracle binning failed (%d)" % rc
     feats = colors_precomp if colors_precomp is not None else st["rgb"]

@@ -190,9 +190,41 @@ static inline int conic_is_risky(float A, float B, float C) { return B * B > 0.9
 static long long g_power_skips[2] = {0, 0};
 void orc_power_skips(long long* out) { out[0] = g_power_skips[0]; out[1] = g_power_skips[1]; }
 
+/* Row by row: the part of the ellipse q <= qmax inside the band of pixel centres y in [Y0, Y1] of one tile row is convex, so the tiles it
+ * reaches in that row are those whose centre box [16 tx, 16 tx + 15] meets its x-range -- one run of consecutive tiles.  For a fixed y
+ * the ellipse spans x = (-B y -+ sqrt(A qmax - det y^2)) / A; the upper end is concave in y with its maximum at
+ * y* = -B sqrt(qmax / (C det)) (the lower end at -y*), so over the band the extremes sit at y* clamped into the band.
+ * ~30 operations per ROW instead of ~50 per tile; the same tiles as a closest-point test per tile, up to the 0.01 px slack below.
+ * (ibgs_amd/csrc/common.h: CullRows / cull_rows_setup / cull_row_run -- the same operations in the same order.) */
+typedef struct { float px, py, B, det, invA, aq, ymax, ystar; int x0, x1; } CullRows;
+static void cull_rows_setup(CullRows* j, float px, float py, float A, float B, float C, float det, float qmax, int x0, int x1)
+{
+    j->px = px; j->py = py; j->B = B; j->det = det; j->x0 = x0; j->x1 = x1;
+    j->invA = 1.0f / A; j->aq = A * qmax;
+    j->ymax = sqrtf(j->aq / det); j->ystar = -B * sqrtf(qmax / (C * det));
+}
+/* tiles [*t0, *t1] of tile row ty (inside the tightened rectangle's columns [x0, x1)); returns 0 when the row holds none */
+static int cull_row_run(const CullRows* j, int ty, int* t0_out, int* t1_out)
+{
+    const float Y0 = (float)(ty * 16) - j->py, Y1 = Y0 + 15.0f;
+    const float yb0 = fmaxf_(Y0, -j->ymax), yb1 = fminf_(Y1, j->ymax);
+    if (yb0 > yb1) return 0;
+    const float yu = clampf_(j->ystar, yb0, yb1), yl = clampf_(-j->ystar, yb0, yb1);
+    const float du = fmaxf_(j->aq - j->det * yu * yu, 0.0f), dl = fmaxf_(j->aq - j->det * yl * yl, 0.0f);
+    const float xhi = (-j->B * yu + sqrtf(du)) * j->invA, xlo = (-j->B * yl - sqrtf(dl)) * j->invA;
+    int t0 = (int)ceilf((xlo - 0.01f + j->px - 15.0f) / 16.0f), t1 = (int)floorf((xhi + 0.01f + j->px) / 16.0f);
+    t0 = imax(t0, j->x0); t1 = imin(t1, j->x1 - 1);
+    *t0_out = t0; *t1_out = t1;
+    return t1 >= t0;
+}
+static inline float cull_qmax(float o) { return 2.0f * ln_portable(255.0f * o) * 1.001f + 0.001f; }
+
 /* In: pixel centre, cov2D diagonal (with the 0.3), conic, opacity, reference rectangle.
- * Out: tightened rectangle, bit mask of surviving tiles (row-major inside the tightened rectangle,
- * CULL_WORDS x 64 bits, only when it has <= CULL_MAX_TILES tiles; otherwise every tile of it survives). Returns the tile count. */
+ * Out: tightened rectangle and which of its tiles survive:
+ *   <= CULL_MAX_TILES tiles: a bit mask (row-major inside the tightened rectangle, CULL_WORDS x 64 bits);
+ *   more tiles: mask all ZERO = "the row runs decide" (orc_bin recomputes cull_row_run per tile row: rectangles of any size are culled),
+ *               mask all ONES = every tile of the rectangle survives (near-singular or degenerate conics; cull = 0).
+ * Returns the tile count. */
 #define CULL_WORDS 4
 #define CULL_MAX_TILES (64 * CULL_WORDS)
 static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, float B, float C, float o,
@@ -202,7 +234,7 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
     if (conic_is_risky(A, B, C)) return (uint32_t)((*x1 - *x0) * (*y1 - *y0));      /* keeps the reference rectangle, every tile of it */
     const float x255 = 255.0f * o;
     if (!(x255 >= 1.0f)) { *x1 = *x0; *y1 = *y0; for (int k = 0; k < CULL_WORDS; k++) mask[k] = 0; return 0; }
-    const float qmax = 2.0f * ln_portable(x255) * 1.001f + 0.001f;
+    const float qmax = cull_qmax(o);
     const float hx = sqrtf(qmax * sxx), hy = sqrtf(qmax * syy);
     int tx0 = (int)ceilf((px - hx - 15.0f) / 16.0f), tx1 = (int)floorf((px + hx) / 16.0f) + 1;
     int ty0 = (int)ceilf((py - hy - 15.0f) / 16.0f), ty1 = (int)floorf((py + hy) / 16.0f) + 1;
@@ -211,27 +243,18 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
     *x0 = tx0; *x1 = tx1; *y0 = ty0; *y1 = ty1;
     const int w = tx1 - tx0, h = ty1 - ty0;
     const float det = A * C - B * B;
-    if (w * h > CULL_MAX_TILES || !(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return (uint32_t)(w * h);
+    if (!(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return (uint32_t)(w * h);
+    const int big = w * h > CULL_MAX_TILES;
     uint64_t m[CULL_WORDS] = {0, 0, 0, 0}; uint32_t cnt = 0;
-    /* Row by row: the part of the ellipse inside the band of pixel centres y in [Y0, Y1] of one tile row is convex, so the tiles it
-     * reaches in that row are those whose centre box [16 tx, 16 tx + 15] meets its x-range -- one run of consecutive tiles.  For a fixed y
-     * the ellipse spans x = (-B y -+ sqrt(A qmax - det y^2)) / A; the upper end is concave in y with its maximum at
-     * y* = -B sqrt(qmax / (C det)) (the lower end at -y*), so over the band the extremes sit at y* clamped into the band.
-     * ~30 operations per ROW instead of ~50 per tile; the same tiles as a closest-point test per tile, up to the 0.01 px slack below. */
-    const float invA = 1.0f / A, aq = A * qmax;
-    const float ymax = sqrtf(aq / det), ystar = -B * sqrtf(qmax / (C * det));
+    CullRows j;
+    cull_rows_setup(&j, px, py, A, B, C, det, qmax, tx0, tx1);
     for (int ty = ty0; ty < ty1; ty++) {
-        const float Y0 = (float)(ty * 16) - py, Y1 = Y0 + 15.0f;
-        const float yb0 = fmaxf_(Y0, -ymax), yb1 = fminf_(Y1, ymax);
-        if (yb0 > yb1) continue;
-        const float yu = clampf_(ystar, yb0, yb1), yl = clampf_(-ystar, yb0, yb1);
-        const float du = fmaxf_(aq - det * yu * yu, 0.0f), dl = fmaxf_(aq - det * yl * yl, 0.0f);
-        const float xhi = (-B * yu + sqrtf(du)) * invA, xlo = (-B * yl - sqrtf(dl)) * invA;
-        int t0 = (int)ceilf((xlo - 0.01f + px - 15.0f) / 16.0f), t1 = (int)floorf((xhi + 0.01f + px) / 16.0f);
-        t0 = imax(t0, tx0); t1 = imin(t1, tx1 - 1);
-        for (int tx = t0; tx <= t1; tx++) { const int bit = (ty - ty0) * w + (tx - tx0); m[bit >> 6] |= 1ull << (bit & 63); cnt++; }
+        int t0, t1;
+        if (!cull_row_run(&j, ty, &t0, &t1)) continue;
+        cnt += (uint32_t)(t1 - t0 + 1);
+        if (!big) for (int tx = t0; tx <= t1; tx++) { const int bit = (ty - ty0) * w + (tx - tx0); m[bit >> 6] |= 1ull << (bit & 63); }
     }
-    for (int k = 0; k < CULL_WORDS; k++) mask[k] = m[k];
+    for (int k = 0; k < CULL_WORDS; k++) mask[k] = m[k];          /* big: all zero = "rows decide" */
     return cnt;
 }
 
@@ -342,6 +365,7 @@ int64_t orc_bin_count(int P, const uint32_t* tiles_touched)
 }
 
 int orc_bin(int P, int64_t R, const int32_t* radii, const int32_t* rect4, const uint64_t* tmask, const float* depths,
+            const float* means2D, const float* conic_opacity /* rectangles above CULL_MAX_TILES tiles whose mask is zero: the row runs are recomputed */,
             int W, int H, uint64_t* keys_sorted, uint32_t* point_list, uint32_t* ranges /* tiles*2 */)
 {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
@@ -358,11 +382,24 @@ int orc_bin(int P, int64_t R, const int32_t* radii, const int32_t* rect4, const 
         const int x0 = rect4[4 * i], y0 = rect4[4 * i + 1], x1 = rect4[4 * i + 2], y1 = rect4[4 * i + 3];
         const int w = x1 - x0, dense = (w * (y1 - y0) > CULL_MAX_TILES);
         uint32_t dbits; memcpy(&dbits, depths + i, 4);
+        if (dense && tmask[CULL_WORDS * i] == 0ull) {          /* culled row by row (tile_cull): the same runs, recomputed */
+            const float A = conic_opacity[4 * i], B = conic_opacity[4 * i + 1], C = conic_opacity[4 * i + 2];
+            CullRows j;
+            cull_rows_setup(&j, means2D[2 * i], means2D[2 * i + 1], A, B, C, A * C - B * B, cull_qmax(conic_opacity[4 * i + 3]), x0, x1);
+            for (int y = y0; y < y1; y++) {
+                int t0, t1;
+                if (!cull_row_run(&j, y, &t0, &t1)) continue;
+                for (int x = t0; x <= t1; x++) {
+                    if (off < R) { k0[off] = ((uint64_t)(y * gx + x) << 32) | dbits; v0[off] = (uint32_t)i; }
+                    off++;
+                }
+            }
+            continue;
+        }
         for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
             const int bit = (y - y0) * w + (x - x0);
             if (!dense && !((tmask[CULL_WORDS * i + (bit >> 6)] >> (bit & 63)) & 1ull)) continue;
-            k0[off] = ((uint64_t)(y * gx + x) << 32) | dbits;
-            v0[off] = (uint32_t)i;
+            if (off < R) { k0[off] = ((uint64_t)(y * gx + x) << 32) | dbits; v0[off] = (uint32_t)i; }
             off++;
         }
     }
