@@ -397,7 +397,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         const float4* rgba = nullptr;
         if (a.render_geo) {
             float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
-            if ((rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
+            if (!(a.flags & IBGS_FLAG_TEX_PACKED) && (rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
             rgba = t;
         }
         { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }

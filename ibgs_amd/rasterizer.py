@@ -15,6 +15,7 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 HIP library.  If the library is missing the import of ``_lib`` raises -- there is no fallback.
 """
 import ctypes
+import os
 from typing import NamedTuple
 
 import torch
@@ -108,7 +109,7 @@ ORDER_HINT = True
 # ... for geo passes as well: their forward runs two waves per tile behind a queue and would take the heaviest tile first.  Off by default: that
 # forward lives on the 8 x 8 block map's L2 locality (source texels), and giving it up costs more than the balance brings on even scenes
 # (C3-geo forward 0.668 -> 0.716 ms, trained 0.375 -> 0.398 ms; half of the Gaussians in one blob: 0.751 -> 0.677 ms)
-ORDER_HINT_GEO = False
+ORDER_HINT_GEO = os.environ.get("IBGS_ORDER_HINT_GEO", "0") == "1"          # (the environment switch is for A/B runs: tools/ab_env.sh)
 ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p)
 _order_hints = {}
 
@@ -171,13 +172,34 @@ def _tex(device, nbytes, what="tex"):
 _tex_writes = [0]
 
 
-def _tex_packed(device, nbytes):
+def _tex_packed(device, nbytes, source=None):
     """The per-stream scratch that receives the packed source RGBA (T1), plus a ticket that names this pack: a later call that
-    holds the ticket and finds it still current (`_tex_still(ticket)`) knows that nothing overwrote the buffer in between."""
+    holds the ticket and finds it still current (`_tex_still(ticket)`) knows that nothing overwrote the buffer in between.
+    `source` = (tensor, its version counter, n, W, H): what is being packed (see _tex_cached)."""
     buf = _tex(device, nbytes)
     _tex_writes[0] += 1
     buf._ibgs_ticket = _tex_writes[0]
+    buf._ibgs_src = source
     return buf, (_stream_key(device) + ("tex",), _tex_writes[0], nbytes)
+
+
+# T1 once per SOURCE SET instead of once per call (SURVEY 8(a) row T1: "build replaces with a cached packed buffer"; the reference packs,
+# allocates and synchronises per forward AND per backward, rasterizer_impl.cu:366, 582).  When a forward is handed the very tensor object
+# whose pack still sits in this stream's scratch -- same object, same version counter (no in-place write since), same n / W / H -- the pack
+# kernel is skipped (IBGS_FLAG_TEX_PACKED).  The scratch keeps a reference to that tensor, so its memory cannot be recycled for another
+# image stack behind the cache's back; a fresh `torch.stack(...)` per call is a different object and packs again.  TEX_CACHE = False: always pack.
+TEX_CACHE = True
+
+
+def _tex_cached(device, nbytes, source):
+    if not TEX_CACHE:
+        return None
+    key = _stream_key(device) + ("tex",)
+    buf = _tex_scratch.get(key)
+    had = getattr(buf, "_ibgs_src", None) if buf is not None else None
+    if had is None or buf.numel() < nbytes or had[0] is not source[0] or had[1:] != source[1:]:
+        return None
+    return buf, (key, buf._ibgs_ticket, nbytes)
 
 
 def _tex_still(ticket, device, nbytes):
@@ -321,8 +343,7 @@ class _CModule:
                 a.ref_to_src = _ptr(r2s_c); a.src_cam_pos = _ptr(scp_c); a.src_images = _ptr(simg_c); a.src_depths = _ptr(sdep_c)
                 a.buffer_length = int(buffer_length); a.depth_error_threshold = float(depth_error_threshold)
                 a.prefiltered = int(bool(prefiltered)); a.render_geo = int(render_geo); a.render_depth_only = int(render_depth_only)
-                a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL) | _shape_flag())
+                tex_flag = 0
                 a.geom = geomBuffer.data_ptr(); a.geom_bytes = geomBuffer.numel()
                 a.img = imgBuffer.data_ptr(); a.img_bytes = imgBuffer.numel()
                 a.binning_alloc = cb; a.binning_user = None
@@ -334,8 +355,16 @@ class _CModule:
                     # the packed RGBA of the sources goes to the per-stream scratch; the ticket lets the backward of this call
                     # skip its own pack when no other geo call used the scratch in between (the training loop's normal case)
                     nbytes = lib.ibgs_required_tex(int(nb_src_images), W, H)
-                    tex, _CModule.last_tex = _tex_packed(device, nbytes)
+                    source = (src_images, getattr(src_images, "_version", None), int(nb_src_images), W, H)
+                    hit = _tex_cached(device, nbytes, source)
+                    if hit is not None:
+                        tex, _CModule.last_tex = hit
+                        tex_flag = _lib.FLAG_TEX_PACKED          # this stream's scratch still holds the pack of this very image stack
+                    else:
+                        tex, _CModule.last_tex = _tex_packed(device, nbytes, source)
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
+                a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
+                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL) | _shape_flag() | tex_flag)
                 a.out_color = out_color.data_ptr() if write_color else None
                 a.radii = radii.data_ptr()
                 if render_geo:

@@ -72,8 +72,9 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                        sequentially in that order (SURVEY 7.2 "alternative without atomics"; replaces the atomicAdds of
                                        backward.cu:673, 770, 793-804).  Gradients are then bit-identical from run to run; they differ from
                                        the default mode only in summation order.  Needs det_scratch.  For CI, ~0.7 ms slower at C3. */
-#define IBGS_FLAG_TEX_PACKED 256u /* ibgs_backward only: `tex` still holds the packed RGBA that the ibgs_forward of this very call pair wrote
-                                     (the caller kept the buffer for the autograd node instead of sharing one scratch): skip the re-pack */
+#define IBGS_FLAG_TEX_PACKED 256u /* `tex` already holds the packed RGBA of exactly these src_images -- ibgs_backward: the ibgs_forward of this call pair wrote it
+                                     and nothing touched the buffer since; ibgs_forward: an earlier call packed the same, unmodified image stack
+                                     (a trainer's source images do not change between steps) -- skip the pack (T1 once per source set) */
 #define IBGS_FLAG_SH_FACTORED 16u /* ibgs_backward only, view-parallel training: dL/dsh of ONE view is the outer product
                                      basis(dir) x dL/dRGB (backward.cu:114-160), so leave dL_dsh unwritten (may be NULL) and
                                      write the clamp-masked dL/dRGB (P x 3) to dL_dcolors; after the ranks exchanged those

@@ -20,6 +20,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libibgs_oracle.so")
 _SO_FMA = os.path.join(_HERE, "_build", "libibgs_oracle_fma.so")
+_SO_F64 = os.path.join(_HERE, "_build", "libibgs_oracle_f64.so")
+_RT = np.float32          # element type of the float arrays at the C interface: float32, float64 inside `variant("f64")`
 _SRC = os.path.join(_HERE, "ibgs_oracle.c")
 _lib = None
 _libs = {}
@@ -31,9 +33,11 @@ def build(force=False):
     """Compile the C oracle with gcc (a few seconds).  Two builds of the same source: the oracle proper (no fused multiply-adds, IEEE
     operation by operation) and a variant in which gcc contracts a*b+c into fma wherever it likes (`variant("fma")`).  nvcc contracts too
     (-fmad=true is its default) in a pattern that cannot be known here, so the difference between the two builds is the size of what
-    the reference's own arithmetic leaves undetermined -- tests use it as the noise floor of ill-conditioned quantities."""
+    the reference's own arithmetic leaves undetermined -- tests use it as the noise floor of ill-conditioned quantities.
+    A third build, `variant("f64")`, turns every float of the source into a double (-DORC_F64): the arbiter for ill-conditioned quantities --
+    a float build is as good as its distance from this one."""
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    for so, flags in ((_SO, ["-ffp-contract=off"]), (_SO_FMA, ["-ffp-contract=fast", "-mfma"])):
+    for so, flags in ((_SO, ["-ffp-contract=off"]), (_SO_FMA, ["-ffp-contract=fast", "-mfma"]), (_SO_F64, ["-ffp-contract=off", "-DORC_F64"])):
         if (not force) and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(_SRC):
             continue
         subprocess.check_call(["gcc", "-O2"] + flags + ["-fno-fast-math", "-fopenmp", "-shared", "-fPIC", "-o", so, _SRC, "-lm"])
@@ -58,21 +62,24 @@ def lib():
 
 
 class variant:
-    """`with oracle.variant("fma"):` runs the calls inside on the fma-contracted build of the same C source (see build())."""
+    """`with oracle.variant("fma"):` runs the calls inside on the fma-contracted build of the same C source, `variant("f64")` on the
+    build in which every float is a double (inputs are converted, results come back as float64 arrays) -- see build()."""
 
     def __init__(self, name):
-        assert name in ("fma", "plain")
-        self.path = _SO_FMA if name == "fma" else _SO
+        assert name in ("fma", "plain", "f64")
+        self.path = {"fma": _SO_FMA, "plain": _SO, "f64": _SO_F64}[name]
+        self.rt = np.float64 if name == "f64" else np.float32
 
     def __enter__(self):
-        global _lib
-        self.prev = _lib
+        global _lib, _RT
+        self.prev = (_lib, _RT)
         _lib = _load(self.path)
+        _RT = self.rt
         return self
 
     def __exit__(self, *exc):
-        global _lib
-        _lib = self.prev
+        global _lib, _RT
+        _lib, _RT = self.prev
         return False
 
 
@@ -85,14 +92,15 @@ def _p(a):
 
 
 def _f32(a):
+    """contiguous array of the build's float type (float32; float64 inside variant("f64")), or None"""
     if a is None:
         return None
-    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    a = np.ascontiguousarray(np.asarray(a, dtype=_RT))
     return a if a.size else None
 
 
 def _cf(x):
-    return ctypes.c_float(float(x))
+    return ctypes.c_double(float(x)) if _RT is np.float64 else ctypes.c_float(float(x))
 
 
 def _ci(x):
@@ -124,13 +132,13 @@ def forward(inp, tex_quant=False, cull=False):
     Returns a dict with the 9 public outputs plus every internal state array.
     """
     L = lib()
-    means3D = np.ascontiguousarray(np.asarray(inp["means3D"], dtype=np.float32)).reshape(-1, 3); P = means3D.shape[0]
+    means3D = np.ascontiguousarray(np.asarray(inp["means3D"], dtype=_RT)).reshape(-1, 3); P = means3D.shape[0]
     W, H = int(inp["W"]), int(inp["H"]); HW = W * H
     gx, gy = tile_grid(W, H)
     shs = _f32(inp.get("shs")); colors_precomp = _f32(inp.get("colors_precomp"))
     scales = _f32(inp.get("scales")); rotations = _f32(inp.get("rotations"))
     cov3D_precomp = _f32(inp.get("cov3D_precomp")); all_map = _f32(inp.get("all_map"))
-    opac = np.ascontiguousarray(np.asarray(inp["opacities"], dtype=np.float32)).reshape(-1)
+    opac = np.ascontiguousarray(np.asarray(inp["opacities"], dtype=_RT)).reshape(-1)
     vm = _f32(inp["viewmatrix"]).reshape(-1); pm = _f32(inp["projmatrix"]).reshape(-1)
     campos = _f32(inp["campos"]).reshape(-1); bg = _f32(inp["bg"]).reshape(-1)
     D = int(inp.get("sh_degree", 0)); M = 0 if shs is None else int(shs.shape[1])
@@ -140,28 +148,28 @@ def forward(inp, tex_quant=False, cull=False):
     n_src = int(inp.get("n_src", 1)); Lbuf = int(inp.get("buffer_length", 4)); thr = float(inp.get("depth_thr", 0.01))
     ref_to_src = _f32(inp.get("ref_to_src")); src_cam_pos = _f32(inp.get("src_cam_pos"))
     src_images = _f32(inp.get("src_images")); src_depths = _f32(inp.get("src_depths"))
-    if ref_to_src is None: ref_to_src = np.zeros((n_src, 16), np.float32)
-    if src_cam_pos is None: src_cam_pos = np.zeros((n_src, 3), np.float32)
-    if src_images is None: src_images = np.zeros((n_src, 3, H, W), np.float32)
-    if src_depths is None: src_depths = np.zeros((n_src, 1, H, W), np.float32)
+    if ref_to_src is None: ref_to_src = np.zeros((n_src, 16), _RT)
+    if src_cam_pos is None: src_cam_pos = np.zeros((n_src, 3), _RT)
+    if src_images is None: src_images = np.zeros((n_src, 3, H, W), _RT)
+    if src_depths is None: src_depths = np.zeros((n_src, 1, H, W), _RT)
 
     st = {}
-    st["radii"] = np.zeros(P, np.int32); st["means2D"] = np.zeros((P, 2), np.float32)
-    st["depths"] = np.zeros(P, np.float32); st["cov3D"] = np.zeros((P, 6), np.float32)
-    st["rgb"] = np.zeros((P, 3), np.float32); st["conic_opacity"] = np.zeros((P, 4), np.float32)
+    st["radii"] = np.zeros(P, np.int32); st["means2D"] = np.zeros((P, 2), _RT)
+    st["depths"] = np.zeros(P, _RT); st["cov3D"] = np.zeros((P, 6), _RT)
+    st["rgb"] = np.zeros((P, 3), _RT); st["conic_opacity"] = np.zeros((P, 4), _RT)
     st["tiles_touched"] = np.zeros(P, np.uint32); st["clamped"] = np.zeros((P, 3), np.uint8)
     st["rect4"] = np.zeros((P, 4), np.int32); st["tmask"] = np.zeros((P, 4), np.uint64)      # CULL_WORDS mask words per Gaussian
     out = {
-        "color": np.zeros((3, H, W), np.float32), "normal_map": np.zeros((3, H, W), np.float32),
-        "median_depth": np.zeros((1, H, W), np.float32), "cam_feat": np.zeros((4 * MAX_SRC, H, W), np.float32),
-        "warped_image": np.zeros((3 * MAX_SRC, H, W), np.float32), "min_depth_diff": np.zeros((1, H, W), np.float32),
-        "camera_ray": np.zeros((3, H, W), np.float32), "use_first_src_frame_mask": np.zeros((1, H, W), np.int32),
+        "color": np.zeros((3, H, W), _RT), "normal_map": np.zeros((3, H, W), _RT),
+        "median_depth": np.zeros((1, H, W), _RT), "cam_feat": np.zeros((4 * MAX_SRC, H, W), _RT),
+        "warped_image": np.zeros((3 * MAX_SRC, H, W), _RT), "min_depth_diff": np.zeros((1, H, W), _RT),
+        "camera_ray": np.zeros((3, H, W), _RT), "use_first_src_frame_mask": np.zeros((1, H, W), np.int32),
     }
     st["ranges"] = np.zeros((gx * gy, 2), np.uint32)
-    st["final_T"] = np.zeros(HW, np.float32); st["n_contrib"] = np.zeros(HW, np.uint32)
-    st["cache_sum_w"] = np.zeros(HW, np.float32); st["cache_low"] = np.zeros(HW, np.uint32)
+    st["final_T"] = np.zeros(HW, _RT); st["n_contrib"] = np.zeros(HW, np.uint32)
+    st["cache_sum_w"] = np.zeros(HW, _RT); st["cache_low"] = np.zeros(HW, np.uint32)
     st["cache_high"] = np.zeros(HW, np.uint32)
-    st["valid_src_idx"] = np.full((MAX_SRC, HW), -1, np.int32); st["valid_src_w"] = np.zeros((MAX_SRC, HW), np.float32)
+    st["valid_src_idx"] = np.full((MAX_SRC, HW), -1, np.int32); st["valid_src_w"] = np.zeros((MAX_SRC, HW), _RT)
     if P == 0:   # rasterize_points.cu:101-102
         st["point_list"] = np.zeros(0, np.uint32); st["keys"] = np.zeros(0, np.uint64)
         out.update(st); out["num_rendered"] = 0
@@ -198,7 +206,7 @@ def backward(inp, fwd, dL_dcolor, dL_dnormal=None, dL_ddepth=None, dL_dwarped=No
     """Full backward given ``forward``'s result.  Returns the reference's 10 gradients
     (rasterize_points.cu:209-219, 270) plus dL_dconic."""
     L = lib()
-    means3D = np.ascontiguousarray(np.asarray(inp["means3D"], dtype=np.float32)).reshape(-1, 3); P = means3D.shape[0]
+    means3D = np.ascontiguousarray(np.asarray(inp["means3D"], dtype=_RT)).reshape(-1, 3); P = means3D.shape[0]
     W, H = int(inp["W"]), int(inp["H"])
     shs = _f32(inp.get("shs")); colors_precomp = _f32(inp.get("colors_precomp"))
     scales = _f32(inp.get("scales")); rotations = _f32(inp.get("rotations"))
@@ -211,23 +219,23 @@ def backward(inp, fwd, dL_dcolor, dL_dnormal=None, dL_ddepth=None, dL_dwarped=No
     render_geo = bool(inp.get("render_geo", False))
     n_src = int(inp.get("n_src", 1))
     ref_to_src = _f32(inp.get("ref_to_src")); src_images = _f32(inp.get("src_images"))
-    if ref_to_src is None: ref_to_src = np.zeros((n_src, 16), np.float32)
-    if src_images is None: src_images = np.zeros((n_src, 3, H, W), np.float32)
+    if ref_to_src is None: ref_to_src = np.zeros((n_src, 16), _RT)
+    if src_images is None: src_images = np.zeros((n_src, 3, H, W), _RT)
     g_c = _f32(dL_dcolor)
-    g_n = _f32(dL_dnormal) if dL_dnormal is not None else np.zeros((3, H, W), np.float32)
-    g_d = _f32(dL_ddepth) if dL_ddepth is not None else np.zeros((1, H, W), np.float32)
-    g_w = _f32(dL_dwarped) if dL_dwarped is not None else np.zeros((3 * MAX_SRC, H, W), np.float32)
-    if g_n is None: g_n = np.zeros((3, H, W), np.float32)
-    if g_d is None: g_d = np.zeros((1, H, W), np.float32)
-    if g_w is None: g_w = np.zeros((3 * MAX_SRC, H, W), np.float32)
+    g_n = _f32(dL_dnormal) if dL_dnormal is not None else np.zeros((3, H, W), _RT)
+    g_d = _f32(dL_ddepth) if dL_ddepth is not None else np.zeros((1, H, W), _RT)
+    g_w = _f32(dL_dwarped) if dL_dwarped is not None else np.zeros((3 * MAX_SRC, H, W), _RT)
+    if g_n is None: g_n = np.zeros((3, H, W), _RT)
+    if g_d is None: g_d = np.zeros((1, H, W), _RT)
+    if g_w is None: g_w = np.zeros((3 * MAX_SRC, H, W), _RT)
 
     res = {
-        "dL_dmeans3D": np.zeros((P, 3), np.float32), "dL_dmeans2D": np.zeros((P, 3), np.float32),
-        "dL_dmeans2D_abs": np.zeros((P, 3), np.float32), "dL_dcolors": np.zeros((P, 3), np.float32),
-        "dL_dall_map": np.zeros((P, 5), np.float32), "dL_dconic": np.zeros((P, 4), np.float32),
-        "dL_dopacity": np.zeros((P, 1), np.float32), "dL_dcov3D": np.zeros((P, 6), np.float32),
-        "dL_dsh": np.zeros((P, M, 3), np.float32), "dL_dscales": np.zeros((P, 3), np.float32),
-        "dL_drotations": np.zeros((P, 4), np.float32),
+        "dL_dmeans3D": np.zeros((P, 3), _RT), "dL_dmeans2D": np.zeros((P, 3), _RT),
+        "dL_dmeans2D_abs": np.zeros((P, 3), _RT), "dL_dcolors": np.zeros((P, 3), _RT),
+        "dL_dall_map": np.zeros((P, 5), _RT), "dL_dconic": np.zeros((P, 4), _RT),
+        "dL_dopacity": np.zeros((P, 1), _RT), "dL_dcov3D": np.zeros((P, 6), _RT),
+        "dL_dsh": np.zeros((P, M, 3), _RT), "dL_dscales": np.zeros((P, 3), _RT),
+        "dL_drotations": np.zeros((P, 4), _RT),
     }
     if P == 0:
         return res
@@ -268,14 +276,14 @@ def eval_sh(deg, shs, dirs):
     """shs (N,M,3), dirs (N,3) unit -> (N,3) SH colour before the +0.5 / clamp."""
     shs = _f32(shs); dirs = _f32(dirs)
     N, M = shs.shape[0], shs.shape[1]
-    out = np.zeros((N, 3), np.float32)
+    out = np.zeros((N, 3), _RT)
     lib().orc_eval_sh(_ci(N), _ci(deg), _ci(M), _p(dirs), _p(shs), _p(out))
     return out
 
 
 def knn_mean_dist2(points):
     """(P,3) -> (P,) mean squared distance to the 3 nearest other points (brute force)."""
-    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32)).reshape(-1, 3)
-    out = np.zeros(pts.shape[0], np.float32)
+    pts = np.ascontiguousarray(np.asarray(points, dtype=_RT)).reshape(-1, 3)
+    out = np.zeros(pts.shape[0], _RT)
     lib().orc_knn_mean_dist2(_ci(pts.shape[0]), _p(pts), _p(out))
     return out

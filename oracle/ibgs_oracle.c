@@ -26,6 +26,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Third build of this one source (oracle.variant("f64"), gcc -DORC_F64): every `float` of the restatement -- arrays at the interface
+ * included -- becomes a double and every libm call its double form.  Same algorithm, same decisions wherever they do not hinge on the last
+ * bit of an fp32 value; the arbiter for ill-conditioned quantities: a float build (the oracle proper, its fma twin, the HIP path) is as
+ * good as its distance from this one (tests/test_gpu_anisotropic.py).  The fp32 constants of the source (0.3f, 1.0f / 255 ...) keep
+ * their fp32 values. */
+typedef float orc_f32;
+#ifdef ORC_F64
+#define float double
+#define sqrtf sqrt
+#define expf exp
+#define floorf floor
+#define ceilf ceil
+#define fabsf fabs
+#endif
+
 #define TILE 16
 #define ROUND 256          /* entries fetched per cooperative round: forward.cu:357,404 */
 #define MAX_L 8            /* auxiliary.h:21 */
@@ -166,12 +181,14 @@ static int sh_basis(int deg, const float* d, float* B)
  * 0.1 % + 1e-3 safety margin, far above fp32 rounding of `power`) are dropped.  All arithmetic
  * is +,-,*,/,sqrt in fp32 so that gcc and hipcc (-ffp-contract=off) agree exactly.
  * ---------------------------------------------------------------------------------------- */
-static float ln_portable(float x)           /* |error| < 2e-6 for x >= 1; basic IEEE ops only */
+static float ln_portable(float x_in)           /* |error| < 2e-6 for x >= 1; basic IEEE ops only */
 {
+    const orc_f32 x = (orc_f32)x_in;
     uint32_t u; memcpy(&u, &x, 4);
     const int e = (int)(u >> 23) - 127;
     u = (u & 0x007FFFFFu) | 0x3F800000u;
-    float m; memcpy(&m, &u, 4);
+    orc_f32 m32; memcpy(&m32, &u, 4);
+    const float m = m32;
     const float s = (m - 1.0f) / (m + 1.0f), z = s * s;
     const float poly = 1.0f + z * (0.33333334f + z * (0.2f + z * (0.14285715f + z * 0.11111111f)));
     return (float)e * 0.6931472f + 2.0f * s * poly;
@@ -381,7 +398,8 @@ int orc_bin(int P, int64_t R, const int32_t* radii, const int32_t* rect4, const 
         if (radii[i] <= 0) continue;
         const int x0 = rect4[4 * i], y0 = rect4[4 * i + 1], x1 = rect4[4 * i + 2], y1 = rect4[4 * i + 3];
         const int w = x1 - x0, dense = (w * (y1 - y0) > CULL_MAX_TILES);
-        uint32_t dbits; memcpy(&dbits, depths + i, 4);
+        const orc_f32 depth32 = (orc_f32)depths[i];          /* the key carries the fp32 bits of the depth (rasterizer_impl.cu:216-220) */
+        uint32_t dbits; memcpy(&dbits, &depth32, 4);
         if (dense && tmask[CULL_WORDS * i] == 0ull) {          /* culled row by row (tile_cull): the same runs, recomputed */
             const float A = conic_opacity[4 * i], B = conic_opacity[4 * i + 1], C = conic_opacity[4 * i + 2];
             CullRows j;

@@ -56,3 +56,45 @@ def test_backward_reuses_or_repacks_the_source_rgba():
         for n in NAMES:
             assert np.abs(alone[v][n]).sum() > 0, n
             assert rel_l2(got[n], alone[v][n]) < 1e-5, (v, n, rel_l2(got[n], alone[v][n]))
+
+
+def test_forward_packs_once_per_source_stack():
+    """A forward that is handed the very image stack whose pack still sits in the stream's scratch skips the pack kernel (TEX_CACHE); an
+    in-place write to the stack, another stack object or another call in between pack again.  Outputs identical either way."""
+    from tests import hipref
+    from tests.scenes import add_sources, scene as mk
+    inp = add_sources(mk(P=1500, W=112, H=80, deg=1, seed=5, opacity="trained", planes=True, scale_mul=1.6), n_src=3, L=4)
+    st = hipref.settings_from(inp, "cuda")
+    lv = hipref.leaf_inputs(inp, "cuda", requires_grad=False)
+
+    def fwd(settings):
+        r = rasterizer.GaussianRasterizer(settings)
+        with torch.no_grad():
+            return r(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"], shs=lv["shs"],
+                     scales=lv["scales"], rotations=lv["rotations"], all_map=lv["all_map"])
+
+    w0 = rasterizer._tex_writes[0]
+    a = [t.clone() for t in fwd(st)]
+    assert rasterizer._tex_writes[0] == w0 + 1
+    b = fwd(st)
+    assert rasterizer._tex_writes[0] == w0 + 1, "the same stack again: no second pack"
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    st.src_images.mul_(0.5)                           # in-place write: the version counter moves, the pack is redone
+    c = fwd(st)
+    assert rasterizer._tex_writes[0] == w0 + 2
+    assert not torch.equal(c[5], a[5]) and torch.equal(c[0], a[0])          # warped colours changed, the render did not
+    st2 = st._replace(src_images=st.src_images.clone())          # another object with the same bytes: packed again, same result
+    d = fwd(st2)
+    assert rasterizer._tex_writes[0] == w0 + 3
+    for x, y in zip(c, d):
+        assert torch.equal(x, y)
+    old = rasterizer.TEX_CACHE
+    try:
+        rasterizer.TEX_CACHE = False
+        e = fwd(st2)
+        assert rasterizer._tex_writes[0] == w0 + 4
+    finally:
+        rasterizer.TEX_CACHE = old
+    for x, y in zip(d, e):
+        assert torch.equal(x, y)
