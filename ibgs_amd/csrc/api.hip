@@ -200,8 +200,12 @@ int64_t ibgs_geom_offset(int32_t P, const char* name)
 {
     size_t t; GeomState g = GeomState::carve(nullptr, (size_t)P, &t);
     OFF(g, rec); OFF(g, depths); OFF(g, cov3D); OFF(g, tiles); OFF(g, fp); OFF(g, tmask_hi); OFF(g, clamped); OFF(g, offsets);
+    // the depth order lies in buffer 0 unless the word offsets[P + 4] is 1 (the sort's last pass found every key in one bucket and left its input
+    // where it was: scan_sort.hip) -- then "order_alt" / "sorted_depth_keys_alt" hold it; offsets[P + 3] = how many leading entries are valid
     if (!strcmp(name, "order")) return (int64_t)((char*)g.sort_val[0] - (char*)nullptr);
+    if (!strcmp(name, "order_alt")) return (int64_t)((char*)g.sort_val[1] - (char*)nullptr);
     if (!strcmp(name, "sorted_depth_keys")) return (int64_t)((char*)g.sort_key[0] - (char*)nullptr);
+    if (!strcmp(name, "sorted_depth_keys_alt")) return (int64_t)((char*)g.sort_key[1] - (char*)nullptr);
     return -1;
 }
 size_t ibgs_tile_order_slots(int32_t W, int32_t H)

@@ -50,6 +50,7 @@ struct BwdParams {
     const float* depth_pixels; const float* warped_pixels;
     const float* dL_dcolor; const float* dL_dnormal; const float* dL_ddepth; const float* dL_dwarped;
     float* gacc;
+    int tab_slots;        // geo: slots of the window table the caller's scratch holds (buffer_length + 1 when the caller stated it, else 8)
     const uint32_t* slot_c; const uint32_t* meta; float* tab;     // geo: the forward's buffered contributor numbers (+ slot count); the window pass's table
     const uint32_t* order;      // balanced launch order of the colour kernel: workgroup -> tile (0xFFFFFFFF: none), nullptr: the tile map decides
     float* slab;          // IBGS_FLAG_DETERMINISTIC: (R x waves per tile) x 16, one row per (list entry, wave of its tile), written instead of the atomics (else nullptr)
@@ -302,7 +303,9 @@ __global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
     const float pxf = (float)px, pyf = (float)py;
     const float fx = p.cam.fx, fy = p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
-    const int L = min((int)p.meta[0], IBGS_MAX_BUFFER_LENGTH);
+    // the forward's buffer_length, but never more entries than the caller's table holds (a caller that states a smaller buffer_length than its
+    // forward used gets truncated windows, not a write past its scratch: include/ibgs_rast.h)
+    const int L = min((int)p.meta[0], p.tab_slots == IBGS_MAX_BUFFER_LENGTH ? IBGS_MAX_BUFFER_LENGTH : p.tab_slots - 1);          // (a full table of 8 slots holds 8 entries and needs no terminator)
     float* tab = p.tab + pix;
     auto put = [&](int slot, int field, float v) { tab[(size_t)(slot * GEO_TAB_FIELDS + field) * HW] = v; };
 
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
         put(out, 0, __uint_as_float(c)); put(out, 1, E); put(out, 2, Kx); put(out, 3, Ky); put(out, 4, Kz); put(out, 5, Kd);
         out++;
     }
-    if (out < IBGS_MAX_BUFFER_LENGTH) put(out, 0, __uint_as_float(0u));
+    if (out < p.tab_slots) put(out, 0, __uint_as_float(0u));
 }
 
 // ---- geo variant, pass 2: the blend loop -----------------------------------------------------------------------------------
@@ -566,7 +569,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                                 vNx = fmaf(w, e[2 * HW], vNx); vNy = fmaf(w, e[3 * HW], vNy); vNz = fmaf(w, e[4 * HW], vNz);
                                 vD = fmaf(w, e[5 * HW], vD);
                                 slot[q]++;
-                                next_c[q] = (slot[q] < (uint32_t)IBGS_MAX_BUFFER_LENGTH) ? __float_as_uint(e[(size_t)GEO_TAB_FIELDS * HW]) : 0u;
+                                next_c[q] = (slot[q] < (uint32_t)p.tab_slots) ? __float_as_uint(e[(size_t)GEO_TAB_FIELDS * HW]) : 0u;
                             }
                         }
                         if constexpr (BG0) dL_dalpha = dL_dalpha * T[q];
@@ -739,6 +742,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.dL_dcolor = a.dL_dcolor; p.dL_dnormal = a.dL_dnormal; p.dL_ddepth = a.dL_ddepth; p.dL_dwarped = a.dL_dwarped;
     p.gacc = a.grad_acc; p.slab = slab; p.order = nullptr;
     p.slot_c = im.slot_c; p.meta = im.meta; p.tab = geo_tab;
+    p.tab_slots = (a.buffer_length >= 1 && a.buffer_length < IBGS_MAX_BUFFER_LENGTH) ? a.buffer_length + 1 : IBGS_MAX_BUFFER_LENGTH;          // as ibgs_required_geo_table_for sizes it
     const int nt = p.ntiles;
     // as the forward (render_fwd.hip): blocks of tiles per XCD; geo 8 x 4 (fetch traffic 0.73 -> 0.35 GB, clustered image 1.92 -> 1.83 ms)
     static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_BWD", TileMap{TMAP_BLOCK, 1, 8, 8});

@@ -14,6 +14,7 @@ Same names, argument order, return values and error behaviour as
 PyTorch is used for device memory, streams and autograd plumbing only; all arithmetic happens in the
 HIP library.  If the library is missing the import of ``_lib`` raises -- there is no fallback.
 """
+import collections
 import ctypes
 import os
 from typing import NamedTuple
@@ -110,8 +111,8 @@ ORDER_HINT = True
 # forward lives on the 8 x 8 block map's L2 locality (source texels), and giving it up costs more than the balance brings on even scenes
 # (C3-geo forward 0.668 -> 0.716 ms, trained 0.375 -> 0.398 ms; half of the Gaussians in one blob: 0.751 -> 0.677 ms)
 ORDER_HINT_GEO = os.environ.get("IBGS_ORDER_HINT_GEO", "0") == "1"          # (the environment switch is for A/B runs: tools/ab_env.sh)
-ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p)
-_order_hints = {}
+ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p); the least recently used one goes first
+_order_hints = collections.OrderedDict()
 
 
 def _camera_key(viewmatrix, device, W, H, geo, stream):
@@ -375,8 +376,10 @@ class _CModule:
                 elif render_depth_only:
                     a.out_depth = out_depth.data_ptr()
                 if ORDER_HINT and (ORDER_HINT_GEO or not render_geo) and not render_depth_only and not debug:
-                    oh = _order_hints.get(_camera_key(viewmatrix, device, W, H, render_geo, stream))
+                    ckey = _camera_key(viewmatrix, device, W, H, render_geo, stream)
+                    oh = _order_hints.get(ckey)
                     if oh is not None:
+                        _order_hints.move_to_end(ckey)
                         a.tile_order_hint = oh.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
                 hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
@@ -521,9 +524,11 @@ class _CModule:
                     if ckey is not None:
                         oh = _order_hints.get(ckey)
                         if oh is None:
-                            if len(_order_hints) >= ORDER_HINT_MAX:
-                                _order_hints.clear()
+                            while len(_order_hints) >= ORDER_HINT_MAX:
+                                _order_hints.popitem(last=False)          # (a buffer still referenced by an enqueued kernel stays alive in the stream's allocator until it ran)
                             oh = _order_hints[ckey] = torch.full((int(lib.ibgs_tile_order_slots(W, H)),), -1, dtype=torch.int32, device=device)
+                        else:
+                            _order_hints.move_to_end(ckey)
                         a.tile_order_out = oh.data_ptr()
                 rc = lib.ibgs_backward(ctypes.byref(a))
                 if rc < 0:

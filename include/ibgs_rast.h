@@ -175,8 +175,8 @@ typedef struct ibgs_forward_args {
      * walked every tile's list -- at img + ibgs_img_offset(W, H, "tile_order") and in ibgs_backward_args.tile_order_out.  Handed to a later ibgs_forward of the SAME
      * camera (whose lists saturate where they did before), lets the forward launch balanced too; the forward cannot know its own work
      * in advance.  Performance only: the words are checked on the device (every tile exactly once, 0xFFFFFFFF = empty slot) and anything
-     * else -- a stale buffer, another resolution, garbage -- is ignored.  Used by the variant with one wave per tile (large frames),
-     * neither by render_geo nor by render_depth_only. */
+     * else -- a stale order, garbage -- is ignored; the buffer itself must hold ibgs_tile_order_slots(W, H) words (all of them are read).  Used by
+     * the variants with one wave per tile / half tile (large frames: colour and render_geo passes), not by render_depth_only. */
     const uint32_t* tile_order_hint;
 } ibgs_forward_args;
 
@@ -245,7 +245,9 @@ typedef struct ibgs_backward_args {
     /* IBGS_FLAG_DETERMINISTIC: transient scratch of >= ibgs_required_deterministic(R, P) bytes (slab R x 16 floats + sort buffers) */
     char* det_scratch; size_t det_scratch_bytes;
     /* the forward's buffer_length (0 = not stated).  When stated, geo_table only needs ibgs_required_geo_table_for(W, H, buffer_length)
-     * bytes and det_scratch ibgs_required_deterministic_for(R, P, W, H, render_geo, flags) */
+     * bytes and det_scratch ibgs_required_deterministic_for(R, P, W, H, render_geo, flags).  It must not be SMALLER than the buffer_length
+     * of the ibgs_forward whose arenas are handed in: the window pass then keeps only the first buffer_length buffered contributors of every
+     * pixel (wrong median / warp gradients, but never a write past geo_table) */
     int32_t buffer_length;
     /* optional (may be NULL): ibgs_tile_order_slots(W, H) words that receive the order in which a colour backward launched its tiles, i.e.
      * what ibgs_forward_args.tile_order_hint of the same camera's next forward wants (the same words also land in the image arena) */

@@ -83,8 +83,8 @@ def internal_state(outs, inp):
     st["cov3D"] = view(gb, go("cov3D"), np.float32, P * 6).reshape(P, 6)
     st["tiles"] = view(gb, go("tiles"), np.uint32, P)
     st["clamped"] = view(gb, go("clamped"), np.uint8, P)
-    st["order"] = view(gb, go("order"), np.uint32, P)
-    st["offsets"] = view(gb, go("offsets"), np.uint32, P + 1)
+    st["offsets"] = view(gb, go("offsets"), np.uint32, P + 5)          # [P] = R, [P+1] sort error flag, [P+2] = C, [P+3] = Gaussians with tiles, [P+4] = 1: the order lies in the alternate buffer
+    st["order"] = view(gb, go("order_alt" if st["offsets"][P + 4] == 1 else "order"), np.uint32, P)[:int(st["offsets"][P + 3])]
     st["ranges"] = view(ib, io("ranges"), np.uint32, gx * gy * 2).reshape(gx * gy, 2)
     st["final_T"] = view(ib, io("final_T"), np.float32, HW)
     st["n_contrib"] = view(ib, io("n_contrib"), np.uint32, HW)

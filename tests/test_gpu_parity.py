@@ -44,6 +44,9 @@ def check_stages(ist, o, ref):
     for a, b in ((ist["depths"], ref["depths"]), (ist["rec"][:, 0:2], ref["means2D"]), (ist["rec"][:, 4:7], ref["conic_opacity"][:, :3]),
                  (ist["rec"][:, 2], ref["conic_opacity"][:, 3]), (ist["cov3D"], ref["cov3D"])):
         assert np.array_equal(a.view(np.uint32), np.ascontiguousarray(b).view(np.uint32)), "preprocess record not bit-identical"
+    # the depth order as exported (ibgs_geom_offset "order" / "order_alt"): the Gaussians with tiles, by the bits of their depth, ties by index
+    kept = np.flatnonzero(ref["tiles_touched"] > 0)
+    assert np.array_equal(ist["order"], kept[np.argsort(ref["depths"][kept].view(np.uint32), kind="stable")])
     assert np.array_equal(ist["ranges"], ref["ranges"])
     assert np.array_equal(ist["point_list"], ref["point_list"])
     assert np.array_equal(ist["sorted_tile_keys"], (ref["keys"] >> 32).astype(np.uint32))

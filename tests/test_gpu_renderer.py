@@ -185,3 +185,36 @@ def test_c3_full_size_against_the_oracle():
     (outs["color"] * torch.as_tensor(g, device="cuda")).sum().backward()
     for k, v in {"dL_dmeans3D": "means3D", "dL_dsh": "shs", "dL_dopacity": "opacities", "dL_dscales": "scales", "dL_drotations": "rotations"}.items():
         assert rel_l2(lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape), rb[k]) < 1e-3, k
+    # ... and against the oracle on the REFERENCE's lists (no tile cull: the AABB lists of rasterizer_impl.cu:205-225, twice as long): the culled
+    # HIP pass must show the same image and the same radii -- "culling changes no public output" at the bench's size, not only at 3 000 Gaussians
+    full = oracle.forward(inp, cull=False)
+    assert full["num_rendered"] > 1.8 * ref["num_rendered"]
+    assert np.array_equal(outs["radii"].cpu().numpy(), full["radii"])
+    assert np.array_equal(full["color"], ref["color"]), "oracle: culled and AABB lists give different images"
+    assert l1(col, full["color"]) < 1e-6 and abs(psnr(col, tgt)[0] - psnr(full["color"], tgt)[0]) < 1e-3
+    assert np.array_equal(full["final_T"], ref["final_T"])
+
+
+def test_c2_and_the_trained_scene_against_the_reference_lists():
+    """HIP with culling against the oracle WITHOUT it at C2 size (100 k, 800 x 800) and on the C3-sized trained scene of bench.py's `trained_geo` line
+    (plane-like, heavy-tailed, clustered: a third of its list entries come from rectangles of more than 256 tiles, culled row by row)."""
+    c = syn.CONFIGS["C2"]
+    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=0, seed=c["seed"])
+    full = oracle.forward(inp, cull=False)
+    outs, _, _ = hipref.run_forward(inp, requires_grad=False)
+    assert np.array_equal(outs["radii"].cpu().numpy(), full["radii"]) and l1(outs["color"].cpu().numpy(), full["color"]) < 1e-6
+    c = syn.CONFIGS["C3"]
+    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity="trained", anisotropy="plane", scale_sigma=1.0, cluster=0.3)
+    ref = oracle.forward(inp, cull=True)
+    outs, _, _ = hipref.run_forward(inp)
+    ist = hipref.internal_state(outs, inp)
+    outs = {k: v.detach() for k, v in outs.items()}
+    assert ist["R"] == ref["num_rendered"] and np.array_equal(ist["point_list"], ref["point_list"]) and np.array_equal(ist["ranges"], ref["ranges"])
+    r = ref["rect4"].astype(np.int64); area = (r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])
+    rows = (area > 256) & (ref["tmask"][:, 0] == 0)
+    assert rows.sum() > 3000 and ref["tiles_touched"][rows].sum() > 0.15 * ref["num_rendered"]
+    col = outs["color"].cpu().numpy()
+    assert l1(col, ref["color"]) < 1e-6 and (ist["n_contrib"] == ref["n_contrib"]).mean() > 0.9999
+    full = oracle.forward(inp, cull=False)
+    assert full["num_rendered"] > 1.8 * ref["num_rendered"]
+    assert np.array_equal(outs["radii"].cpu().numpy(), full["radii"]) and np.array_equal(full["color"], ref["color"]) and l1(col, full["color"]) < 1e-6
