@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ibgs_amd import _lib, synthetic as syn  # noqa: E402
-from ibgs_amd._build import csrc_sha  # noqa: E402
+from ibgs_amd._build import csrc_sha, tu_of, tu_shas  # noqa: E402
 from ibgs_amd import dist as vdist  # noqa: E402
 from ibgs_amd.losses import l1_loss  # noqa: E402
 from ibgs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
@@ -74,31 +74,50 @@ def implementation_bytes(P, kept, R, C, HW, Mc):
     return pre + sort + binning + fwd + bwd + pre_bwd
 
 
-def profile_counters(kernel_substr, workload_tag):
-    """Per-launch PMC counters of one kernel from the committed rocprofv3 summary (profiles/counters_latest.json, written by
-    profiles/summarize.py).  Returns (counters, source) -- (None, reason) when the summary was taken on other kernel
-    sources or another workload: stale numbers are dropped, not quoted next to fresh timings."""
-    # every profiles/*_counters.json carries the workload tag and the kernel-source fingerprint it was taken on: pick the one that matches both
+def _profiles_for(workload_tag):
+    """Committed rocprofv3 summaries (profiles/*_counters.json, written by profiles/summarize.py) of this workload, newest first."""
     import glob
-    sha, reason, d = csrc_sha(), "no profiles/*_counters.json for workload %r" % workload_tag, None
+    res = []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), key=os.path.getmtime, reverse=True):
         try:
             c = json.load(open(path))
         except Exception:   # noqa: BLE001
             continue
-        if c.get("workload") != workload_tag:
+        if c.get("workload") == workload_tag:
+            res.append(c)
+    return res
+
+
+def profile_counters(kernel_substr, workload_tag):
+    """Per-launch PMC counters of one kernel from the committed rocprofv3 summaries.  Returns (counters, source) -- (None, reason) when no
+    summary of this workload was taken on the CURRENT sources of the translation unit that holds the kernel (its .hip + the headers;
+    ibgs_amd/_build.py: tu_shas): stale numbers are dropped, not quoted next to fresh timings.  (Until round 4 the stamp was one hash over
+    every source file, so a host-only edit of api.hip made every kernel's counters "stale".)"""
+    tu = tu_of(kernel_substr)
+    now = tu_shas().get(tu) if tu else None
+    reason = "no profiles/*_counters.json for workload %r" % workload_tag
+    for d in _profiles_for(workload_tag):
+        stamp = (d.get("tu_shas") or {}).get(tu) if tu else None
+        fresh = (stamp is not None and stamp == now) or d.get("csrc_sha") == csrc_sha()
+        if not fresh:
+            reason = "profile of %r: %s.hip / headers changed since it was taken (%s -> %s)" % (workload_tag, tu, stamp or d.get("csrc_sha"), now)
             continue
-        if c.get("csrc_sha") != sha:
-            reason = "profile of %r taken on csrc %s, this build is %s" % (workload_tag, c.get("csrc_sha"), sha)
-            continue
-        d = c
-        break
-    if d is None:
-        return None, reason
-    for k, c in d.get("per_launch_counters", {}).items():
-        if kernel_substr in k:
-            return c, "profiles/%s @ csrc %s (%s)" % (d.get("tag", "counters_latest") + "_counters.json", d["csrc_sha"], d.get("date", "?"))
-    return None, "kernel %s not in the profile summary" % kernel_substr
+        for k, c in d.get("per_launch_counters", {}).items():
+            if kernel_substr in k:
+                return c, "profiles/%s @ %s %s (%s)" % (d.get("tag", "counters_latest") + "_counters.json", tu, stamp or d.get("csrc_sha"), d.get("date", "?"))
+        reason = "kernel %s not in the profile summary" % kernel_substr
+    return None, reason
+
+
+def step_traffic_measured(workload_tag):
+    """HBM bytes of one step as the PMC passes measured them (profiles/summarize.py: sum over the library's kernels), quoted only while EVERY
+    translation unit of the library is what it was when the passes ran."""
+    now = tu_shas()
+    for d in _profiles_for(workload_tag):
+        if "step_traffic_measured" in d and ((d.get("tu_shas") or {}) == now or d.get("csrc_sha") == csrc_sha()):
+            return {"bytes_per_step": d["step_traffic_measured"]["bytes_per_step"], "source": "profiles/%s_counters.json (%s)" % (d.get("tag"), d.get("date", "?")),
+                    "how": d["step_traffic_measured"].get("how")}
+    return None
 
 
 def workload_tag(cfg, geo, forward_only, opacity, cluster=0.0, anisotropy=None, scale_sigma=0.0):
@@ -586,6 +605,10 @@ def main():
             ib = implementation_bytes(wl.P, kept, R_, C_, wl.H * wl.W, int(wl.inp["shs"].shape[1]))
             extras["implementation_bytes"] = {"bytes_per_step": ib, "coarse_entries": C_, "gaussians_with_tiles": kept,
                                               "step_frac_impl": ib / (m["ms_step"] * 1e-3) / HBM_PEAK}
+            stm = step_traffic_measured(workload_tag(a.config, False, False, a.opacity, a.cluster, a.anisotropy, a.scale_sigma))
+            if stm is not None:          # the model above beside what the counters saw
+                stm["step_frac_measured"] = stm["bytes_per_step"] / (m["ms_step"] * 1e-3) / HBM_PEAK
+                extras["implementation_bytes"]["step_traffic_measured"] = stm
         # (a) a trainer hops between cameras (train.py:275-281): 8 orbit views round-robin.  The first round fills the window of the
         # R hint (a miss = binning + render run twice); afterwards every call is sized by the largest R of the last 16
         miss0 = _r.HINT_MISSES

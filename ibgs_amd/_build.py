@@ -59,6 +59,38 @@ def csrc_sha():
     return h.hexdigest()[:12]
 
 
+# which translation unit a kernel of the step lives in (substring of its name -> TU): profile-derived numbers of a kernel stay valid while ITS
+# unit (and the headers) are unchanged -- a host-only edit of api.hip does not make the blend kernels' counters stale
+KERNEL_TU = (("render_fwd", "render_fwd"), ("pack_rgba", "render_fwd"), ("render_bwd", "render_bwd"), ("geo_window", "render_bwd"), ("tile_order", "render_bwd"),
+             ("preprocess_bwd", "preprocess_bwd"), ("sh_grad", "preprocess_bwd"), ("preprocess_kernel", "preprocess"), ("sh_color", "preprocess"), ("mark_visible", "preprocess"),
+             ("onesweep", "scan_sort"), ("radix", "scan_sort"), ("scan_", "scan_sort"), ("cell_", "binning"), ("expand_", "binning"), ("tile_ranges", "binning"),
+             ("l1_", "loss"), ("adam", "adam"), ("compact", "compact"), ("det_", "deterministic"), ("knn", "knn"))
+
+
+def tu_of(kernel_name):
+    for sub, tu in KERNEL_TU:
+        if sub in kernel_name:
+            return tu
+    return None
+
+
+def tu_shas():
+    """{translation unit: fingerprint of its .hip + every header (csrc/*.h, include/ibgs_rast.h)}, comments and blank lines excluded."""
+    import hashlib
+    hdr = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            hdr.update(f.encode()); hdr.update(_code_only(open(os.path.join(CSRC, f), "r").read()).encode())
+    hdr.update(_code_only(open(os.path.join(HERE, "..", "include", "ibgs_rast.h"), "r").read()).encode())
+    out = {}
+    for name in SOURCES:
+        h = hdr.copy()
+        h.update(_code_only(open(os.path.join(CSRC, name + ".hip"), "r").read()).encode())
+        h.update(" ".join(EXTRA.get(name, [])).encode())
+        out[name] = h.hexdigest()[:12]
+    return out
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

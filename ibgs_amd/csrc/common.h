@@ -197,6 +197,20 @@ constexpr int IBGS_TRACE_MAX = 32768;
 #define IBGS_TRACE_END(buf) do { } while (0)
 #endif
 
+// ---- diagnostic build only (-DIBGS_COUNT_LANES, tools/lane_stats.py): how full are the blend kernels' lanes? ---------------------------------
+// Per kernel four 64-bit counters: [0] list entries walked (wave x entry), [1] entries that at least one pixel of the wave blends, [2] lanes that
+// EXECUTE a pair evaluation (64 per quadrant evaluation that is not skipped), [3] lanes whose pixel really blends the Gaussian.  Each wave adds
+// its totals once, at its end.  The product build compiles none of this.
+#ifdef IBGS_COUNT_LANES
+#define IBGS_LANES_DECL() unsigned long long ibgs_lc_[4] = {0ull, 0ull, 0ull, 0ull}
+#define IBGS_LANES_ADD(i, n) ibgs_lc_[i] += (unsigned long long)(n)
+#define IBGS_LANES_FLUSH(buf) do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 4; i_++) atomicAdd(&(buf)[i_], ibgs_lc_[i_]); } } while (0)
+#else
+#define IBGS_LANES_DECL() do { } while (0)
+#define IBGS_LANES_ADD(i, n) do { } while (0)
+#define IBGS_LANES_FLUSH(buf) do { } while (0)
+#endif
+
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 #define IBGS_HIP(expr)                                                                    \

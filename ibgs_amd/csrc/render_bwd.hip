@@ -107,9 +107,13 @@ __device__ __forceinline__ float fast_rcp(float x)
 //     parity bars see: T picks up ~1e-7 sqrt(k) relative noise over k divisions);
 //   * "k < n_contrib" costs two compares per quadrant per CHUNK when no pixel of the quadrant switches on inside the chunk
 //     (each pixel switches on once per traversal), instead of one per Gaussian.
+#ifdef IBGS_COUNT_LANES
+__device__ unsigned long long g_lanes_bwd[4];
+#endif
 template <int PPL>
 __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const int tile, const int sub)
 {
+    IBGS_LANES_DECL();
     constexpr int CHUNK = 16;          // 16 records per round: 0.75 KB + 4 KB of per-pixel constants <= 5 KB per wave = 8 waves per SIMD, every tile of a 1080p frame resident at once
     __shared__ float4 s_rec[3][CHUNK];
     __shared__ float4 s_gpix[PPL][WAVE];                  // dL/dC (rgb), -T_final * (bg . dL/dC)
@@ -212,6 +216,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                 }
                 float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f;
                 bool any = false;
+                IBGS_LANES_ADD(0, 1);
 #pragma unroll
                 for (int q = 0; q < PPL; q++) {
                     // the forward's test: E <= log2(255) (render_fwd.hip, common.h)
@@ -220,6 +225,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                     Q[q] = 0.f;
                     if (okm != 0ull) {
                         any = true;
+                        IBGS_LANES_ADD(2, 64); IBGS_LANES_ADD(3, __builtin_popcountll(okm));
                         // lanes that fail the test run the same instructions with G = 0: alpha = 0 leaves T and S
                         // unchanged (1 / (1 - 0) = 1 exactly) and every sum receives a zero
                         // (exp2(-E) = o G.  The select is inline asm and the first reader of the transcendental's result: it carries its own
@@ -245,6 +251,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
+                    IBGS_LANES_ADD(1, 1);
                     // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb (= grad_acc columns)
                     float v[12];
                     if constexpr (PPL == 4) {
@@ -275,6 +282,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
         __syncthreads();
         top -= count;
     }
+    IBGS_LANES_FLUSH(g_lanes_bwd);
 }
 
 // ---- geo variant, pass 1: the median / warp terms of every buffered contributor, per pixel ---------------------------------
@@ -803,6 +811,14 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
 
 }  // namespace ibgs
 
+#ifdef IBGS_COUNT_LANES
+extern "C" int ibgs_debug_lanes_bwd(unsigned long long* dst, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ibgs::g_lanes_bwd), sizeof(unsigned long long) * 4, 0, hipMemcpyDeviceToHost);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(ibgs::g_lanes_bwd), z, sizeof(z), 0, hipMemcpyHostToDevice); }
+    return rc;
+}
+#endif
 #ifdef IBGS_TRACE_WAVES
 extern "C" int ibgs_debug_trace_bwd(void* dst, size_t bytes)
 {

@@ -106,10 +106,14 @@ __device__ __forceinline__ float tex_depth(const float* __restrict__ img, int W,
 #ifdef IBGS_TRACE_WAVES
 __device__ uint4 g_trace_fwd[IBGS_TRACE_MAX];
 #endif
+#ifdef IBGS_COUNT_LANES
+__device__ unsigned long long g_lanes_fwd[4];
+#endif
 template <int MODE, int PPL, int MAXL>
 __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
 {
     IBGS_TRACE_BEGIN();
+    IBGS_LANES_DECL();
     constexpr bool GEO = (MODE == MODE_GEO);
     constexpr bool DEPTH = (MODE == MODE_DEPTH);
     constexpr int NQ = GEO ? 4 : 3;          // record quads staged per Gaussian
@@ -239,6 +243,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
             float4 q3 = q2;
             if constexpr (GEO) q3 = s_rec[3][j];          // normal
             const int e = base + j;
+            IBGS_LANES_ADD(0, 1);
+#ifdef IBGS_COUNT_LANES
+            bool lc_any_ = false;
+#endif
             // 1-based list position as ONE vector register per Gaussian (opaque to the optimiser, which otherwise re-materialises
             // the scalar -> vector move inside every quadrant's branch)
             uint32_t e1v = (uint32_t)(e + 1);
@@ -274,6 +282,10 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                     m &= running;
                 }
                 if (m == 0ull) continue;                              // wave-uniform: nobody sees this Gaussian
+                IBGS_LANES_ADD(2, 64); IBGS_LANES_ADD(3, __builtin_popcountll(m));
+#ifdef IBGS_COUNT_LANES
+                lc_any_ = true;
+#endif
                 const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(-p2));
                 const float aeff = __builtin_amdgcn_inverse_ballot_w64(m) ? alpha : 0.f;
                 float aT = aeff * T[q];
@@ -338,6 +350,9 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
                 T[q] = test_T;
                 lastc[q] = acc ? contributor : lastc[q];
             }
+#ifdef IBGS_COUNT_LANES
+            if (lc_any_) IBGS_LANES_ADD(1, 1);
+#endif
         }
         __syncthreads();
         uint64_t anylive = 0ull;
@@ -506,6 +521,7 @@ __global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
         }
     }
     IBGS_TRACE_END(g_trace_fwd);
+    IBGS_LANES_FLUSH(g_lanes_fwd);
 }
 
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
@@ -569,6 +585,14 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
 
 }  // namespace ibgs
 
+#ifdef IBGS_COUNT_LANES
+extern "C" int ibgs_debug_lanes_fwd(unsigned long long* dst, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ibgs::g_lanes_fwd), sizeof(unsigned long long) * 4, 0, hipMemcpyDeviceToHost);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(ibgs::g_lanes_fwd), z, sizeof(z), 0, hipMemcpyHostToDevice); }
+    return rc;
+}
+#endif
 #ifdef IBGS_TRACE_WAVES
 extern "C" int ibgs_debug_trace_fwd(void* dst, size_t bytes)
 {

@@ -441,3 +441,243 @@ def assert_replicas_identical(tensors, group=None, what="parameters"):
     if not torch.equal(lo, hi):
         bad = [i // 2 for i in range(0, cs.numel(), 2) if not (lo[i] == hi[i] and lo[i + 1] == hi[i + 1])]
         raise RuntimeError("view-parallel replicas diverged: %s %s differ between ranks (unsynchronised densification?)" % (what, bad))
+
+
+# ---- the step without the replicated optimiser (round 4) ---------------------------------------------------------------
+# With the rasterizer at ~1.7 ms per view the serial terms of an 8-GPU step are the exchange and the optimiser: every rank running Adam over
+# all P x 59 floats (0.32 ms at 1 M Gaussians, ibgs_adam_step) repeats work eight times.  ShardedOptimizerStep splits the Gaussians into
+# N contiguous row ranges, one per rank:
+#   1. dense gradients:  REDUCE-SCATTER per parameter -- a rank receives the all-rank sum of ITS rows only (half the bytes of an all-reduce);
+#   2. SH gradients:     the dL/dRGB factors of the views travel by ALL-TO-ALL -- a rank receives every view's factors for its rows only
+#                        (P x 3 floats in total instead of N x P x 3 with the all-gather of ViewParallelReducer) and rebuilds dL/dsh for its rows;
+#   3. Adam on the rank's rows of every parameter (1 / N of the work; the moments of the other rows are not touched);
+#   4. ALL-GATHER of the updated rows: every rank holds the full, identical parameters again.
+# The optimiser's state tensors stay full-sized (the reference's densification surgery on them keeps working: scene/gaussian_model.py:
+# 377-463) but only a rank's own rows are current: call gather_state() before densify_and_prune, before a checkpoint, and whenever the
+# row ranges change.  Same sums as ViewParallelReducer + a replicated step; with two ranks bit-identical (a + b = b + a), with more ranks
+# up to the summation order of the backend's reduce-scatter.
+def _rows(P, world, rank):
+    chunk = (P + world - 1) // world
+    return chunk, min(P, rank * chunk), min(P, (rank + 1) * chunk)
+
+
+def _fused_adam_rows(entries):
+    """Default `adam`: ibgs_adam_step (csrc/adam.hip) on row slices.  entries: dicts with param / grad / exp_avg / exp_avg_sq (contiguous
+    slices), lr, betas, eps, step (the 1-based step count)."""
+    import ctypes, math
+    from . import _lib
+    lib = _lib.load()
+    ds = []
+    for e in entries:
+        if e["param"].numel() == 0:
+            continue
+        if not e["param"].is_cuda:
+            raise RuntimeError("ShardedOptimizerStep: the default Adam runs on the MI355X only (ibgs_adam_step); there is no CPU path")
+        d = _lib.AdamTensor()
+        d.param, d.grad, d.exp_avg, d.exp_avg_sq = e["param"].data_ptr(), e["grad"].data_ptr(), e["exp_avg"].data_ptr(), e["exp_avg_sq"].data_ptr()
+        d.numel = e["param"].numel()
+        b1, b2 = e["betas"]
+        d.lr, d.beta1, d.beta2, d.eps = float(e["lr"]), float(b1), float(b2), float(e["eps"])
+        d.bias_correction1 = 1.0 - math.pow(b1, e["step"]); d.bias_correction2 = 1.0 - math.pow(b2, e["step"])
+        ds.append(d)
+    if not ds:
+        return
+    dev = entries[0]["param"].device
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for i in range(0, len(ds), 16):
+            part = ds[i:i + 16]
+            arr = (_lib.AdamTensor * len(part))(*part)
+            rc = lib.ibgs_adam_step(stream, len(part), ctypes.cast(arr, ctypes.c_void_p))
+            if rc < 0:
+                raise RuntimeError("ibgs_adam_step failed (%d): %s" % (rc, _lib.last_error()))
+
+
+class ShardedOptimizerStep:
+    """Exchange + optimiser step of one view-parallel iteration with the Adam work split over the ranks (see above).
+
+        opt = FusedAdam(param_groups, lr=0.0, eps=1e-15)            # or the reference's torch.optim.Adam: only its state layout is used
+        sh = ShardedOptimizerStep(opt, sh=[f_dc, f_rest], means3D=xyz)
+        with sh.capture():                                          # one or more backward passes (views) per rank
+            loss.backward()
+        sh.step()                                                   # instead of reducer.reduce(); optimizer.step()
+        ...
+        sh.gather_state(); gaussians.densify_and_prune(...)         # the moments of all rows, before anything reads or reshapes them
+
+    Every parameter of `optimizer` must be a per-Gaussian tensor (first dimension P); `sh` names the SH leaves whose gradient arrives
+    factored (rasterizer.capture_sh_factors), `means3D` the positions.  `expand` / `adam` replace the HIP kernels in the CPU tests."""
+
+    def __init__(self, optimizer, sh=None, means3D=None, group=None, expand=None, adam=None):
+        self.opt, self._sh, self._means3D, self.group = optimizer, sh, means3D, group
+        self._expand, self._adam = expand, (adam or _fused_adam_rows)
+        self.items = None
+        self.last_bytes = 0
+        self.state_is_gathered = True          # nothing is sharded before the first step
+        self._agree = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == "gloo":
+                self._agree = group if group is not None else dist.group.WORLD
+            else:
+                self._agree = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend="gloo")
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    def _params(self):
+        return [(g, p) for g in self.opt.param_groups for p in g["params"]]
+
+    def capture(self):
+        from . import rasterizer
+        me = self
+
+        class _Ctx(rasterizer.capture_sh_factors):
+            def __enter__(self):
+                me.items = super().__enter__()
+                return me.items
+        return _Ctx()
+
+    def _state(self, p):
+        st = self.opt.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self):
+        world, rank = self._world()
+        items, self.items = self.items or [], None
+        sh_parts = _resolve(self._sh)
+        m3 = _resolve(self._means3D)
+        means3D = m3[0] if m3 else None
+        pairs = self._params()
+        if not pairs:
+            return
+        P = int(pairs[0][1].shape[0])
+        err = None
+        for _, p in pairs:
+            if int(p.shape[0]) != P or not p.is_contiguous():
+                err = "ShardedOptimizerStep: every parameter must be a contiguous per-Gaussian tensor with the same first dimension"
+        M = int(items[0]["M"]) if items else -1
+        degree = int(items[0]["degree"]) if items else -1
+        if err is None and items and (means3D is None or int(means3D.shape[0]) != P or any(int(it["dcolor"].shape[0]) != P for it in items)):
+            err = "ShardedOptimizerStep: the captured views / means3D do not have the optimiser's P = %d rows (stale references after densification?)" % P
+        if err is None and items and sum(int(q.shape[1]) for q in sh_parts) != M:
+            err = "ShardedOptimizerStep: the `sh` leaves hold %d coefficients, the captured views M = %d" % (sum(int(q.shape[1]) for q in sh_parts), M)
+        has_grad = [int(p.grad is not None) for _, p in pairs]
+        if world > 1:          # ranks must agree on the collective sequence before the first one starts (as ViewParallelReducer does)
+            mine = [len(items), P, M, degree] + has_grad
+            v = torch.tensor(mine + [-x for x in mine] + [int(err is not None)], dtype=torch.int64)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._agree)
+            k = len(mine)
+            if bool(v[2 * k].item()):
+                raise RuntimeError(err if err is not None else "ShardedOptimizerStep: another rank failed its local checks; no collective was started")
+            if v[:k].tolist() != [-x for x in v[k:2 * k].tolist()]:
+                raise RuntimeError("ShardedOptimizerStep: ranks disagree on (views captured, P, M, degree, which parameters have gradients)")
+        elif err is not None:
+            raise RuntimeError(err)
+        chunk, lo, hi = _rows(P, world, rank)
+        n = hi - lo
+        dev = pairs[0][1].device
+        self.last_bytes = 0
+
+        def scatter_sum(g):          # (P, ...) local gradient -> (n, ...) all-rank sum of this rank's rows
+            flat = g.reshape(P, -1)
+            if world == 1:
+                return flat
+            k = flat.shape[1]
+            if P == chunk * world and flat.is_contiguous():
+                src = flat
+            else:
+                src = torch.zeros(chunk * world, k, dtype=flat.dtype, device=flat.device); src[:P] = flat
+            out = torch.empty(chunk, k, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_bytes += out.numel() * 4 * (world - 1)
+            return out[:n]
+
+        # ---- 2. the SH leaves: factors by all-to-all, expansion for the own rows
+        g_sh = None
+        if items:
+            n_local = len(items)
+            if world > 1:
+                send = torch.zeros(world, n_local, chunk, 3, dtype=torch.float32, device=dev)
+                for i, it in enumerate(items):
+                    pad = torch.zeros(chunk * world, 3, dtype=torch.float32, device=dev); pad[:P] = it["dcolor"]
+                    send[:, i] = pad.view(world, chunk, 3)
+                recv = torch.empty_like(send)
+                dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)          # recv[q, i] = view i of rank q, my rows
+                cam = torch.stack([it["campos"].to(dev).reshape(3) for it in items]).contiguous()
+                cams = torch.empty(world * n_local, 3, dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(cams, cam, group=self.group)
+                dcolor = recv.view(world * n_local, chunk, 3)[:, :n].contiguous()
+                self.last_bytes += (recv.numel() // world) * (world - 1) * 4
+            else:
+                dcolor = torch.stack([it["dcolor"] for it in items]).contiguous()
+                cams = torch.stack([it["campos"].to(dev).reshape(3) for it in items]).contiguous()
+            expand = self._expand
+            if expand is None:
+                from .shgrad import sh_grad_from_views as expand
+            with torch.enable_grad():          # (a replacement `expand` may differentiate through an SH evaluation: tests)
+                g_sh = expand(means3D.detach()[lo:hi].contiguous(), cams, dcolor, degree, M) if n > 0 else torch.zeros(0, M, 3, device=dev)
+            g_sh = g_sh.detach()
+        # ---- 1. + 3. per parameter: the sum of the own rows, then Adam on them
+        entries, off = [], 0
+        sh_off = {}
+        for q in sh_parts:
+            sh_off[id(q)] = off; off += int(q.shape[1])
+        for (group, p), hg in zip(pairs, has_grad):
+            is_sh = id(p) in sh_off
+            g_rows = scatter_sum(p.grad) if hg else None
+            if is_sh and g_sh is not None:
+                o = sh_off[id(p)]
+                part = g_sh[:, o:o + int(p.shape[1])].reshape(n, -1)
+                g_rows = part if g_rows is None else g_rows + part          # a dense SH gradient (another loss term) on top of the factored one
+            if g_rows is None:
+                continue
+            st = self._state(p)
+            st["step"] += 1
+            pr = p.data.reshape(P, -1)
+            entries.append({"param": pr[lo:hi], "grad": g_rows.contiguous(), "exp_avg": st["exp_avg"].reshape(P, -1)[lo:hi],
+                            "exp_avg_sq": st["exp_avg_sq"].reshape(P, -1)[lo:hi], "lr": group["lr"], "betas": group["betas"], "eps": group["eps"],
+                            "step": float(st["step"]), "full": p})
+        self._adam(entries)
+        # ---- 4. every rank gets every row back
+        if world > 1:
+            for e in entries:
+                self._gather_rows(e["full"].data, P, chunk, lo, hi, world)
+            self.state_is_gathered = False
+        for _, p in pairs:
+            p.grad = None
+
+    def _gather_rows(self, full, P, chunk, lo, hi, world):
+        flat = full.reshape(P, -1)
+        k = flat.shape[1]
+        if P == chunk * world:
+            dist.all_gather_into_tensor(flat, flat[lo:hi].clone(), group=self.group)
+        else:
+            mine = torch.zeros(chunk, k, dtype=flat.dtype, device=flat.device); mine[:hi - lo] = flat[lo:hi]
+            allr = torch.empty(chunk * world, k, dtype=flat.dtype, device=flat.device)
+            dist.all_gather_into_tensor(allr, mine, group=self.group)
+            flat.copy_(allr[:P])
+        self.last_bytes += chunk * k * 4 * (world - 1)
+
+    @torch.no_grad()
+    def gather_state(self):
+        """All-gather the Adam moments so that every rank holds them for every row (before densification surgery, checkpoints, or a change
+        of the row ranges).  No-op when nothing has been stepped since the last call."""
+        world, rank = self._world()
+        if world == 1 or self.state_is_gathered:
+            self.state_is_gathered = True
+            return
+        for _, p in self._params():
+            st = self.opt.state.get(p)
+            if not st:
+                continue
+            P = int(p.shape[0])
+            chunk, lo, hi = _rows(P, world, rank)
+            for key in ("exp_avg", "exp_avg_sq"):
+                self._gather_rows(st[key], P, chunk, lo, hi, world)
+        self.state_is_gathered = True

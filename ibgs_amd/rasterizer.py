@@ -17,6 +17,7 @@ HIP library.  If the library is missing the import of ``_lib`` raises -- there i
 import collections
 import ctypes
 import os
+import threading
 from typing import NamedTuple
 
 import torch
@@ -138,6 +139,10 @@ def _dev_f32(t, device):
     """contiguous fp32 tensor on `device`, or None for the reference's 'empty tensor = not provided'."""
     if t is None or t.numel() == 0:
         return None
+    # the common case first -- an fp32, contiguous, 16-byte-aligned tensor that already lives on the device -- in as few Python-level calls as possible
+    # (this runs ~30 times per step; DESIGN.md section 7, host time)
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous() and not (t.data_ptr() & 15):
+        return t
     if t.device != device:
         t = t.to(device)
     if t.dtype != torch.float32:
@@ -230,6 +235,58 @@ def _gacc(device, P):
 _zero_scalar = {}
 
 
+class _CallState(threading.local):
+    """Per-thread scratch of the Python layer: ONE ForwardArgs / BackwardArgs structure that is cleared and refilled per call (allocating a
+    ~70-field ctypes structure costs ~15 us), and ONE arena callback whose closure hands the binning tensor of the current call back through
+    `holder` (creating a ctypes callback per call: ~10 us)."""
+
+    def __init__(self):
+        self.fwd = _lib.ForwardArgs()
+        self.bwd = _lib.BackwardArgs()
+        self.holder = {}
+        self.alloc_device = None
+
+        def _alloc(nbytes, _user):
+            try:
+                self.holder["t"] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.alloc_device)
+                return self.holder["t"].data_ptr()
+            except Exception as ex:  # surfaces as IBGS_ERR_ALLOC
+                self.holder["err"] = ex
+                return 0
+
+        self.cb = _lib.ALLOC_FN(_alloc)
+
+    def forward_args(self, device):
+        ctypes.memset(ctypes.byref(self.fwd), 0, ctypes.sizeof(self.fwd))
+        self.holder.clear()
+        self.alloc_device = device
+        return self.fwd, self.holder, self.cb
+
+    def backward_args(self):
+        ctypes.memset(ctypes.byref(self.bwd), 0, ctypes.sizeof(self.bwd))
+        return self.bwd
+
+
+_call_state = _CallState()
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already the current device (the context manager costs ~8 us per entry)."""
+
+    def __init__(self, device):
+        idx = device.index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def _zeros_view(shape, device, dtype=torch.float32):
     """Zeros of the given shape as a zero-stride view of ONE cached element per (device, dtype): no allocation,
     no fill kernel.  Read-only by construction (PyTorch refuses in-place writes through overlapping views)."""
@@ -268,7 +325,7 @@ class _CModule:
         P = int(means3D.size(0)); H = int(image_height); W = int(image_width)
         render_geo = bool(render_geo); render_depth_only = bool(render_depth_only)
 
-        with torch.cuda.device(device):
+        with _on_device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             means3D_c = _dev_f32(means3D, device)
             sh_c = _dev_f32(sh, device); colors_c = _dev_f32(colors, device)
@@ -317,18 +374,7 @@ class _CModule:
                 M = 0 if sh_c is None else int(sh_c.size(1))
                 geomBuffer = torch.empty(lib.ibgs_required_geom(P), dtype=torch.uint8, device=device)
                 imgBuffer = torch.empty(lib.ibgs_required_img(W, H), dtype=torch.uint8, device=device)
-                holder = {}
-
-                def _alloc(nbytes, _user):
-                    try:
-                        holder["t"] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-                        return holder["t"].data_ptr()
-                    except Exception as ex:  # surfaces as IBGS_ERR_ALLOC
-                        holder["err"] = ex
-                        return 0
-
-                cb = _lib.ALLOC_FN(_alloc)
-                a = _lib.ForwardArgs()
+                a, holder, cb = _call_state.forward_args(device)
                 a.stream = stream
                 a.P, a.D, a.M, a.W, a.H = P, int(degree), M, W, H
                 a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c)
@@ -421,7 +467,7 @@ class _CModule:
         P = int(means3D.size(0))
         H = int(normal_map_pixels.size(1)); W = int(normal_map_pixels.size(2))
         render_geo = bool(render_geo)
-        with torch.cuda.device(device):
+        with _on_device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             sh_c = _dev_f32(sh, device)
             M = int(sh.size(1)) if sh.dim() == 3 else 0     # keeps (0, M, 3) for P == 0 so autograd accepts the shape
@@ -468,7 +514,7 @@ class _CModule:
                 gacc_ent = _gacc(device, P)
                 grad_acc = gacc_ent[0]
                 radii_c = radii.contiguous()
-                a = _lib.BackwardArgs()
+                a = _call_state.backward_args()
                 a.stream = stream
                 a.P, a.D, a.M, a.W, a.H = P, int(degree), M, W, H
                 a.R = int(R)

@@ -37,9 +37,11 @@ def main():
     # sources: bench.py drops these numbers as soon as either differs from what it is timing
     workload = sys.argv[2] if len(sys.argv) > 2 else "C3 opacity=init"
     sys.path.insert(0, ROOT)
-    from ibgs_amd._build import csrc_sha
+    from ibgs_amd._build import csrc_sha, tu_shas
     import datetime
-    out = {"tag": tag, "workload": workload, "csrc_sha": csrc_sha(), "date": datetime.date.today().isoformat()}
+    # stamps: the whole source tree (csrc_sha) and every translation unit on its own (tu_shas): bench.py quotes a kernel's counters while the
+    # unit that holds the kernel is unchanged
+    out = {"tag": tag, "workload": workload, "csrc_sha": csrc_sha(), "tu_shas": tu_shas(), "date": datetime.date.today().isoformat()}
     st = find(tag + "_stats", "kernel_stats.csv")
     if st:
         rows = list(csv.DictReader(open(st)))
@@ -60,13 +62,29 @@ def main():
         if not cc:
             continue
         for r in csv.DictReader(open(cc)):
+            if "ibgs::" not in r["Kernel_Name"]:
+                continue          # every kernel of the library (the step's torch kernels -- three adds of the loss -- are not the rasterizer's)
             per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    counters = {}
-    for k, v in per_kernel.items():
-        if not any(s in k for s in ("render_", "preprocess", "radix_", "onesweep", "emit", "scan", "ranges", "expand_", "cell_", "gather_", "geo_window", "pack_rgba")):
-            continue
-        counters[k] = {c: sum(x) / len(x) for c, x in v.items()}      # mean per launch
+    counters = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in per_kernel.items()}      # mean per launch
     out["per_launch_counters"] = counters
+    # HBM traffic of ONE STEP as measured: sum over the library's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches per step.  The PMC passes
+    # run full steps and forward-only passes: a forward kernel's launches are counted per forward (= launches of the preprocess kernel),
+    # a backward / loss kernel's per backward (= launches of preprocess_bwd)
+    launches = {k: len(v.get("FETCH_SIZE", [])) for k, v in per_kernel.items()}
+    n_fwd = max([n for k, n in launches.items() if "preprocess_kernel" in k] or [0])
+    n_bwd = max([n for k, n in launches.items() if "preprocess_bwd" in k] or [0])
+    if n_fwd and n_bwd:
+        total, table = 0.0, {}
+        for k, c in counters.items():
+            if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            bwd = any(s in k for s in ("render_bwd", "geo_window", "tile_order", "preprocess_bwd", "l1_", "det_"))
+            per_step = launches[k] / float(n_bwd if bwd else n_fwd)
+            b = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 * per_step
+            table[k] = {"launches_per_step": round(per_step, 3), "bytes_per_step": b}
+            total += b
+        out["step_traffic_measured"] = {"bytes_per_step": total, "by_kernel": table,
+                                        "how": "sum over ibgs:: kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB x launches per step (separate --pmc passes; MI355X_MICROARCH.md gfx950 correction)"}
     for k, c in counters.items():
         if "render_bwd" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch, write = c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0

@@ -316,3 +316,102 @@ def test_local_errors_sparse_agreement_and_bucket_resident_gradients(tmp_path):
     assert torch.equal(res[0]["c_split"], res[1]["c_split"])
     assert res[0]["c_restored"] and res[1]["c_restored"]
     assert not torch.equal(res[0]["c_next"], res[1]["c_next"])                 # the ranks' own streams stay independent
+
+
+# ---- round 4: the step without the replicated optimiser: reduce-scatter -> Adam on the rank's rows -> all-gather -------------------------
+def _adam_ref(entries):
+    """torch.optim.Adam's single-tensor update (no weight decay / amsgrad), in place on whatever rows it is handed."""
+    import math
+    for e in entries:
+        p, g, m, v = e["param"], e["grad"], e["exp_avg"], e["exp_avg_sq"]
+        b1, b2 = e["betas"]
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** e["step"], 1 - b2 ** e["step"]
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(e["eps"])
+        p.addcdiv_(m, denom, value=-e["lr"] / bc1)
+
+
+def _worker_sharded(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init_from_env(backend="gloo")
+    out = {}
+    for P in (40, 41):          # rows divide evenly over the ranks / they do not (padded collectives)
+        M, deg = 16, 3
+
+        def fresh():
+            g = torch.Generator().manual_seed(5)
+            return {"xyz": torch.randn(P, 3, generator=g).requires_grad_(True), "f_dc": torch.randn(P, 1, 3, generator=g).requires_grad_(True),
+                    "f_rest": torch.randn(P, M - 1, 3, generator=g).requires_grad_(True), "opa": torch.rand(P, 1, generator=g).requires_grad_(True)}
+
+        def groups(s):
+            return [{"params": [s["xyz"]], "lr": 1e-2, "name": "xyz"}, {"params": [s["f_dc"]], "lr": 3e-3, "name": "f_dc"},
+                    {"params": [s["f_rest"]], "lr": 2e-4, "name": "f_rest"}, {"params": [s["opa"]], "lr": 5e-2, "name": "opacity"}]
+        A, B = fresh(), fresh()          # A: sharded step; B: today's path (ViewParallelReducer + the same Adam on every row, on every rank)
+        optA = torch.optim.Adam(groups(A), lr=0.0, eps=1e-15); optB = torch.optim.Adam(groups(B), lr=0.0, eps=1e-15)
+        sh = vdist.ShardedOptimizerStep(optA, sh=[A["f_dc"], A["f_rest"]], means3D=A["xyz"], expand=_expand_ref, adam=_adam_ref)
+        red = vdist.ViewParallelReducer([B["xyz"], B["f_dc"], B["f_rest"], B["opa"]], sh=[B["f_dc"], B["f_rest"]], means3D=B["xyz"], expand=_expand_ref)
+        gr = torch.Generator().manual_seed(100 + rank)
+        for step in range(3):
+            views = [{"dcolor": torch.randn(P, 3, generator=gr), "campos": torch.randn(3, generator=gr) * 4.0, "degree": deg, "M": M} for _ in range(2)]
+            gx, go = torch.randn(P, 3, generator=gr), torch.randn(P, 1, generator=gr)
+            extra = torch.randn(P, 1, 3, generator=gr) if step == 1 else None          # another loss term on an SH leaf: a dense gradient on top of the factored one
+            for s, drv in ((A, sh), (B, red)):
+                with drv.capture() as sink:
+                    for it in views:
+                        sink.append(dict(it))
+                s["xyz"].grad = gx.clone(); s["opa"].grad = go.clone()
+                if extra is not None:
+                    s["f_dc"].grad = extra.clone()
+            sh.step()
+            red.reduce()
+            entries = []
+            for gdict in optB.param_groups:
+                p = gdict["params"][0]
+                st = optB.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0); st["exp_avg"] = torch.zeros_like(p); st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                entries.append({"param": p.data, "grad": p.grad, "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"], "lr": gdict["lr"],
+                                "betas": gdict["betas"], "eps": gdict["eps"], "step": float(st["step"])})
+            _adam_ref(entries)
+            for p in B.values():
+                p.grad = None
+        chunk, lo, hi = vdist._rows(P, world, rank)
+        stale = {k: optA.state[A[k]]["exp_avg"].clone() for k in A}
+        sh.gather_state()
+        out[P] = {"A": {k: v.detach().clone() for k, v in A.items()}, "B": {k: v.detach().clone() for k, v in B.items()},
+                  "mA": {k: optA.state[A[k]]["exp_avg"].clone() for k in A}, "mB": {k: optB.state[B[k]]["exp_avg"].clone() for k in B},
+                  "vA": {k: optA.state[A[k]]["exp_avg_sq"].clone() for k in A}, "vB": {k: optB.state[B[k]]["exp_avg_sq"].clone() for k in B},
+                  "stale_other_rows_untouched": all(not stale[k][:lo].any() and not stale[k][hi:].any() for k in A), "rows": (lo, hi), "bytes": sh.last_bytes}
+    # a rank whose captured views disagree makes EVERY rank raise before a collective starts
+    s = {"xyz": torch.randn(8, 3).requires_grad_(True)}
+    opt = torch.optim.Adam([{"params": [s["xyz"]], "lr": 1e-2}])
+    bad = vdist.ShardedOptimizerStep(opt, means3D=s["xyz"], expand=_expand_ref, adam=_adam_ref)
+    s["xyz"].grad = torch.randn(8, 3)
+    with bad.capture() as sink:
+        for _ in range(rank):
+            sink.append({"dcolor": torch.randn(8, 3), "campos": torch.randn(3), "degree": 0, "M": 1})
+    try:
+        bad.step(); out["bad"] = "no error"
+    except RuntimeError as ex:
+        out["bad"] = str(ex)
+    torch.save(out, os.path.join(out_dir, "s%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_equals_the_replicated_step(tmp_path):
+    world = 2
+    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "s%d.pt" % r)) for r in range(world)]
+    for P in (40, 41):
+        for k in ("xyz", "f_dc", "f_rest", "opa"):
+            for r in res:
+                assert torch.equal(r[P]["A"][k], r[P]["B"][k]), (P, k)          # sharded == replicated, bit for bit (two ranks: a + b = b + a)
+                assert torch.equal(r[P]["mA"][k], r[P]["mB"][k]) and torch.equal(r[P]["vA"][k], r[P]["vB"][k]), (P, k)      # ... the gathered moments too
+            assert torch.equal(res[0][P]["A"][k], res[1][P]["A"][k])            # identical replicas
+        assert all(r[P]["stale_other_rows_untouched"] for r in res)              # before gather_state a rank only holds its own rows' moments
+        assert res[0][P]["rows"][1] == res[1][P]["rows"][0] and res[1][P]["rows"][1] == P
+    # rank 1 captured a view (and has no SH leaf for it), rank 0 none: rank 1 reports its local error, rank 0 raises too instead of waiting in a collective
+    assert "sh` leaves hold 0 coefficients" in res[1]["bad"] and "another rank failed its local checks" in res[0]["bad"], [r["bad"] for r in res]

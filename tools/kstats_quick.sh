@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ksq
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ksq -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-geo-line $@ > gpurun_out/ksq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ksq -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-geo-line --no-trained-geo-line $@ > gpurun_out/ksq.log 2>&1
 python3 - <<'PY'
 import csv, glob
 for f in glob.glob("gpurun_out/ksq/*/*kernel_stats.csv"):

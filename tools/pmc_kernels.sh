@@ -5,7 +5,7 @@ pat="$1"; shift
 n=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
   n=$((n+1)); rm -rf gpurun_out/pk_$n
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pk_$n -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-geo-line "$@" > gpurun_out/pk_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pk_$n -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-geo-line --no-trained-geo-line "$@" > gpurun_out/pk_$n.log 2>&1
 done
 python3 - "$pat" <<'PY'
 import csv, glob, collections, sys

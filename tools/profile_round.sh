@@ -8,7 +8,7 @@ shift
 extra="$@"
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-B="--no-cpu-baseline --no-extras --no-geo-line $extra"
+B="--no-cpu-baseline --no-extras --no-geo-line --no-trained-geo-line $extra"
 rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_sq gpurun_out/${tag}_tcc gpurun_out/${tag}_mfma
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 20 --warmup 3 $B > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_stats.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- python3 bench.py --steps 5 --warmup 2 $B > /dev/null 2> gpurun_out/${tag}_fetch.log
