@@ -52,6 +52,8 @@ def parse(argv=None):
     ap.add_argument("--densify-every", type=int, default=0, help="0 = no densification")
     ap.add_argument("--densify-from", type=int, default=20)
     ap.add_argument("--densify-until", type=int, default=10 ** 9)
+    ap.add_argument("--sharded-optimizer", action="store_true",
+                    help="more than one rank: reduce-scatter + Adam on the rank's rows + all-gather (dist.ShardedOptimizerStep) instead of all-reduce + the same Adam on every rank")
     ap.add_argument("--quiet", action="store_true")
     return ap.parse_args(argv)
 
@@ -123,6 +125,10 @@ def run(a, rasterize=None):
     opt = FusedAdam([{"params": [getattr(pc, attr)], "lr": lr, "name": name} for name, attr, lr in GROUPS], lr=0.0, eps=1e-15)
     params = lambda: [g["params"][0] for g in opt.param_groups]          # densification replaces the Parameters: always ask the optimiser
     red = vdist.ViewParallelReducer(params, sh=lambda: [pc._features_dc, pc._features_rest], means3D=lambda: pc._xyz) if world > 1 else None
+    sharded = None
+    if world > 1 and a.sharded_optimizer:          # the same sums and the same update, the optimiser's work split over the ranks
+        sharded = vdist.ShardedOptimizerStep(opt, sh=lambda: [pc._features_dc, pc._features_rest], means3D=lambda: pc._xyz)
+        red = None
     stats = [torch.zeros(a.points, 1, device=dev), torch.zeros(a.points, 1, device=dev)]
 
     def refresh_depths():
@@ -155,7 +161,10 @@ def run(a, rasterize=None):
                 box.update(out=out)
                 return loss
 
-            if red is not None:
+            if sharded is not None:
+                with sharded.capture():
+                    loss = fwd_bwd()
+            elif red is not None:
                 with red.capture():
                     loss = fwd_bwd()
                 red.reduce(average=True)
@@ -165,9 +174,14 @@ def run(a, rasterize=None):
             if a.densify_every and it < a.densify_until:          # train.py:400-410: statistics of every view of the step
                 gn, _gna, cnt, _rmax = vdist.allreduce_densification_stats(out["viewspace_points"].grad, out["viewspace_points_abs"].grad, out["radii"])
                 stats[0] += gn; stats[1] += cnt
-            opt.step()
+            if sharded is not None:
+                sharded.step(average=True)          # reduce-scatter, Adam on this rank's rows, all-gather of the parameters
+            else:
+                opt.step()
             hist["loss"].append(float(loss.detach())); hist["psnr"].append(psnr(out["render"].detach(), targets[vid])); hist["points"].append(int(pc._xyz.shape[0]))
             if a.densify_every and a.densify_from <= it < a.densify_until and (it + 1) % a.densify_every == 0:
+                if sharded is not None:
+                    sharded.gather_state()          # the surgery below reads and reshapes the moments of EVERY row
                 stats, n_split, n_pruned = densify_step(pc, opt, stats, it, world)
                 hist["split"] += n_split; hist["pruned"] += n_pruned
                 if world > 1:

@@ -547,7 +547,8 @@ class ShardedOptimizerStep:
         return st
 
     @torch.no_grad()
-    def step(self):
+    def step(self, average=False):
+        """average: divide the summed gradients by the number of ranks (ViewParallelReducer.reduce(average=True))"""
         world, rank = self._world()
         items, self.items = self.items or [], None
         sh_parts = _resolve(self._sh)
@@ -637,6 +638,8 @@ class ShardedOptimizerStep:
                 g_rows = part if g_rows is None else g_rows + part          # a dense SH gradient (another loss term) on top of the factored one
             if g_rows is None:
                 continue
+            if average and world > 1:
+                g_rows = g_rows / world
             st = self._state(p)
             st["step"] += 1
             pr = p.data.reshape(P, -1)

@@ -64,3 +64,12 @@ def test_example_training_view_parallel_two_ranks_on_one_gpu():
     m = re.search(r"loss ([0-9.]+) -> ([0-9.]+)", r.stdout)
     assert m and float(m.group(2)) < 0.85 * float(m.group(1)), r.stdout
     assert re.search(r"split [1-9]", r.stdout), r.stdout
+    # the same run with the optimiser's work split over the ranks (dist.ShardedOptimizerStep: reduce-scatter, Adam on the rank's rows, all-gather):
+    # with two ranks the sums are the same bits (a + b = b + a) and Adam is elementwise, so the whole trajectory must repeat -- same losses, same
+    # PSNR, the same points split and pruned
+    cmd = r.args + ["--sharded-optimizer"]
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, (r2.stdout + r2.stderr)[-3000:]
+    assert "replicas in sync: True" in r2.stdout, r2.stdout
+    tail = lambda out: re.search(r"loss [0-9.]+ -> [0-9.]+, psnr [0-9.]+ -> [0-9.]+ dB, points \d+ -> \d+ \(split \d+, pruned \d+\)", out).group(0)
+    assert tail(r2.stdout) == tail(r.stdout), (tail(r.stdout), tail(r2.stdout))
