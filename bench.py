@@ -261,7 +261,9 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     # only see what the steps themselves allocate.  A training loop should do the same once after set-up.
     # The collection runs BEFORE the warm-up steps: it idles the GPU for those 40 ms, and the first ten steps after an idle gap run up
     # to 30 % slower while the clocks come back (per_step_ms_hipevent showed 2.31, 1.97, 1.94, 1.91 ... 1.79 at the start of the timed
-    # region when the collection sat between warm-up and timing) -- that is what warm-up steps are for.
+    # region when the collection sat between warm-up and timing) -- that is what warm-up steps are for.  (Round 4: 40 ms of dense matrix products or
+    # of 256 MB copies in front of the warm-up steps do NOT shorten that ramp -- it follows the workload's own kernels; with 25 warm-up steps the
+    # timed steps start at the steady value, with the driver's 5 the first seven or so are 1-5 % slow.  Left as it is: W is the driver's.)
     gc.collect()
     gc.freeze()
     for _ in range(warmup):
@@ -585,6 +587,17 @@ def main():
         fence(1)
         extras["ms_per_step_with_torch_l1"] = (time.perf_counter() - t0) / a.steps * 1e3
         Workload.torch_l1 = False
+        # (f) the same step when nobody asks for the densification statistic |dL/dmean2D| (means2D_abs without requires_grad: after densify_until_iter,
+        # train.py:400-410, and at test time): IBGS_FLAG_NO_ABS_GRAD, the colour blend skips the two |.| moments.  Never `value`.
+        wl.leaves["means2D_abs"].requires_grad_(False)
+        for _ in range(3):
+            wl.local_step()
+        fence(1); t0 = time.perf_counter()
+        for _ in range(a.steps):
+            wl.local_step()
+        fence(1)
+        extras["ms_per_step_without_abs_grad"] = (time.perf_counter() - t0) / a.steps * 1e3
+        wl.leaves["means2D_abs"].requires_grad_(True)
         # the timed loop renders ONE camera again and again, so the forward's launch order hint (the previous backward's balanced order for this
         # camera, rasterizer.ORDER_HINT) is always fresh; a trainer revisits a camera only every few hundred steps.  The same step without it:
         _r.ORDER_HINT = False
@@ -633,7 +646,7 @@ def main():
             radii = gwl._call()[1]
             big = int((radii > 128).sum().item()); vis = int((radii > 0).sum().item())
         return {"workload": gwl.describe(opacity, 1, a.exchange), "steps": gsteps, "ms_per_step": gm["ms_step"],
-                "median_ms_hipevent": gm["median_ms"], "max_ms_hipevent": gm["max_ms"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
+                "median_ms_hipevent": gm["median_ms"], "max_ms_hipevent": gm["max_ms"], "per_step_ms_hipevent": gm["per_step"], "fps": 1000.0 / gm["ms_step"], "forward_only_ms": gm["fwd_ms"],
                 "num_rendered": int(gwl.R), "gaussians_in_frustum": vis, "gaussians_radius_gt_128px": big, "stages_ms": gm["stages"], "roofline": grf}
 
     geo_line = trained_geo = None

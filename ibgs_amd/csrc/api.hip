@@ -438,7 +438,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     if (a.P <= 0) return 0;                                       // rasterize_points.cu:221
     if (!a.geom || !a.img || (!a.binning && a.R > 0)) { set_error("backward needs the forward's arenas"); return -IBGS_ERR_INVALID; }
     if (!a.grad_acc) { set_error("grad_acc scratch required"); return -IBGS_ERR_INVALID; }
-    if (!a.dL_dmean2D || !a.dL_dmean2D_abs || !a.dL_dopacity || !a.dL_dmean3D) {
+    if (!a.dL_dmean2D || (!a.dL_dmean2D_abs && !(a.flags & IBGS_FLAG_NO_ABS_GRAD)) || !a.dL_dopacity || !a.dL_dmean3D) {
         set_error("missing gradient output"); return -IBGS_ERR_INVALID;
     }
     if (a.shs && !a.dL_dsh && !(a.flags & IBGS_FLAG_SH_FACTORED)) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }

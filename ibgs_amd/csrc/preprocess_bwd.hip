@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     if (valid && !vis) {
         // invisible (or untouched) Gaussian: every gradient is zero; written explicitly so that callers need no memset
         p.dL_dmean2D[3 * i] = 0.f; p.dL_dmean2D[3 * i + 1] = 0.f; p.dL_dmean2D[3 * i + 2] = 0.f;
-        p.dL_dmean2D_abs[3 * i] = 0.f; p.dL_dmean2D_abs[3 * i + 1] = 0.f; p.dL_dmean2D_abs[3 * i + 2] = 0.f;
+        if (p.dL_dmean2D_abs) { p.dL_dmean2D_abs[3 * i] = 0.f; p.dL_dmean2D_abs[3 * i + 1] = 0.f; p.dL_dmean2D_abs[3 * i + 2] = 0.f; }          // (NULL: IBGS_FLAG_NO_ABS_GRAD)
         if (p.dL_dconic) { p.dL_dconic[4 * i] = 0.f; p.dL_dconic[4 * i + 1] = 0.f; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = 0.f; }
         p.dL_dopacity[i] = 0.f;
         if (p.dL_dcolors) { p.dL_dcolors[3 * i] = 0.f; p.dL_dcolors[3 * i + 1] = 0.f; p.dL_dcolors[3 * i + 2] = 0.f; }
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
 
     p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y; p.dL_dmean2D[3 * i + 2] = 0.f;
     // (the blend kernels form sum |q (conic d)| with the conic in exp2 units, common.h: undone here, once per Gaussian)
-    p.dL_dmean2D_abs[3 * i] = ddelx_dx * (g0.z * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * (g0.w * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 2] = 0.f;
+    if (p.dL_dmean2D_abs) { p.dL_dmean2D_abs[3 * i] = ddelx_dx * (g0.z * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * (g0.w * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 2] = 0.f; }
     if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }
     p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
     if ((WRITE_SH || !p.shs) && p.dL_dcolors) { p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2]; }

@@ -110,7 +110,7 @@ __device__ __forceinline__ float fast_rcp(float x)
 #ifdef IBGS_COUNT_LANES
 __device__ unsigned long long g_lanes_bwd[4];
 #endif
-template <int PPL>
+template <int PPL, bool ABS = true>          // ABS = false (IBGS_FLAG_NO_ABS_GRAD): the |.| moments of dL/dmean2D are not accumulated
 __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const int tile, const int sub)
 {
     IBGS_LANES_DECL();
@@ -197,13 +197,15 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                 p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
                 if constexpr (PPL >= 2) {
                     p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
-                    lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0);
+                    if constexpr (ABS) { lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0); }
                 }
                 if constexpr (PPL == 4) {
                     p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
                     p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));          // E3 = E2 + (E1 - E0) + 128 b: three instructions, as the forward
-                    lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
-                    lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                    if constexpr (ABS) {
+                        lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
+                        lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                    }
                 }
                 if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h)
                     const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
@@ -247,7 +249,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                         else dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);      // ... - T_final (bg . g) / (1 - alpha)
                         const float qv = oG * dL_dalpha;                          // dL/dG * G
                         Q[q] = qv;
-                        aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);      // |a b| = |a| |b|: one v_fma with source modifiers
+                        if constexpr (ABS) { aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY); }      // |a b| = |a| |b|: one v_fma with source modifiers
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {   // wave-uniform
@@ -642,6 +644,14 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p)
     if (have) render_bwd_color_body<4>(p, tile, sub);
     IBGS_TRACE_END(g_trace_bwd);
 }
+__global__ void __launch_bounds__(64, 8) render_bwd_color_noabs_kernel(BwdParams p)          // IBGS_FLAG_NO_ABS_GRAD
+{
+    int tile, sub = 0;
+    bool have;
+    if (p.order) { const uint32_t t = p.order[blockIdx.x]; tile = (int)t; have = t != 0xFFFFFFFFu; }
+    else have = tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub);
+    if (have) render_bwd_color_body<4, false>(p, tile, sub);
+}
 
 // ---- balanced launch order for the colour kernel ----------------------------------------------------------------------------------
 // One wave per tile, all of them resident at once (8 160 tiles on 8 192 slots at 1080p): the dispatcher puts workgroups i and i + 1024 on the
@@ -797,7 +807,8 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             IBGS_HIP(hipGetLastError());
             p.order = im.tile_order;
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_color_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
             IBGS_HIP(hipGetLastError());
             return 0;
         }

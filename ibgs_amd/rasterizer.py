@@ -43,6 +43,10 @@ KEEP_DET_SCRATCH = False          # diagnostics: keep the last deterministic bac
 # Deterministic backward (IBGS_FLAG_DETERMINISTIC): no float atomics, gradients bit-identical from run to run (CI mode, slower).
 DETERMINISTIC = False
 
+# means2D_abs without requires_grad (nobody will read the |dL/dmean2D| statistic: after densify_until_iter, at test time) = IBGS_FLAG_NO_ABS_GRAD:
+# the colour blend skips the two |.| moments.  False: always compute them (the reference does).
+NO_ABS_GRAD_WHEN_UNUSED = True
+
 # Work decomposition of the colour blend kernels: None = by frame size (one wave per 16x16 tile from 4096 tiles on,
 # one wave per 8x8 quadrant below), "tile" / "quadrant" force one of them (tests run both against the oracle).
 WAVE_SHAPE = None
@@ -458,7 +462,7 @@ class _CModule:
                                      src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
                                      dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False, buffer_length=0):
+                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False, buffer_length=0, want_abs=True):
         """The reference's 34 positional arguments and 10 results; with `plane` (see rasterize_gaussians) two more
         results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1).  `buffer_length` (the forward's; not among the reference's
         arguments, 0 = unknown) only sizes the geo backward's scratch table."""
@@ -476,7 +480,8 @@ class _CModule:
             have_sr = scales is not None and scales.numel() != 0
             new = torch.empty if P != 0 else torch.zeros
             dL_dmeans3D = _sink_or_new("means3D", (P, 3), new, opts) if P != 0 else new(P, 3, **opts); dL_dmeans2D = new(P, 3, **opts)
-            dL_dmeans2D_abs = new(P, 3, **opts)
+            # want_abs = False (the autograd node: means2D_abs needs no gradient -- after densify_until_iter, at test time): IBGS_FLAG_NO_ABS_GRAD
+            dL_dmeans2D_abs = new(P, 3, **opts) if want_abs else None
             # gradients of inputs the mode does not use: zeros without a fill (the reference memsets them, rasterize_points.cu:196-206)
             fused = plane is not None and bool(plane[2])
             dL_dall_map = new(P, NUM_PLANE_PARAMS, **opts) if (render_geo and all_maps.numel() != 0 and P != 0 and not fused) else _zeros_view((P, NUM_PLANE_PARAMS), device)
@@ -543,7 +548,7 @@ class _CModule:
                     a.geo_table = tab.data_ptr(); a.geo_table_bytes = tab.numel()
                 a.dL_dcolor = _ptr(g_color); a.dL_dnormal = _ptr(g_normal); a.dL_ddepth = _ptr(g_depth); a.dL_dwarped = _ptr(g_warp)
                 a.grad_acc = grad_acc.data_ptr()
-                a.dL_dmean2D = dL_dmeans2D.data_ptr(); a.dL_dmean2D_abs = dL_dmeans2D_abs.data_ptr()
+                a.dL_dmean2D = dL_dmeans2D.data_ptr(); a.dL_dmean2D_abs = dL_dmeans2D_abs.data_ptr() if want_abs else None
                 a.dL_dconic = None
                 a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr() if want_colors else None
                 a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr() if want_cov else None
@@ -556,7 +561,8 @@ class _CModule:
                     a.dL_dplane_normal = _ptr(dL_dplane_normal); a.dL_dplane_offset = _ptr(dL_dplane_offset)
                 a.render_geo = int(render_geo)
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag() | tex_flag)
+                           | _lib.FLAG_CLEAR_GRAD_ACC | (_lib.FLAG_SH_FACTORED if factored else 0) | _shape_flag() | tex_flag
+                           | (0 if want_abs else _lib.FLAG_NO_ABS_GRAD))
                 if DETERMINISTIC and int(R) > 0:
                     det = torch.empty(lib.ibgs_required_deterministic_for(int(R), P, W, H, int(render_geo), int(a.flags)), dtype=torch.uint8, device=device)
                     if KEEP_DET_SCRATCH:
@@ -746,6 +752,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             kw["packed_tex"] = ctx.packed_tex
         kw["skip_unused"] = True
         kw["buffer_length"] = int(raster_settings.buffer_length)
+        kw["want_abs"] = bool(ctx.needs_input_grad[2]) or not NO_ABS_GRAD_WHEN_UNUSED
 
         # argument order of the reference's _C.rasterize_gaussians_backward (reference __init__.py:182-221)
         args = (raster_settings.bg, normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels,

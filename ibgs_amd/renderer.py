@@ -136,12 +136,21 @@ def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
     return scales, rotations, cov3D_precomp, shs, colors_precomp
 
 
+# The |dL/dmean2D| statistic (viewspace_points_abs.grad) has one reader, densification (train.py:400-410, until densify_until_iter).  A trainer
+# that is past it -- or a caller that never densifies -- sets this False: the abs sink is then created without requires_grad, the rasterizer's
+# backward runs with IBGS_FLAG_NO_ABS_GRAD (the colour blend skips the two |.| moments: -8 % of that kernel) and `viewspace_points_abs.grad`
+# stays None.  Default: the reference's behaviour.
+TRACK_ABS_GRAD = True
+
+
 def _sinks(pc):
     xyz = pc.get_xyz
     a = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
-    b = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    b = (torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0) if TRACK_ABS_GRAD else torch.zeros_like(xyz, dtype=xyz.dtype)
     try:
-        a.retain_grad(); b.retain_grad()
+        a.retain_grad()
+        if TRACK_ABS_GRAD:
+            b.retain_grad()
     except Exception:
         pass
     return a, b

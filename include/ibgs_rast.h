@@ -86,6 +86,11 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                            csrc/common.h: conic_is_risky) and drop the pairs it drops; with this flag every Gaussian
                                            takes the fast path and such pairs are blended with alpha ~= opacity */
 
+#define IBGS_FLAG_NO_ABS_GRAD 1024u /* ibgs_backward only: dL_dmean2D_abs is not wanted (it may be NULL and is not written).  It is the densification statistic of
+                                       train.py:400-410 (sum over pixels of |dL/dmean2D| per Gaussian, backward.cu:793-804): nobody reads it after
+                                       densify_until_iter or at test time.  The colour blend then skips the two |.| moments (conic x d per quadrant, two fma per
+                                       pair); every other gradient is unchanged bit for bit up to the order of the float atomics */
+
 typedef struct ibgs_forward_args {
     void* stream;
     /* problem size */
