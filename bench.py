@@ -653,15 +653,19 @@ def main():
     if world == 1 and not (a.geo or a.forward_only or a.no_geo_line):
         # second line of SURVEY 8(d) under the same clock: C3 + render_geo, n_src 4, L 4 (extra key; never part of `value`)
         del step
+        torch.cuda.empty_cache()
         gwl = Workload(a.config, rank % 8, dev, a.opacity, True, False, 1234 + rank)
         geo_line = geo_object(gwl, a.opacity, max(5, min(20, a.steps)))
         del gwl
+        torch.cuda.empty_cache()          # the next workload's blocks are then allocated during ITS warm-up (a 54 ms step appeared once in the middle of
+                                          # the trained_geo line: the caching allocator releasing and re-allocating the previous workload's blocks)
     if world == 1 and not (a.geo or a.forward_only or a.no_trained_geo_line):
         # what train.py:289-292 runs for ~77 % of its iterations: render_geo on TRAINED Gaussians -- plane-like (scene/gaussian_model.py:156-173),
         # a heavy tail of sizes (densification, :580-604), an uneven image (30 % of them in one blob), trained-like opacities.  Extra key; never `value`
         twl = Workload(a.config, rank % 8, dev, "trained", True, False, 1234 + rank, cluster=0.3, anisotropy="plane", scale_sigma=1.0)
         trained_geo = geo_object(twl, "trained", max(5, min(20, a.steps)))
         del twl
+        torch.cuda.empty_cache()
 
     if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
         extras["test_frame"] = test_frame(dev, wl.c)

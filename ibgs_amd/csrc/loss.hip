@@ -52,6 +52,22 @@ __global__ void __launch_bounds__(L1_THREADS) l1_grad_kernel(const float* __rest
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * L1_THREADS) grad[i] = one(x[i], y[i]);
 }
 
+// The gradient that the loss pass stored (sign(x - y) / n) times autograd's incoming gradient, a DEVICE scalar, in place.  A loss term that enters the
+// total with weight one (`loss = l1 + ...`) arrives with 1.0: every workgroup reads the scalar and leaves -- the backward of the term then moves no data.
+__global__ void __launch_bounds__(L1_THREADS) l1_rescale_kernel(float* __restrict__ grad, size_t n, const float* __restrict__ scale)
+{
+    const float k = *scale;
+    if (k == 1.0f) return;          // (wave-uniform: a scalar load and a branch)
+    const bool vec = (reinterpret_cast<uintptr_t>(grad) & 15u) == 0;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * L1_THREADS) {
+        float4 g = reinterpret_cast<float4*>(grad)[i];
+        g.x *= k; g.y *= k; g.z *= k; g.w *= k;
+        reinterpret_cast<float4*>(grad)[i] = g;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * L1_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * L1_THREADS) grad[i] *= k;
+}
+
 __global__ void __launch_bounds__(64) l1_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n, float* __restrict__ loss)
 {
     double v = 0.0;
@@ -91,6 +107,18 @@ extern "C" int32_t ibgs_l1_grad(void* stream, int64_t n, const float* x, const f
     size_t nb = ((size_t)n + per_block - 1) / per_block;
     if (nb > (size_t)L1_MAX_BLOCKS * 4) nb = (size_t)L1_MAX_BLOCKS * 4;
     hipLaunchKernelGGL(l1_grad_kernel, dim3((unsigned)nb), dim3(L1_THREADS), 0, s, x, y, (size_t)n, (float)(1.0 / (double)n), scale_dev, grad);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int32_t ibgs_l1_rescale(void* stream, int64_t n, float* grad, const float* scale_dev)
+{
+    if (n <= 0 || !grad || !scale_dev) { set_error("ibgs_l1_rescale: n > 0, grad and scale_dev required"); return -IBGS_ERR_INVALID; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t per_block = (size_t)L1_THREADS * 4 * 4;
+    size_t nb = ((size_t)n + per_block - 1) / per_block;
+    if (nb > (size_t)L1_MAX_BLOCKS * 4) nb = (size_t)L1_MAX_BLOCKS * 4;
+    hipLaunchKernelGGL(l1_rescale_kernel, dim3((unsigned)nb), dim3(L1_THREADS), 0, s, grad, (size_t)n, scale_dev);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -29,10 +29,14 @@ class _L1(torch.autograd.Function):
                 if len(_scratch) > 8:
                     _scratch.clear()
                 sc = _scratch[key] = torch.empty(lib.ibgs_required_l1(), dtype=torch.uint8, device=x.device)
-            rc = lib.ibgs_l1_loss(stream, x.numel(), x.data_ptr(), y.data_ptr(), None, loss.data_ptr(), sc.data_ptr(), sc.numel())
+            # value AND gradient sign(x - y) / N in the one pass over x and y (when a gradient will be asked for): the backward then only has to
+            # scale it by the incoming gradient -- and not even that when the term enters the total with weight one
+            grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            rc = lib.ibgs_l1_loss(stream, x.numel(), x.data_ptr(), y.data_ptr(), None if grad is None else grad.data_ptr(), loss.data_ptr(), sc.data_ptr(), sc.numel())
         if rc < 0:
             raise RuntimeError("ibgs_l1_loss failed (%d): %s" % (rc, _lib.last_error()))
         ctx.save_for_backward(x, y)
+        ctx.unit_grad = grad          # consumed (scaled in place) by the first backward
         ctx.shape = image.shape
         return loss
 
@@ -43,7 +47,14 @@ class _L1(torch.autograd.Function):
         x, y = ctx.saved_tensors
         lib = _lib.load()
         go = grad_out.detach().to(x.device).float().contiguous()
-        grad = torch.empty_like(x)
+        grad, ctx.unit_grad = ctx.unit_grad, None
+        if grad is not None:
+            with torch.cuda.device(x.device):
+                rc = lib.ibgs_l1_rescale(torch.cuda.current_stream(x.device).cuda_stream, grad.numel(), grad.data_ptr(), go.data_ptr())
+            if rc < 0:
+                raise RuntimeError("ibgs_l1_rescale failed (%d): %s" % (rc, _lib.last_error()))
+            return grad.view(ctx.shape), None
+        grad = torch.empty_like(x)          # a second backward through the same node (retain_graph): from x and y again
         with torch.cuda.device(x.device):
             # sign(x - y) * grad_out / N in ONE pass: the incoming gradient is read on the device (no host sync, no separate multiply)
             rc = lib.ibgs_l1_grad(torch.cuda.current_stream(x.device).cuda_stream, x.numel(), x.data_ptr(), y.data_ptr(), go.data_ptr(), grad.data_ptr())

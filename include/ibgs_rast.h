@@ -309,6 +309,9 @@ size_t ibgs_required_l1(void);
 int32_t ibgs_l1_loss(void* stream, int64_t n, const float* x, const float* y, float* grad, float* loss, char* scratch, size_t scratch_bytes);
 /* The gradient alone, scaled by a DEVICE scalar (autograd's incoming gradient; NULL = 1): grad[i] = sign(x[i] - y[i]) * (*scale_dev) / n. */
 int32_t ibgs_l1_grad(void* stream, int64_t n, const float* x, const float* y, const float* scale_dev, float* grad);
+/* ... or, when ibgs_l1_loss already stored grad = sign(x - y) / n: grad[i] *= *scale_dev in place.  A scale of exactly 1.0 (a loss term that is
+ * added to the total unweighted) is detected on the device and moves no data: value + gradient of the term then cost ONE pass over x and y. */
+int32_t ibgs_l1_rescale(void* stream, int64_t n, float* grad, const float* scale_dev);
 
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other

@@ -32,3 +32,19 @@ def test_l1_loss_is_reproducible_and_value_only_without_grad():
     assert abs(v[0] - float(torch.abs(a - b).mean())) <= 2e-6 * v[0]
     with pytest.raises(ValueError):
         l1_loss(a, b[:, :10])
+
+
+def test_unweighted_term_and_repeated_backward():
+    """The gradient is stored by the loss pass and only scaled in the backward (not at all for a scale of exactly one); a second backward through the
+    same node (retain_graph) falls back to the two-input kernel.  Bits must equal the autograd gradient of the reference's expression in every case."""
+    dev = torch.device("cuda")
+    a = torch.rand(3, 200, 300, device=dev); b = torch.rand(3, 200, 300, device=dev)
+    for w in (1.0, 0.8, 3.0):
+        a1 = a.clone().requires_grad_(True); a2 = a.clone().requires_grad_(True)
+        (torch.abs(a1 - b).mean() * w + 0.0).backward()
+        l = l1_loss(a2, b)
+        (l * w + 0.0).backward(retain_graph=True)
+        assert torch.allclose(a2.grad, a1.grad, rtol=1e-6, atol=0.0), w
+        g1 = a2.grad.clone(); a2.grad = None
+        (l * w).backward()                                # the node's stored gradient is spent: recomputed from x and y
+        assert torch.equal(a2.grad, g1), w
