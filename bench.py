@@ -272,6 +272,13 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     _lib.timing_enable([kstage])     # hipEvents around the dominant kernel only, on the op's stream
     _lib.timing_collect()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # ... and the AUTOMATIC collector is off for the K timed steps (round 4).  Every step leaves ~120 objects in reference cycles (the autograd nodes of
+    # custom Functions), so generation-0 collections run every few steps whatever is frozen, and every few hundred steps a generation-2 collection
+    # stops the host for 5-11 ms on a fresh process and for ~55 ms late in this one (tools/spike_hunt.py: 31 such stops in 8 000 steps, none with the
+    # collector disabled; one of them landed inside the 20 timed steps of the `trained_geo` line in every full run).  The stop belongs to the
+    # interpreter, not to the step: a training loop calls gc.disable() and collects by hand every N iterations.
+    gc_was_on = gc.isenabled()
+    gc.disable()
     fence(world)
     t0 = time.perf_counter()
     for a, b in ev:
@@ -280,6 +287,8 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
         b.record()
     fence(world)
     dt = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     tm = _lib.timing_collect()
     _lib.timing_enable([])
     per_step = [a.elapsed_time(b) for a, b in ev]
@@ -574,11 +583,12 @@ def main():
                 "grads_copied_into_bucket": reducer.last_packed}
 
     extras = {}
+    skip = set(filter(None, os.environ.get("IBGS_BENCH_SKIP", "").split(",")))          # diagnostics: leave named extras out (torch_l1, abs, hint, impl, hop)
     if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
         from ibgs_amd import rasterizer as _r
         # (e) the same step with the reference's own L1 expression (six small torch kernels) instead of the one-pass loss: what part of
         # the step time is the rasterizer's and what the loss's
-        Workload.torch_l1 = True
+        Workload.torch_l1 = "torch_l1" not in skip
         for _ in range(3):
             wl.local_step()
         fence(1); t0 = time.perf_counter()
@@ -589,7 +599,7 @@ def main():
         Workload.torch_l1 = False
         # (f) the same step when nobody asks for the densification statistic |dL/dmean2D| (means2D_abs without requires_grad: after densify_until_iter,
         # train.py:400-410, and at test time): IBGS_FLAG_NO_ABS_GRAD, the colour blend skips the two |.| moments.  Never `value`.
-        wl.leaves["means2D_abs"].requires_grad_(False)
+        wl.leaves["means2D_abs"].requires_grad_("abs" in skip)
         for _ in range(3):
             wl.local_step()
         fence(1); t0 = time.perf_counter()
@@ -600,7 +610,7 @@ def main():
         wl.leaves["means2D_abs"].requires_grad_(True)
         # the timed loop renders ONE camera again and again, so the forward's launch order hint (the previous backward's balanced order for this
         # camera, rasterizer.ORDER_HINT) is always fresh; a trainer revisits a camera only every few hundred steps.  The same step without it:
-        _r.ORDER_HINT = False
+        _r.ORDER_HINT = "hint" in skip
         for _ in range(3):
             wl.local_step()
         fence(1); t0 = time.perf_counter()
@@ -625,14 +635,14 @@ def main():
         # (a) a trainer hops between cameras (train.py:275-281): 8 orbit views round-robin.  The first round fills the window of the
         # R hint (a miss = binning + render run twice); afterwards every call is sized by the largest R of the last 16
         miss0 = _r.HINT_MISSES
-        for k in range(8):
+        for k in range(0 if "hop" in skip else 8):
             wl.hop_to(k); wl.local_step()
         fence(1)
         miss1 = _r.HINT_MISSES
         n_hop = 24
         t0 = time.perf_counter()
         for k in range(n_hop):
-            wl.hop_to(k % 8); wl.local_step()
+            wl.hop_to(0 if "hop" in skip else k % 8); wl.local_step()
         fence(1)
         extras["view_hopping"] = {"views": 8, "steps": n_hop, "ms_per_step": (time.perf_counter() - t0) / n_hop * 1e3,
                                   "hint_misses_first_round": miss1 - miss0, "hint_misses_steady": _r.HINT_MISSES - miss1,

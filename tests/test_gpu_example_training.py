@@ -44,7 +44,9 @@ def test_full_schedule_improves_monotonically_with_densification_and_geo():
     assert h["split"] > 0 and h["points"][-1] != a.points and len(set(h["points"])) >= 4          # the point set really changed, several times
     win = np.array(h["psnr"]).reshape(-1, 8).mean(1)          # one window = one pass over the 8 views
     print("\nPSNR per pass over the views:", np.round(win, 2), " points:", h["points"][::16])
-    assert np.all(np.diff(win) > -0.3), win          # monotone up to the small dip right after a densification step (the copies start without Adam moments)
+    # monotone up to the small dip right after a densification step (the copies start without Adam moments): -0.20 .. -0.21 dB at two places of this
+    # schedule, +-0.1 dB from run to run (the float atomics' summation order, amplified by Adam) -- one run in ~10 crossed the -0.3 of round 3
+    assert np.all(np.diff(win) > -0.45), win
     assert win[-1] > win[0] + 1.5, win
     assert h["loss"][-1] < 0.75 * h["loss"][0]
 
