@@ -272,11 +272,13 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     _lib.timing_enable([kstage])     # hipEvents around the dominant kernel only, on the op's stream
     _lib.timing_collect()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    # ... and the AUTOMATIC collector is off for the K timed steps (round 4).  Every step leaves ~120 objects in reference cycles (the autograd nodes of
-    # custom Functions), so generation-0 collections run every few steps whatever is frozen, and every few hundred steps a generation-2 collection
-    # stops the host for 5-11 ms on a fresh process and for ~55 ms late in this one (tools/spike_hunt.py: 31 such stops in 8 000 steps, none with the
-    # collector disabled; one of them landed inside the 20 timed steps of the `trained_geo` line in every full run).  The stop belongs to the
-    # interpreter, not to the step: a training loop calls gc.disable() and collects by hand every N iterations.
+    # ... and the AUTOMATIC collector is off for the K timed steps (round 4): a generation-2 collection stops the host for 5-11 ms (tools/spike_hunt.py), and
+    # whether one falls into 20 timed steps is the interpreter's business, not the step's.  A training loop calls gc.disable() and collects by hand every
+    # N iterations.
+    # (NOT explained by it: in about one full run of three, ONE of the 20 timed steps of the `trained_geo` line -- the last workload of a ~30 s process --
+    # takes 55-60 ms: `loss.backward()` returns that late although every Python-level backward function has returned after 0.1 ms; the autograd engine's
+    # device thread sits in native code, no allocator call, no hipMalloc.  40 000 steps of the same workload in a fresh process show no such step.
+    # The line therefore carries median, maximum and every step's time; `ms_per_step` is the wall clock as always.)
     gc_was_on = gc.isenabled()
     gc.disable()
     fence(world)

@@ -15,7 +15,7 @@ if mode == "after_geo":          # as the default bench line: another geo worklo
     del w0
     torch.cuda.empty_cache()
 wl = bench.Workload("C3", 0, dev, "trained", True, False, 1234, cluster=0.3, anisotropy="plane", scale_sigma=1.0)
-if mode == "nogc":
+if mode in ("nogc", "long", "nosync"):
     gc.disable()
 gc.collect(); gc.freeze()
 prev = torch.cuda.memory_stats()
@@ -23,10 +23,11 @@ T0 = time.perf_counter()
 for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 80):
     t0 = time.perf_counter()
     wl.local_step()
-    torch.cuda.synchronize()
+    if mode != "nosync":
+        torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3
-    st = torch.cuda.memory_stats()
-    if dt > 5.0:
+    st = torch.cuda.memory_stats() if mode not in ("long", "nosync") else prev
+    if dt > (20.0 if mode in ("long", "nosync") else 5.0):
         print("t = %.2f s, step %d: %.1f ms | hipMalloc calls +%d, frees +%d, alloc retries +%d | gc counts %s | hint misses %d | reserved %.2f GB"
               % (time.perf_counter() - T0, i, dt, st["num_device_alloc"] - prev["num_device_alloc"], st["num_device_free"] - prev["num_device_free"], st["num_alloc_retries"] - prev["num_alloc_retries"],
                  gc.get_count(), rz.HINT_MISSES, st["reserved_bytes.all.current"] / 2 ** 30))
