@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
 // render_bwd_color_body plus (i) the three normal channels, blended like colour channels (they share S), (ii) the window pairs:
 // a pixel's next buffered contributor number sits in a register; when the traversal reaches it (one integer compare per quadrant
 // and Gaussian) the lane loads that entry of the window table, adds E to dL/dalpha and w K to the plane sums, and moves on.
-template <int PPL>
+template <int PPL, bool ABS = true>          // ABS = false: IBGS_FLAG_NO_ABS_GRAD, as in the colour body
 __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
 {
     constexpr int CHUNK = 16;
@@ -532,13 +532,15 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                 p2q[0] = P0; lxq[0] = lx0; lyq[0] = ly0;
                 if constexpr (PPL >= 2) {
                     p2q[1] = fmaf(-16.0f, lx0, P0 + 64.0f * ca);
-                    lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0);
+                    if constexpr (ABS) { lxq[1] = fmaf(-8.0f, ca, lx0); lyq[1] = fmaf(-8.0f, cb, ly0); }
                 }
                 if constexpr (PPL == 4) {
                     p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * cc);
                     p2q[3] = fmaf(128.0f, cb, p2q[2] + (p2q[1] - P0));          // E3 = E2 + (E1 - E0) + 128 b: three instructions, as the forward
-                    lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
-                    lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                    if constexpr (ABS) {
+                        lxq[2] = fmaf(-8.0f, cb, lx0); lyq[2] = fmaf(-8.0f, cc, ly0);
+                        lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
+                    }
                 }
                 if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h)
                     const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
@@ -586,7 +588,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                         else dL_dalpha = fmaf(dL_dalpha, T[q], gp.w * rinv);
                         const float qv = oG * dL_dalpha;
                         Q[q] = qv;
-                        aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY);      // |a b| = |a| |b|: one v_fma with source modifiers
+                        if constexpr (ABS) { aX = fmaf(fabsf(qv), fabsf(lxq[q]), aX); aY = fmaf(fabsf(qv), fabsf(lyq[q]), aY); }      // |a b| = |a| |b|: one v_fma with source modifiers
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
@@ -734,6 +736,7 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams
     if (tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4, tile, sub)) render_bwd_color_body<1>(p, tile, sub);
 }
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_body<4>(p); }
+__global__ void __launch_bounds__(64, 4) render_bwd_geo4_noabs_kernel(BwdParams p) { render_bwd_geo_body<4, false>(p); }          // IBGS_FLAG_NO_ABS_GRAD
 __global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_geo_body<1>(p); }
 
 // how many waves share one tile in the variant launch_render_backward picks (1, 2 or 4): rows per list entry of the deterministic slab
@@ -786,7 +789,8 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
               hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
             p.order = im.tile_order;
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo4_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
         } else {
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, grid(1), dim3(64), 0, s, p);
