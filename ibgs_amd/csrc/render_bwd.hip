@@ -300,7 +300,10 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
 // The blend loop (pass 2) then handles a window pair with one compare, five loads and five fma instead of ~300 instructions and
 // 25 texel gathers under a one-lane exec mask, and no longer carries the warp code's registers.
 // Table layout: tab[(slot * 6 + field) * HW + pixel], fields = {contributor number (uint bits), E, Kx, Ky, Kz, Kd}.
-__global__ void __launch_bounds__(256) geo_window_kernel(BwdParams p)
+// (six waves per SIMD: the compiler settles at 101 VGPRs = 4 waves when left alone; at 80 -- no spills -- the pass takes 0.205 instead of 0.219 ms on the trained scene,
+// 0.226 instead of 0.239 at C3; 72 VGPRs / 7 waves spill 36 bytes per lane: 0.239; 64 / 8: 0.434.  Fewer instructions at the price of registers -- 9 gathers instead of 13,
+// reciprocals instead of IEEE divisions -- lost every time: the pass lives on the waves it can keep in flight)
+__global__ void __launch_bounds__(256, 6) geo_window_kernel(BwdParams p)
 {
     // no fused multiply-adds: the in-bounds test of backward.cu:722 is a decision on a projected coordinate, which is then the oracle's
     // bit for bit (the depth it starts from is evaluated in double by both); the pass is bound by its gathers

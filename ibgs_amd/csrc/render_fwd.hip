@@ -110,7 +110,7 @@ __device__ uint4 g_trace_fwd[IBGS_TRACE_MAX];
 __device__ unsigned long long g_lanes_fwd[4];
 #endif
 template <int MODE, int PPL, int MAXL>
-__global__ void __launch_bounds__(64) render_fwd_kernel(FwdParams p)
+__global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 : 1) render_fwd_kernel(FwdParams p)
 {
     IBGS_TRACE_BEGIN();
     IBGS_LANES_DECL();
