@@ -539,9 +539,14 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         static const bool split_env = !(getenv("IBGS_PREPROCESS_SPLIT") && atoi(getenv("IBGS_PREPROCESS_SPLIT")) == 0);
         const bool split = split_env && a.shs && !a.colors_precomp && !a.render_depth_only;
         p.alive64 = split ? g.alive64 : nullptr;
+        // no SH evaluation at all (depth-only passes, precomputed colours): the geometry kernel alone -- the one-kernel form carries the SH path's
+        // registers (120 VGPRs, 4 waves per SIMD against 65 / 7) whether it runs or not: 73 -> ~50 us per source view of a test-time frame
+        const bool no_sh = a.render_depth_only || a.colors_precomp || !a.shs;
         if (split) {
             hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
             hipLaunchKernelGGL(sh_color_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        } else if (no_sh) {
+            hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
         } else {
             hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, s, p, cam);
         }
