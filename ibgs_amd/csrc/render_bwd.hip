@@ -810,12 +810,14 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         if (balanced) {
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
             { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
-              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
+              static const int slot_rounds = getenv("IBGS_BWD_SLOT_ROUNDS") ? atoi(getenv("IBGS_BWD_SLOT_ROUNDS")) : ORDER_SNAKE_ROUNDS;      // experiments (with IBGS_BWD_PAD_LDS)
+              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, slot_rounds, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
             IBGS_HIP(hipGetLastError());
             p.order = im.tile_order;
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_color_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
-            else hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            static const int pad_bal = getenv("IBGS_BWD_PAD_LDS") ? atoi(getenv("IBGS_BWD_PAD_LDS")) : 0;      // experiments: dynamic LDS that nobody uses = fewer waves per SIMD
+            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_color_noabs_kernel, dim3((unsigned)nslots), dim3(64), pad_bal, s, p);
+            else hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), pad_bal, s, p);
             IBGS_HIP(hipGetLastError());
             return 0;
         }
