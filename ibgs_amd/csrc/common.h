@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "../../include/ibgs_rast.h"
 
 namespace ibgs {
@@ -67,7 +68,7 @@ struct ImgState {
     uint32_t* low_high;    // HW x 2 (geo) min / max contributor of the median buffer
     int32_t* valid_idx;    // 5 x HW (geo)
     float* valid_w;        // 5 x HW (geo)
-    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = waves per tile of the forward variant that wrote tile_walked, [11] = 1 when the caller's tile_order_hint holds a valid order
+    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = waves per tile of the forward variant that wrote tile_walked, [11] = 1 when the caller's tile_order_hint holds a valid order, [12] = list entries of the frame (binning)
     uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
     uint32_t* tile_walked; // tiles x 4   how far the forward walked every tile's list (largest n_contrib), per wave of the tile ([tile * waves + wave]) = the backward's work there
     uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)
@@ -344,6 +345,40 @@ __device__ __forceinline__ bool tile_map_item(const TileMap& m, int b, int gx, i
     tile = item / ipt; sub = item % ipt;
     return item < gx * gy * ipt;
 }
+
+// hybrid colour kernels (render_fwd.hip, render_bwd.hip): a tile is walked by four quadrant waves instead of one tile wave when its work exceeds
+// theta per cent of a SIMD's fair share of the frame's (total / 1024)
+__device__ __forceinline__ bool hybrid_split(uint32_t work, unsigned long long total, uint32_t theta_pct)
+{
+    return (unsigned long long)work * 1024ull * 100ull > total * theta_pct;
+}
+// A launch order (ImgState::tile_order, ibgs_backward_args::tile_order_out, ibgs_forward_args::tile_order_hint) holds one word per slot: the tile, or
+// 0xFFFFFFFF for an empty slot; bit 31 of a tile's word: the backward that wrote the order found the tile heavy enough for four quadrant waves.
+constexpr uint32_t ORDER_SPLIT_BIT = 0x80000000u;
+// workgroup -> (tile, wave of the tile, split?) for the hybrid kernels under a launch order of grid1 slots: the first grid1 workgroups are wave 0 of the slots'
+// tiles, the 3 x grid1 behind them waves 1..3.  A tile's four side by side would put the work of a frame of tile waves
+// into every fourth workgroup, and the dispatcher deals consecutive workgroups round-robin: a quarter of the SIMDs got all of it (3.0 against 1.24 ms at 720p).
+__device__ __forceinline__ bool hybrid_item(int b, int grid1, const uint32_t* __restrict__ order, int& tile, int& sub, bool& split)
+{
+    // (workgroup b runs on XCD b % 8, and grid1 is a multiple of 8: waves 1..3 of a slot land on the XCD of its wave 0 -- one L2 fetches the tile's records)
+    const int idx = (b - grid1) >> 3;
+    const int slot = b < grid1 ? b : (idx / 3) * 8 + (b & 7);
+    sub = b < grid1 ? 0 : idx % 3 + 1;
+    const uint32_t t = order[slot];
+    split = (t & ORDER_SPLIT_BIT) != 0u;
+    tile = (int)(t & ~ORDER_SPLIT_BIT);
+    return t != 0xFFFFFFFFu;
+}
+// ... and without one: the tiles in the tile map's order (grid1 = tile_map_grid(m, gx, gy, 1), then tile_map_grid(m, gx, gy, 3) workgroups)
+__device__ __forceinline__ bool hybrid_item_mapped(const TileMap& m, int b, int grid1, int gx, int gy, int& tile, int& sub)
+{
+    if (b < grid1) { const bool ok = tile_map_item(m, b, gx, gy, 1, tile, sub); sub = 0; return ok; }
+    const bool ok = tile_map_item(m, b - grid1, gx, gy, 3, tile, sub);
+    sub += 1;
+    return ok;
+}
+constexpr int HYBRID_THETA = 50;
+inline int hybrid_theta() { static const int v = getenv("IBGS_HYBRID_THETA") ? atoi(getenv("IBGS_HYBRID_THETA")) : HYBRID_THETA; return v > 0 ? v : HYBRID_THETA; }      // (the env: experiments)
 
 int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g);
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);

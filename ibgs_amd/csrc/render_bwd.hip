@@ -53,6 +53,8 @@ struct BwdParams {
     int tab_slots;        // geo: slots of the window table the caller's scratch holds (buffer_length + 1 when the caller stated it, else 8)
     const uint32_t* slot_c; const uint32_t* meta; float* tab;     // geo: the forward's buffered contributor numbers (+ slot count); the window pass's table
     const uint32_t* order;      // balanced launch order of the colour kernel: workgroup -> tile (0xFFFFFFFF: none), nullptr: the tile map decides
+    int slab_ipt;         // rows per list entry in `slab` when that is not the body's own waves per tile (hybrid kernel: 4), else 0
+    int hybrid_grid1;     // hybrid colour kernel: slots of `order` = workgroups that are a tile's first wave (hybrid_item, common.h)
     float* slab;          // IBGS_FLAG_DETERMINISTIC: (R x waves per tile) x 16, one row per (list entry, wave of its tile), written instead of the atomics (else nullptr)
 };
 
@@ -110,13 +112,14 @@ __device__ __forceinline__ float fast_rcp(float x)
 #ifdef IBGS_COUNT_LANES
 __device__ unsigned long long g_lanes_bwd[4];
 #endif
+constexpr int BWD_CHUNK = 16;          // 16 records per round: 0.75 KB + 4 KB of per-pixel constants <= 5 KB per wave = 8 waves per SIMD, every tile of a 1080p frame resident at once
 template <int PPL, bool ABS = true>          // ABS = false (IBGS_FLAG_NO_ABS_GRAD): the |.| moments of dL/dmean2D are not accumulated
-__device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const int tile, const int sub)
+__device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const int tile, const int sub, float4 (&s_rec)[3][BWD_CHUNK],
+                                                      float4 (*s_gpix)[WAVE] /* PPL rows: dL/dC (rgb), -T_final * (bg . dL/dC) */)
 {
+    // (the LDS is the caller's: the hybrid kernel below holds two instantiations of this body and hands both the same arrays)
     IBGS_LANES_DECL();
-    constexpr int CHUNK = 16;          // 16 records per round: 0.75 KB + 4 KB of per-pixel constants <= 5 KB per wave = 8 waves per SIMD, every tile of a 1080p frame resident at once
-    __shared__ float4 s_rec[3][CHUNK];
-    __shared__ float4 s_gpix[PPL][WAVE];                  // dL/dC (rgb), -T_final * (bg . dL/dC)
+    constexpr int CHUNK = BWD_CHUNK;
 
     const int lane = threadIdx.x;
     int col = reduce12_column(lane);
@@ -273,7 +276,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                     const float tot = wave_transpose_reduce12(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);
                     if (col >= 0) {
-                        if (p.slab) p.slab[((size_t)(r0 + k) * IPT + (size_t)sub) * GACC_FLOATS + col] = tot;      // wave-uniform choice
+                        if (p.slab) p.slab[((size_t)(r0 + k) * (p.slab_ipt ? p.slab_ipt : IPT) + (size_t)sub) * GACC_FLOATS + col] = tot;      // wave-uniform choice
                         else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
                     }
                 }
@@ -457,7 +460,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
     if (col >= 15) col = -1;
     constexpr int IPT = 4 / PPL;
     int tile, sub;
-    if (PPL == 4 && p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)t; sub = 0; }
+    if (PPL == 4 && p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)(t & ~ORDER_SPLIT_BIT); sub = 0; }
     else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
@@ -644,18 +647,22 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p)
     IBGS_TRACE_BEGIN();
     int tile, sub = 0;
     bool have;
-    if (p.order) { const uint32_t t = p.order[blockIdx.x]; tile = (int)t; have = t != 0xFFFFFFFFu; }
+    if (p.order) { const uint32_t t = p.order[blockIdx.x]; tile = (int)(t & ~ORDER_SPLIT_BIT); have = t != 0xFFFFFFFFu; }
     else have = tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub);
-    if (have) render_bwd_color_body<4>(p, tile, sub);
+    __shared__ float4 s_rec[3][BWD_CHUNK];
+    __shared__ float4 s_gpix[4][WAVE];
+    if (have) render_bwd_color_body<4>(p, tile, sub, s_rec, s_gpix);
     IBGS_TRACE_END(g_trace_bwd);
 }
 __global__ void __launch_bounds__(64, 8) render_bwd_color_noabs_kernel(BwdParams p)          // IBGS_FLAG_NO_ABS_GRAD
 {
     int tile, sub = 0;
     bool have;
-    if (p.order) { const uint32_t t = p.order[blockIdx.x]; tile = (int)t; have = t != 0xFFFFFFFFu; }
+    if (p.order) { const uint32_t t = p.order[blockIdx.x]; tile = (int)(t & ~ORDER_SPLIT_BIT); have = t != 0xFFFFFFFFu; }
     else have = tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub);
-    if (have) render_bwd_color_body<4, false>(p, tile, sub);
+    __shared__ float4 s_rec[3][BWD_CHUNK];
+    __shared__ float4 s_gpix[4][WAVE];
+    if (have) render_bwd_color_body<4, false>(p, tile, sub, s_rec, s_gpix);
 }
 
 // ---- balanced launch order for the colour kernel ----------------------------------------------------------------------------------
@@ -673,32 +680,41 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_noabs_kernel(BwdParams
 constexpr int ORDER_SNAKE_ROUNDS = 8;
 __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots /* ntiles rounded up to ORDER_CLASSES */, int slot_rounds /* waves per SIMD of the kernel that follows */,
                                                           const uint32_t* __restrict__ walked_waves, const uint32_t* __restrict__ meta, uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ order_out /* the caller's copy (ibgs_backward_args::tile_order_out) or nullptr */)
+                                                          uint32_t* __restrict__ order_out /* the caller's copy (ibgs_backward_args::tile_order_out) or nullptr */,
+                                                          int theta_pct = 0 /* > 0 (hybrid kernels): bit 31 of a tile's word says that four quadrant waves should walk it (hybrid_split, common.h) */)
 {
     __shared__ uint32_t s_hist[1024];
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_max;
+    __shared__ unsigned long long s_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t ipt = meta[10];          // waves per tile of the forward variant that ran (1, 2 or 4): a tile was walked as far as its farthest wave
     if (ipt != 1u && ipt != 2u && ipt != 4u) {          // (an arena no forward of this library wrote)
-        for (int i = tid; i < nslots; i += 1024) { const uint32_t v = i < ntiles ? (uint32_t)i : 0xFFFFFFFFu; order[i] = v; if (order_out) order_out[i] = v; }
+        // (hybrid: every tile split -- four waves each are never wrong, one wave for a tile nobody measured may be)
+        for (int i = tid; i < nslots; i += 1024) { const uint32_t v = i < ntiles ? ((uint32_t)i | (theta_pct > 0 ? ORDER_SPLIT_BIT : 0u)) : 0xFFFFFFFFu; order[i] = v; if (order_out) order_out[i] = v; }
         return;
     }
     auto walked_of = [&](int t) { uint32_t v = walked_waves[(size_t)t * ipt]; for (uint32_t k = 1; k < ipt; k++) v = max(v, walked_waves[(size_t)t * ipt + k]); return v; };
     s_hist[tid] = 0u;
-    if (tid == 0) s_max = 0u;
+    if (tid == 0) { s_max = 0u; s_total = 0ull; }
     for (int i = tid; i < nslots; i += 1024) { order[i] = 0xFFFFFFFFu; if (order_out) order_out[i] = 0xFFFFFFFFu; }          // every slot empty first: a backwards round that is not full leaves its holes at ITS low end
     __syncthreads();
     constexpr int KEEP = 16;          // tiles per thread kept in registers (frames up to 16 K tiles; more: read again)
     uint32_t w[KEEP];
     uint32_t m = 0;
+    unsigned long long sum = 0ull;
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) { const int t = tid + k * 1024; w[k] = t < ntiles ? walked_of(t) : 0u; m = max(m, w[k]); }
-    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) m = max(m, walked_of(t));
+    for (int k = 0; k < KEEP; k++) { const int t = tid + k * 1024; w[k] = t < ntiles ? walked_of(t) : 0u; m = max(m, w[k]); sum += w[k]; }
+    for (int t = tid + KEEP * 1024; t < ntiles; t += 1024) { const uint32_t v = walked_of(t); m = max(m, v); sum += v; }
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     if (lane == 0) atomicMax(&s_max, m);
+    if (theta_pct > 0) {
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if (lane == 0) atomicAdd(&s_total, sum);
+    }
     __syncthreads();
     const uint32_t mx = s_max;
+    const unsigned long long total = s_total;
     const int sh = mx >= 1024u ? (32 - __builtin_clz(mx)) - 10 : 0;
     auto bucket = [&](uint32_t v) { return 1023u - min(v >> sh, 1023u); };          // descending
 #pragma unroll
@@ -726,8 +742,9 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
             const uint32_t round = (stratum + 1u) % nrounds;
             slot = round * ORDER_CLASSES + ((stratum & 1u) ? ORDER_CLASSES - 1u - c : c);
         }
-        order[slot] = (uint32_t)t;
-        if (order_out) order_out[slot] = (uint32_t)t;
+        const uint32_t word = (uint32_t)t | ((theta_pct > 0 && hybrid_split(key, total, (uint32_t)theta_pct)) ? ORDER_SPLIT_BIT : 0u);
+        order[slot] = word;
+        if (order_out) order_out[slot] = word;
     };
 #pragma unroll
     for (int k = 0; k < KEEP; k++) if (tid + k * 1024 < ntiles) put(tid + k * 1024, w[k]);
@@ -736,7 +753,22 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int ntiles, int nslots
 __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams p)
 {
     int tile, sub;
-    if (tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4, tile, sub)) render_bwd_color_body<1>(p, tile, sub);
+    __shared__ float4 s_rec[3][BWD_CHUNK];
+    __shared__ float4 s_gpix[1][WAVE];
+    if (tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4, tile, sub)) render_bwd_color_body<1>(p, tile, sub, s_rec, s_gpix);
+}
+// Hybrid (frames of fewer tiles than wave slots; render_fwd.hip has the forward's twin and the reasoning): four workgroups per tile; where the forward
+// walked the tile's list further than `hybrid` per cent of a SIMD's fair share of all walks, each takes a quadrant, elsewhere the first takes the tile.
+// The forward left four walk lengths per tile (meta[10] = 4) and their sum in tile-wave units (meta[13]); after any other forward every tile is split.
+template <bool ABS>
+__global__ void __launch_bounds__(64, 8) render_bwd_color_hybrid_kernel(BwdParams p)
+{
+    __shared__ float4 s_rec[3][BWD_CHUNK];
+    __shared__ float4 s_gpix[4][WAVE];
+    int tile, sub; bool split;
+    if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split)) return;
+    if (split) render_bwd_color_body<1, ABS>(p, tile, sub, s_rec, s_gpix);
+    else if (sub == 0) render_bwd_color_body<4, ABS>(p, tile, 0, s_rec, s_gpix);
 }
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_body<4>(p); }
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_noabs_kernel(BwdParams p) { render_bwd_geo_body<4, false>(p); }          // IBGS_FLAG_NO_ABS_GRAD
@@ -764,7 +796,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
     p.depth_pixels = a.out_depth; p.warped_pixels = a.out_warped;
     p.dL_dcolor = a.dL_dcolor; p.dL_dnormal = a.dL_dnormal; p.dL_ddepth = a.dL_ddepth; p.dL_dwarped = a.dL_dwarped;
-    p.gacc = a.grad_acc; p.slab = slab; p.order = nullptr;
+    p.gacc = a.grad_acc; p.slab = slab; p.order = nullptr; p.slab_ipt = 0; p.hybrid_grid1 = 0;
     p.slot_c = im.slot_c; p.meta = im.meta; p.tab = geo_tab;
     p.tab_slots = (a.buffer_length >= 1 && a.buffer_length < IBGS_MAX_BUFFER_LENGTH) ? a.buffer_length + 1 : IBGS_MAX_BUFFER_LENGTH;          // as ibgs_required_geo_table_for sizes it
     const int nt = p.ntiles;
@@ -801,6 +833,20 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         }
     } else {
         if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {
+            if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES)) {
+                // per tile one wave or four (render_bwd_color_hybrid_kernel), the tiles' first waves in the balanced order of the tile-wave kernel below
+                const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+                { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
+                  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order, a.tile_order_out, hybrid_theta()); }
+                IBGS_HIP(hipGetLastError());
+                p.order = im.tile_order;
+                p.slab_ipt = 4; p.hybrid_grid1 = nslots;
+                StageTimer t(s, IBGS_STAGE_RENDER_BWD);
+                if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_color_hybrid_kernel<false>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
+                else hipLaunchKernelGGL(render_bwd_color_hybrid_kernel<true>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
+                IBGS_HIP(hipGetLastError());
+                return 0;
+            }
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             hipLaunchKernelGGL(render_bwd_color_small_kernel, grid(4), dim3(64), 0, s, p);
             IBGS_HIP(hipGetLastError());

@@ -39,6 +39,8 @@ struct FwdParams {
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
+    int hybrid_grid1;    // ... its first hybrid_grid1 workgroups are the tiles' first waves (hybrid_item, common.h)
+    int hybrid;          // > 0: render_fwd_color_hybrid_kernel; the value is the split threshold in per cent of a SIMD's fair share (HYBRID_THETA)
     const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by an extra workgroup of cell_place_kernel: meta[11]; nullptr: the tile map
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
@@ -109,8 +111,15 @@ __device__ uint4 g_trace_fwd[IBGS_TRACE_MAX];
 #ifdef IBGS_COUNT_LANES
 __device__ unsigned long long g_lanes_fwd[4];
 #endif
-template <int MODE, int PPL, int MAXL>
-__global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 : 1) render_fwd_kernel(FwdParams p)
+// The wave's work: `sub` of the 4 / PPL waves of `tile`.  s_rec: the caller's staging area (NQ x CHUNK float4; a kernel that holds two
+// instantiations of the body -- the hybrid colour kernel below -- hands both the same one).
+// TILE_Q >= 0 (PPL == 1, the hybrid kernel's quadrant waves; = sub, at compile time): the exponent E of the wave's pixels is formed exactly as a tile wave
+// forms it for that quadrant -- for the lane's quadrant-0 pixel, then shifted -- so that a pixel's colour does not depend, not by one bit, on which shape
+// walked its tile.  (With the quadrant as a run-time value the select between the four expressions became a chain of six scalar branches per list entry:
+// quadrant waves 0.35 -> 0.51 ms at 400 x 400.)
+template <int MODE, int PPL, int MAXL, int TILE_Q = -1>
+__device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int tile, const int sub,
+                                                float4 (&s_rec)[(MODE == MODE_GEO) ? 4 : 3][(MODE == MODE_GEO) ? 16 : WAVE])
 {
     IBGS_TRACE_BEGIN();
     IBGS_LANES_DECL();
@@ -122,19 +131,10 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
     // holds 5 KB instead of 8, and LDS stops limiting the kernel to five waves per SIMD.  The next round's quad is fetched before the
     // current round is blended (one float4 per lane in flight), so the shorter rounds do not expose their load latency.
     constexpr int CHUNK = GEO ? 16 : WAVE;
-    __shared__ float4 s_rec[NQ][CHUNK];
+    static_assert(sizeof(s_rec) == sizeof(float4) * NQ * CHUNK, "staging area");
 
     const int lane = threadIdx.x;
     constexpr int IPT = 4 / PPL;                          // work items (waves) per tile: 1, 2 (half tiles: quadrant pairs 0-1 / 2-3) or 4
-    int tile, sub;
-    if (((MODE == MODE_COLOR && PPL == 4) || (MODE == MODE_GEO && PPL == 2)) && p.order) {
-        // launched over the slots of a tile order (ibgs_forward_args::tile_order_hint), IPT consecutive workgroups per slot: the hinted tile when the
-        // hint was found valid, else tile = slot
-        uint32_t t = blockIdx.x / IPT;
-        if (p.meta[11] == 1u) t = p.order[t];
-        if (t >= (uint32_t)p.ntiles) return;          // (0xFFFFFFFF: an empty slot)
-        tile = (int)t; sub = (int)(blockIdx.x % IPT);
-    } else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.ntiles / p.cam.gx, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
     int trow = tile / p.cam.gx, view = 0;
@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
         recm[q] = live[q];
         T[q] = 1.0f; C[q][0] = C[q][1] = C[q][2] = 0.f; lastc[q] = 0;
     }
+    const float pxf_t0 = (float)(tx0 + (lane & 7)), pyf_t0 = (float)(ty0 + (lane >> 3));          // the lane's pixel in quadrant 0 of the tile (TILE_Q)
     const float fx = (DEPTH && p.n_views > 1) ? p.fxv[view] : p.cam.fx, fy = (DEPTH && p.n_views > 1) ? p.fyv[view] : p.cam.fy;
     const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
     const float eps = 1.0e-8f;
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
             // p2 = d^T conic d = -2 * power.  With 4 pixels per lane the quadratic form is evaluated once for the
             // lane's pixel in quadrant 0 and shifted to the other three (pixel offsets (8,0), (0,8), (8,8)):
             // p2(d - s) = p2(d) - 2 s^T conic d + s^T conic s -- 14 VALU ops for four pixels instead of 32.
-            const float dx0 = q0.x - pxf[0], dy0 = q0.y - pyf[0];
+            const float dx0 = q0.x - (TILE_Q >= 0 ? pxf_t0 : pxf[0]), dy0 = q0.y - (TILE_Q >= 0 ? pyf_t0 : pyf[0]);
             const float lx0 = q1.x * dx0 + q1.y * dy0, ly0 = q1.y * dx0 + q1.z * dy0;
             const float P0 = fmaf(dx0, lx0, fmaf(dy0, ly0, q0.z));          // E = -log2(o G) of the lane's quadrant-0 pixel (common.h)
             float p2q[PPL];
@@ -263,6 +264,11 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
             if (PPL == 4) {
                 p2q[2] = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
                 p2q[3] = fmaf(128.0f, q1.y, p2q[2] + (p2q[1] - P0));          // E(d - (8,8)) = E2 + (E1 - E0) + 128 b: three instructions instead of four
+            }
+            if constexpr (TILE_Q >= 1 && PPL == 1) {          // the tile wave's expressions for this quadrant, operation by operation
+                const float E1 = fmaf(-16.0f, lx0, P0 + 64.0f * q1.x);
+                const float E2 = fmaf(-16.0f, ly0, P0 + 64.0f * q1.z);
+                p2q[0] = TILE_Q == 1 ? E1 : (TILE_Q == 2 ? E2 : fmaf(128.0f, q1.y, E2 + (E1 - P0)));
             }
             if ((riskm >> (GEO ? 4 * j + 1 : j)) & 1ull) {          // wave-uniform and rare: the record as preprocess wrote it, the reference's expression per pixel
                 const uint32_t gid = p.point_list[r0 + e];
@@ -384,7 +390,13 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
         for (int q = 0; q < PPL; q++) m = max(m, inside[q] ? lastc[q] : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
-        if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
+        if (p.hybrid) {
+            // hybrid colour kernel: four words per tile whichever shape walked it (a tile wave leaves the other three at zero)
+            if (IPT == 1) { if (lane < 4) p.walked[(size_t)tile * 4 + lane] = lane == 0 ? m : 0u; }
+            else if (lane == 0) p.walked[(size_t)tile * 4 + sub] = m;
+            if (lane == 0 && tile == 0 && sub == 0) p.meta[10] = 4u;
+        }
+        else if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
     }
     // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
     // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --
@@ -524,6 +536,59 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
     IBGS_LANES_FLUSH(g_lanes_fwd);
 }
 
+template <int MODE, int PPL, int MAXL>
+__global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 : 1) render_fwd_kernel(FwdParams p)
+{
+    __shared__ float4 s_rec[(MODE == MODE_GEO) ? 4 : 3][(MODE == MODE_GEO) ? 16 : WAVE];
+    constexpr int IPT = 4 / PPL;
+    int tile, sub;
+    if (((MODE == MODE_COLOR && PPL == 4) || (MODE == MODE_GEO && PPL == 2)) && p.order) {
+        // launched over the slots of a tile order (ibgs_forward_args::tile_order_hint), IPT consecutive workgroups per slot: the hinted tile when the
+        // hint was found valid, else tile = slot
+        uint32_t t = blockIdx.x / IPT;
+        if (p.meta[11] == 1u) { t = p.order[t]; if (t != 0xFFFFFFFFu) t &= ~ORDER_SPLIT_BIT; }
+        if (t >= (uint32_t)p.ntiles) return;          // (0xFFFFFFFF: an empty slot)
+        tile = (int)t; sub = (int)(blockIdx.x % IPT);
+    } else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.ntiles / p.cam.gx, IPT, tile, sub)) return;
+    render_fwd_body<MODE, PPL, MAXL>(p, tile, sub, s_rec);
+}
+
+// ---- hybrid colour kernel: frames of fewer tiles than the chip has wave slots --------------------------------------------------------------
+// One wave per tile leaves SIMDs idle or with a single wave (which issues at half the rate of two: probe_xlane), one wave per 8 x 8 quadrant fills
+// the chip but repeats the per-entry work that the four quadrants of a tile share (1.35 x the instructions).  Which is faster depends on the frame
+// AND on the tile (tools/sweep_wave_shape.py: tile waves win from ~1 500 even tiles up, quadrant waves below; one heavy list in a frame of light
+// ones is walked four times faster by four waves).  So the choice is made per tile, on the device: four workgroups per tile are launched; where
+// the tile's work exceeds HYBRID_THETA per cent of a SIMD's fair share of the frame's (common.h) each of them takes a quadrant, elsewhere the first
+// one takes the tile and the other three leave at once.  The tiles' FIRST workgroups are the first of the launch, the other three follow behind
+// them all (hybrid_item).  Any choice gives the same image BIT FOR BIT (both bodies blend a pixel's list in the same order with the same
+// operations, TILE_Q above): the hint that may steer the choice stays a pure performance matter.
+__global__ void __launch_bounds__(64, 8) render_fwd_color_hybrid_kernel(FwdParams p)
+{
+    __shared__ float4 s_rec[3][WAVE];
+    int tile, sub; bool split;
+    if (p.order && p.meta[11] == 1u) {
+        // the same camera's last backward: its balanced order, and per tile its choice of shape -- made on what counts, how far the list was WALKED (with
+        // trained opacities the length of a list says little about that)
+        if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split)) return;
+    } else {
+        if (p.order) {          // a hint that did not pass the check: slot = tile
+            const int idx = ((int)blockIdx.x - p.hybrid_grid1) >> 3;          // (as hybrid_item)
+            tile = blockIdx.x < (unsigned)p.hybrid_grid1 ? (int)blockIdx.x : (idx / 3) * 8 + (int)(blockIdx.x & 7u);
+            sub = blockIdx.x < (unsigned)p.hybrid_grid1 ? 0 : idx % 3 + 1;
+            if (tile >= p.ntiles) return;
+        }
+        else if (!hybrid_item_mapped(p.tmap, blockIdx.x, p.hybrid_grid1, p.cam.gx, p.ntiles / p.cam.gx, tile, sub)) return;
+        split = hybrid_split(p.ranges[2 * tile + 1] - p.ranges[2 * tile], p.meta[12], (uint32_t)p.hybrid);          // no measurement: by the length of the list
+    }
+    if (split) {
+        if (sub == 0) render_fwd_body<MODE_COLOR, 1, 4, 0>(p, tile, 0, s_rec);
+        else if (sub == 1) render_fwd_body<MODE_COLOR, 1, 4, 1>(p, tile, 1, s_rec);
+        else if (sub == 2) render_fwd_body<MODE_COLOR, 1, 4, 2>(p, tile, 2, s_rec);
+        else render_fwd_body<MODE_COLOR, 1, 4, 3>(p, tile, 3, s_rec);
+    }
+    else if (sub == 0) render_fwd_body<MODE_COLOR, 4, 4>(p, tile, 0, s_rec);
+}
+
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
                           const ImgState& im, const float4* src_rgba)
 {
@@ -540,6 +605,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;
+    p.hybrid = 0;
     p.n_views = a.n_views > 1 ? a.n_views : 1; p.gyv = p.cam.gy;
     for (int v = 0; v < IBGS_MAX_VIEWS; v++) {
         p.fxv[v] = (v < p.n_views && p.n_views > 1) ? a.W / (2.0f * a.view_tanfovx[v]) : p.cam.fx;
@@ -572,7 +638,19 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
         // Small frames: one wave per 8x8 quadrant instead of per tile, otherwise the chip (1024 SIMDs x 8 waves) stays
         // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).
         const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096);
-        if (small) hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 1, 4>), grid(4), dim3(64), 0, s, p);
+        const bool forced = (a.flags & (IBGS_FLAG_QUADRANT_WAVES | IBGS_FLAG_TILE_WAVES)) != 0;
+        if (small && !forced && p.n_views <= 1) {
+            p.hybrid = hybrid_theta();
+            if (a.tile_order_hint) {          // (the same camera's last backward order, as for the tile-wave kernel below)
+                p.order = a.tile_order_hint;
+                p.hybrid_grid1 = (p.ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+                hipLaunchKernelGGL(render_fwd_color_hybrid_kernel, dim3(4u * (unsigned)p.hybrid_grid1), dim3(64), 0, s, p);
+            } else {
+                p.hybrid_grid1 = tile_map_grid(p.tmap, gx, gyt, 1);
+                hipLaunchKernelGGL(render_fwd_color_hybrid_kernel, dim3((unsigned)(p.hybrid_grid1 + tile_map_grid(p.tmap, gx, gyt, 3))), dim3(64), 0, s, p);
+            }
+        }
+        else if (small) hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 1, 4>), grid(4), dim3(64), 0, s, p);
         else if (a.tile_order_hint && p.n_views <= 1) {
             p.order = a.tile_order_hint;
             hipLaunchKernelGGL((render_fwd_kernel<MODE_COLOR, 4, 4>), dim3((unsigned)((p.ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES)), dim3(64), 0, s, p);

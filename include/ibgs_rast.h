@@ -60,7 +60,10 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
 
 #define IBGS_FLAG_TILE_WAVES 32u     /* blend kernels: always the coarse decomposition -- one wave per 16x16 tile (colour) or per half
                                         tile (geo); default: only when the frame has >= 4096 tiles */
-#define IBGS_FLAG_QUADRANT_WAVES 64u /* blend kernels: always one wave per 8x8 quadrant (default for small frames, fills the chip) */
+#define IBGS_FLAG_QUADRANT_WAVES 64u /* blend kernels: always one wave per 8x8 quadrant.  Default for frames of fewer than 4096 tiles: geo passes
+                                        this; colour passes choose PER TILE on the device -- one wave, or four quadrant waves for a tile whose
+                                        work exceeds half of a SIMD's fair share of the frame's (the forward goes by the length of the tile's list
+                                        or, given tile_order_hint, by the last backward's choice; the backward by how far the forward walked it) */
 
 #define IBGS_PLANE_NONE 0
 #define IBGS_PLANE_LEARNT 1
@@ -179,9 +182,11 @@ typedef struct ibgs_forward_args {
      * ibgs_backward of a colour pass leaves the order in which it launched its tiles -- balanced over the SIMDs by how far the forward
      * walked every tile's list -- at img + ibgs_img_offset(W, H, "tile_order") and in ibgs_backward_args.tile_order_out.  Handed to a later ibgs_forward of the SAME
      * camera (whose lists saturate where they did before), lets the forward launch balanced too; the forward cannot know its own work
-     * in advance.  Performance only: the words are checked on the device (every tile exactly once, 0xFFFFFFFF = empty slot) and anything
+     * in advance.  Bit 31 of a tile's word: that backward found the tile heavy enough for four quadrant waves (frames of fewer than 4096 tiles).
+     * Performance only: the words are checked on the device (every tile exactly once, 0xFFFFFFFF = empty slot) and anything
      * else -- a stale order, garbage -- is ignored; the buffer itself must hold ibgs_tile_order_slots(W, H) words (all of them are read).  Used by
-     * the variants with one wave per tile / half tile (large frames: colour and render_geo passes), not by render_depth_only. */
+     * the variants with one wave per tile / half tile (large frames: colour and render_geo passes) and by the per-tile choice of small colour frames,
+     * not by render_depth_only. */
     const uint32_t* tile_order_hint;
 } ibgs_forward_args;
 

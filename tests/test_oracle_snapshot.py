@@ -72,6 +72,6 @@ def test_hip_meets_the_north_star_bars_against_the_frozen_c1_answer():
         a = lv[leaf].grad.detach().cpu().numpy().reshape(P, -1)
         want = gold[k + "_head"]
         a_head = a[:snap.HEAD, :want.shape[1]]
-        assert rel_l2(a_head, want) < 2e-5, (k, rel_l2(a_head, want))
+        assert rel_l2(a_head, want) < 5e-5, (k, rel_l2(a_head, want))          # (north star: 1e-3; measured 0.5-2.2e-5 -- float atomics, and which wave shape the library picked per tile)
         tot = float(np.abs(a[:, :want.shape[1]]).astype(np.float64).sum())
         assert abs(tot - float(gold[k + "_abs_sum"])) < 1e-4 * float(gold[k + "_abs_sum"]), k
