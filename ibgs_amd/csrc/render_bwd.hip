@@ -448,20 +448,14 @@ __global__ void __launch_bounds__(256, 6) geo_window_kernel(BwdParams p)
 // a pixel's next buffered contributor number sits in a register; when the traversal reaches it (one integer compare per quadrant
 // and Gaussian) the lane loads that entry of the window table, adds E to dL/dalpha and w K to the plane sums, and moves on.
 template <int PPL, bool ABS = true>          // ABS = false: IBGS_FLAG_NO_ABS_GRAD, as in the colour body
-__device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
+__device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p, const int tile, const int sub, float4 (&s_rec)[4][BWD_CHUNK],
+                                                    float4 (*s_gpix)[WAVE] /* PPL rows: dL/dC (rgb), -T_final * (bg . dL/dC) */, float4 (*s_gnrm)[WAVE] /* PPL rows: dL/dN (xyz) */)
 {
-    constexpr int CHUNK = 16;
-    __shared__ float4 s_rec[4][CHUNK];
-    __shared__ float4 s_gpix[PPL][WAVE];                  // dL/dC (rgb), -T_final * (bg . dL/dC)
-    __shared__ float4 s_gnrm[PPL][WAVE];                  // dL/dN (xyz)
-
+    constexpr int CHUNK = BWD_CHUNK;          // (the LDS is the caller's, as for the colour body)
     const int lane = threadIdx.x;
     int col = reduce16_column(lane);
     if (col >= 15) col = -1;
     constexpr int IPT = 4 / PPL;
-    int tile, sub;
-    if (PPL == 4 && p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)(t & ~ORDER_SPLIT_BIT); sub = 0; }
-    else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, IPT, tile, sub)) return;
     const int quad0 = sub * PPL;
     const int W = p.cam.W, H = p.cam.H;
     const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
@@ -624,7 +618,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p)
                     const float tot = wave_transpose_reduce16(v, lane);
                     const uint32_t id = __float_as_uint(q0.w);
                     if (col >= 0) {
-                        if (p.slab) p.slab[((size_t)(r0 + k) * IPT + (size_t)sub) * GACC_FLOATS + col] = tot;
+                        if (p.slab) p.slab[((size_t)(r0 + k) * (p.slab_ipt ? p.slab_ipt : IPT) + (size_t)sub) * GACC_FLOATS + col] = tot;
                         else atomicAdd(p.gacc + (size_t)id * GACC_FLOATS + col, tot);
                     }
                 }
@@ -770,9 +764,32 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_hybrid_kernel(BwdParam
     if (split) render_bwd_color_body<1, ABS>(p, tile, sub, s_rec, s_gpix);
     else if (sub == 0) render_bwd_color_body<4, ABS>(p, tile, 0, s_rec, s_gpix);
 }
-__global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_body<4>(p); }
-__global__ void __launch_bounds__(64, 4) render_bwd_geo4_noabs_kernel(BwdParams p) { render_bwd_geo_body<4, false>(p); }          // IBGS_FLAG_NO_ABS_GRAD
-__global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_geo_body<1>(p); }
+template <int PPL, bool ABS>
+__device__ __forceinline__ void render_bwd_geo_entry(const BwdParams& p)
+{
+    __shared__ float4 s_rec[4][BWD_CHUNK];
+    __shared__ float4 s_gpix[PPL][WAVE];
+    __shared__ float4 s_gnrm[PPL][WAVE];
+    int tile, sub;
+    if (PPL == 4 && p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)(t & ~ORDER_SPLIT_BIT); sub = 0; }
+    else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4 / PPL, tile, sub)) return;
+    render_bwd_geo_body<PPL, ABS>(p, tile, sub, s_rec, s_gpix, s_gnrm);
+}
+__global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_entry<4, true>(p); }
+__global__ void __launch_bounds__(64, 4) render_bwd_geo4_noabs_kernel(BwdParams p) { render_bwd_geo_entry<4, false>(p); }          // IBGS_FLAG_NO_ABS_GRAD
+__global__ void __launch_bounds__(64, 6) render_bwd_geo_kernel(BwdParams p) { render_bwd_geo_entry<1, true>(p); }
+// ... and the geo pass's hybrid (frames of fewer tiles than wave slots): one wave per tile or four quadrant waves, by the flag in the tile's order word
+template <bool ABS>
+__global__ void __launch_bounds__(64, 4) render_bwd_geo_hybrid_kernel(BwdParams p)
+{
+    __shared__ float4 s_rec[4][BWD_CHUNK];
+    __shared__ float4 s_gpix[4][WAVE];
+    __shared__ float4 s_gnrm[4][WAVE];
+    int tile, sub; bool split;
+    if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split)) return;
+    if (split) render_bwd_geo_body<1, ABS>(p, tile, sub, s_rec, s_gpix, s_gnrm);
+    else if (sub == 0) render_bwd_geo_body<4, ABS>(p, tile, 0, s_rec, s_gpix, s_gnrm);
+}
 
 // how many waves share one tile in the variant launch_render_backward picks (1, 2 or 4): rows per list entry of the deterministic slab
 int render_backward_waves_per_tile(const ibgs_backward_args& a)
@@ -826,6 +843,16 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo4_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
             else hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+        } else if (!big && !(a.flags & IBGS_FLAG_QUADRANT_WAVES)) {
+            // small frames: per tile one wave or four (render_bwd_geo_hybrid_kernel), the tiles' first waves in the balanced (snake) order
+            const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+            { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
+              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out, hybrid_theta()); }
+            IBGS_HIP(hipGetLastError());
+            p.order = im.tile_order; p.slab_ipt = 4; p.hybrid_grid1 = nslots;
+            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
+            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo_hybrid_kernel<false>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(render_bwd_geo_hybrid_kernel<true>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
         } else {
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, grid(1), dim3(64), 0, s, p);
