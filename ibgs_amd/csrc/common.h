@@ -378,6 +378,8 @@ __device__ __forceinline__ bool hybrid_item_mapped(const TileMap& m, int b, int 
     return ok;
 }
 constexpr int HYBRID_THETA = 50;
+// colour passes of frames with fewer tiles than this use the hybrid kernels (the env: experiments)
+inline int hybrid_max_tiles() { static const int v = getenv("IBGS_HYBRID_MAX_TILES") ? atoi(getenv("IBGS_HYBRID_MAX_TILES")) : 4096; return v; }
 inline int hybrid_theta() { static const int v = getenv("IBGS_HYBRID_THETA") ? atoi(getenv("IBGS_HYBRID_THETA")) : HYBRID_THETA; return v > 0 ? v : HYBRID_THETA; }      // (the env: experiments)
 
 int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g);

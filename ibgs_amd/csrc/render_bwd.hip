@@ -796,7 +796,7 @@ int render_backward_waves_per_tile(const ibgs_backward_args& a)
 {
     const int nt = ((a.W + TILE - 1) / TILE) * ((a.H + TILE - 1) / TILE);
     if (a.render_geo) return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096)) ? 1 : 4;
-    return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) ? 4 : 1;
+    return ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles())) ? 4 : 1;
 }
 
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
@@ -859,7 +859,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             else hipLaunchKernelGGL(render_bwd_geo_kernel, grid(4), dim3(64), 0, s, p);
         }
     } else {
-        if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096)) {
+        if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles())) {
             if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES)) {
                 // per tile one wave or four (render_bwd_color_hybrid_kernel), the tiles' first waves in the balanced order of the tile-wave kernel below
                 const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;

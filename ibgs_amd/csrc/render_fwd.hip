@@ -637,7 +637,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     } else {
         // Small frames: one wave per 8x8 quadrant instead of per tile, otherwise the chip (1024 SIMDs x 8 waves) stays
         // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).
-        const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < 4096);
+        const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles());
         const bool forced = (a.flags & (IBGS_FLAG_QUADRANT_WAVES | IBGS_FLAG_TILE_WAVES)) != 0;
         if (small && !forced && p.n_views <= 1) {
             p.hybrid = hybrid_theta();
