@@ -26,9 +26,43 @@ import subprocess
 import sys
 import time
 
+
+def cpu_budget():
+    """Host CPUs this process may really use: the cgroup's CPU bandwidth quota (cpu.max = "<quota> <period>"), the affinity mask, the core count.
+    The GPU boxes of this pool show 256 CPUs and grant 16 (cpu.max 1600000 100000)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                n = min(n, max(1, int(q) // int(per)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
+# Thread pools sized for every CPU the box SHOWS (OpenMP in torch and in the oracle, the BLAS under numpy) burn the cgroup's CPU quota in one burst -- their
+# workers also spin for a while after each parallel region -- and the kernel then stops EVERY thread of the process until the next 100 ms period.  That was
+# the "one step of 55-60 ms in about one run of three" of the `trained_geo` line (round 4: /sys/fs/cgroup/cpu.stat counted 13 throttled periods per bench
+# run; the HIP API trace showed the main thread standing still between two kernel launches inside ibgs_forward, the autograd thread with it).  So: pools
+# no larger than the quota, and no spinning.  Must happen before the libraries load.
+CPU_BUDGET = max(1, cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))          # (ranks of one node share the quota)
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_k, str(CPU_BUDGET))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+torch.set_num_threads(CPU_BUDGET)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -275,10 +309,8 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
     # ... and the AUTOMATIC collector is off for the K timed steps (round 4): a generation-2 collection stops the host for 5-11 ms (tools/spike_hunt.py), and
     # whether one falls into 20 timed steps is the interpreter's business, not the step's.  A training loop calls gc.disable() and collects by hand every
     # N iterations.
-    # (NOT explained by it: in about one full run of three, ONE of the 20 timed steps of the `trained_geo` line -- the last workload of a ~30 s process --
-    # takes 55-60 ms: `loss.backward()` returns that late although every Python-level backward function has returned after 0.1 ms; the autograd engine's
-    # device thread sits in native code, no allocator call, no hipMalloc.  40 000 steps of the same workload in a fresh process show no such step.
-    # The line therefore carries median, maximum and every step's time; `ms_per_step` is the wall clock as always.)
+    # (The 55-60 ms step that one full run of three showed in the `trained_geo` line was neither: the cgroup's CPU bandwidth quota, exhausted by 128-thread
+    # pools -- see CPU_BUDGET at the top of this file.  The line still carries median, maximum and every step's time; `ms_per_step` is the wall clock as always.)
     gc_was_on = gc.isenabled()
     gc.disable()
     fence(world)

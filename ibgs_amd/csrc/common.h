@@ -378,6 +378,9 @@ __device__ __forceinline__ bool hybrid_item_mapped(const TileMap& m, int b, int 
     return ok;
 }
 constexpr int HYBRID_THETA = 50;
+// Frames of fewer than HYBRID_MIN_TILES tiles: a SIMD's fair share is less than a tile, nearly every tile would be split -- plain quadrant waves, without the
+// order kernel in front (400 x 400 / 10 k Gaussians, BASELINE's C1: backward 0.29 -> 0.20 ms).
+constexpr int HYBRID_MIN_TILES = 768;
 // colour passes of frames with fewer tiles than this use the hybrid kernels (the env: experiments)
 inline int hybrid_max_tiles() { static const int v = getenv("IBGS_HYBRID_MAX_TILES") ? atoi(getenv("IBGS_HYBRID_MAX_TILES")) : 4096; return v; }
 inline int hybrid_theta() { static const int v = getenv("IBGS_HYBRID_THETA") ? atoi(getenv("IBGS_HYBRID_THETA")) : HYBRID_THETA; return v > 0 ? v : HYBRID_THETA; }      // (the env: experiments)

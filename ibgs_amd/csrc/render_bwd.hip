@@ -843,7 +843,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo4_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
             else hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
-        } else if (!big && !(a.flags & IBGS_FLAG_QUADRANT_WAVES)) {
+        } else if (!big && !(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
             // small frames: per tile one wave or four (render_bwd_geo_hybrid_kernel), the tiles' first waves in the balanced (snake) order
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
             { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
@@ -860,7 +860,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
         }
     } else {
         if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles())) {
-            if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES)) {
+            if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
                 // per tile one wave or four (render_bwd_color_hybrid_kernel), the tiles' first waves in the balanced order of the tile-wave kernel below
                 const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
                 { StageTimer t(s, IBGS_STAGE_TILE_ORDER);

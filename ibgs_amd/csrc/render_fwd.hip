@@ -639,7 +639,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
         // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).
         const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles());
         const bool forced = (a.flags & (IBGS_FLAG_QUADRANT_WAVES | IBGS_FLAG_TILE_WAVES)) != 0;
-        if (small && !forced && p.n_views <= 1) {
+        if (small && !forced && p.n_views <= 1 && nt >= HYBRID_MIN_TILES) {
             p.hybrid = hybrid_theta();
             if (a.tile_order_hint) {          // (the same camera's last backward order, as for the tile-wave kernel below)
                 p.order = a.tile_order_hint;

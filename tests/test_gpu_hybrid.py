@@ -11,7 +11,8 @@ import oracle
 from ibgs_amd import _lib, rasterizer, synthetic as syn
 from tests import hipref
 from tests.metrics import rel_l2
-from tests.test_gpu_parity import GRAD_PAIRS, check_color, check_grads, rnd
+from tests.scenes import add_sources
+from tests.test_gpu_parity import GEO_GRAD_TOL, GRAD_PAIRS, check_color, check_grads, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -126,3 +127,33 @@ def test_image_bits_do_not_depend_on_the_mixture():
     assert np.array_equal(o1["color"], o2["color"])
     assert np.array_equal(ist1["final_T"], ist2["final_T"]) and np.array_equal(ist1["n_contrib"], ist2["n_contrib"])
     assert np.array_equal(walked1.max(axis=1), walked2.max(axis=1))
+
+
+def test_geo_backward_mixture():
+    """render_geo: the forward keeps quadrant waves on such frames, the backward picks per tile (render_bwd_geo_hybrid_kernel)."""
+    inp = syn.make_scene(9000, 640, 400, sh_degree=1, seed=99, opacity="trained", with_planes=True, anisotropy="plane", cluster=0.5)
+    inp["scales"] = (inp["scales"] * 5.0).astype(np.float32)
+    inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
+    inp = add_sources(inp, n_src=3, L=4)
+    H, W = inp["H"], inp["W"]
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    assert 768 <= nt < 4096
+    grads = {"color": rnd((3, H, W), 7), "normal_map": rnd((3, H, W), 8), "median_depth": rnd((1, H, W), 9), "warped_image": rnd((15, H, W), 10)}
+    ref = oracle.forward(inp, cull=True)
+    gb = oracle.backward(inp, ref, grads["color"], grads["normal_map"], grads["median_depth"], grads["warped_image"])
+    st = hipref.settings_from(inp, "cuda", False)
+    lv = hipref.leaf_inputs(inp, "cuda", True)
+    outs = dict(zip(NAMES, rasterizer.GaussianRasterizer(st)(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
+                                                            shs=lv["shs"], colors_precomp=lv["colors_precomp"], scales=lv["scales"], rotations=lv["rotations"],
+                                                            cov3D_precomp=lv["cov3D_precomp"], all_map=lv["all_map"])))
+    loss = 0
+    for k, g in grads.items():
+        loss = loss + (outs[k] * torch.as_tensor(g, device="cuda")).sum()
+    loss.backward(retain_graph=True)
+    torch.cuda.synchronize()
+    order = arena_words(outs, inp, "tile_order", int(_lib.load().ibgs_tile_order_slots(W, H)))
+    tiles = order[order != 0xFFFFFFFF]
+    assert np.array_equal(np.sort(tiles & ~np.uint32(SPLIT)), np.arange(nt, dtype=np.uint32))
+    nsplit = int(((tiles & SPLIT) != 0).sum())
+    assert 8 < nsplit < nt - 50, ("no mixture", nsplit, nt)
+    check_grads(lv, gb, tol=GEO_GRAD_TOL)

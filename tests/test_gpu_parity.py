@@ -18,11 +18,11 @@ from tests.metrics import l1, psnr, rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["tile", "quadrant", None], ids=["tile", "quadrant", "library"])
+@pytest.fixture(autouse=True, params=["tile", "quadrant"])
 def wave_shape(request):
     """Every parity test runs with both work decompositions of the colour kernels (one wave per 16x16 tile / per 8x8
-    quadrant) and with the library's own choice: for these small frames the hybrid kernels, which pick per tile
-    (tests/test_gpu_hybrid.py looks at their choices)."""
+    quadrant); left alone the library would pick 'quadrant' for all of these small frames (below 768 tiles; from there
+    to 4 096 tiles it picks per tile: tests/test_gpu_hybrid.py)."""
     from ibgs_amd import rasterizer
     old = rasterizer.WAVE_SHAPE
     rasterizer.WAVE_SHAPE = request.param
