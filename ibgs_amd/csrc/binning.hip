@@ -166,7 +166,7 @@ __device__ __forceinline__ CullRows rows_job(const PlaceGeom& pg, const Footprin
 {
     const float4 q0 = rec[(size_t)id * 4], q1 = rec[(size_t)id * 4 + 1];
     CullRows j;
-    cull_rows_setup(j, q0.x, q0.y, q1.x, q1.y, q1.z, q1.x * q1.z - q1.y * q1.y, cull_qmax(q0.z), (int)f.r.x0, (int)f.r.x1);
+    cull_rows_setup_conic(j, q0.x, q0.y, q1.x, q1.y, q1.z, cull_qmax(q0.z), (int)f.r.x0, (int)f.r.x1);
     row_off = (int)(id / (uint32_t)pg.Pv) * pg.gyv;          // batched views: the record's y is the view's own, the rectangle's rows are the stacked grid's
     return j;
 }

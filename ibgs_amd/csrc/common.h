@@ -163,6 +163,15 @@ __device__ __forceinline__ void cull_rows_setup(CullRows& j, float px, float py,
     j.invA = 1.0f / A; j.aq = A * qmax;
     j.ymax = sqrtf(j.aq / det); j.ystar = -B * sqrtf(qmax / (C * det));
 }
+// ... from the record's conic alone (what the binning and the wave-cooperative walks have at hand).  The determinant is formed HERE, uncontracted: written at
+// a call site in a translation unit that contracts (binning.hip) it became fma(A, C, -B B), an ulp away from preprocess's and the oracle's A C - B B, and one
+// tile of one row of a 1 386-tile rectangle went missing (tools/fuzz_parity.py ... big, case 4; tests/test_gpu_trained_scene.py keeps the scene).
+__device__ __forceinline__ void cull_rows_setup_conic(CullRows& j, float px, float py, float A, float B, float C, float qmax, int x0, int x1)
+{
+#pragma clang fp contract(off)
+    const float det = A * C - B * B;
+    cull_rows_setup(j, px, py, A, B, C, det, qmax, x0, x1);
+}
 // tiles [t0, t1] of tile row ty; false when the row holds none.  (median of (v, lo, hi) == the oracle's v < lo ? lo : (v > hi ? hi : v) for
 // lo <= hi and finite v: a pure selection, one v_med3_f32)
 __device__ __forceinline__ bool cull_row_run(const CullRows& j, int ty, int& t0, int& t1)

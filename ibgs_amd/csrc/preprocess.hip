@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
             const float gpx = gq0.x, gpy = gq0.y, go = gq0.z, gA = gq1.x, gB = gq1.y, gC = gq1.z;
             const uint32_t grx = (uint32_t)__builtin_amdgcn_readlane((int)rx, g), gry = (uint32_t)__builtin_amdgcn_readlane((int)ry, g);
             CullJob u;
-            cull_rows_setup(u.rows, gpx, gpy, gA, gB, gC, gA * gC - gB * gB, cull_qmax(go), (int)(grx & 0xFFFFu), (int)(grx >> 16));
+            cull_rows_setup_conic(u.rows, gpx, gpy, gA, gB, gC, cull_qmax(go), (int)(grx & 0xFFFFu), (int)(grx >> 16));
             u.y0 = (int)(gry & 0xFFFFu) - p.tile_row0; u.w = (int)(grx >> 16) - (int)(grx & 0xFFFFu); u.h = (int)(gry >> 16) - (int)(gry & 0xFFFFu);
             const bool masked = u.w * u.h <= IBGS_CULL_MAX_TILES;
             uint64_t m[IBGS_CULL_WORDS] = {0, 0, 0, 0};

@@ -125,3 +125,21 @@ def test_batched_depth_views_with_large_rectangles():
         d = np.abs(depths[v].cpu().numpy() - ref["median_depth"])
         assert d.mean() / (np.abs(ref["median_depth"]).mean() + 1e-9) < 1e-5, v
     assert nbig > 100
+
+
+@pytest.mark.parametrize("P,W,H,deg,seed", [(9000, 668, 604, 0, 582813), (9000, 1143, 524, 2, 166922)])
+def test_row_runs_of_the_binning_equal_the_count(P, W, H, deg, seed):
+    """Two scenes a random sweep found (tools/fuzz_parity.py 30 11 - big, cases 4 and 21): a row-culled rectangle of 1 386 tiles whose
+    determinant A C - B B, formed with a fused multiply-add at the binning's call site, put one run one tile short of what preprocess had
+    counted -- R one below the oracle's, 244 tile ranges shifted.  The determinant is formed in one uncontracted place now (common.h)."""
+    from tests.scenes import scene
+    inp = scene(P=P, W=W, H=H, deg=deg, seed=seed, opacity="init", scale_mul=7.5)
+    ref = oracle.forward(inp, cull=True)
+    big = (rect_area(ref) > 256) & (ref["tmask"][:, 0] == 0)
+    assert big.sum() > 50
+    outs, lv, _ = hipref.run_forward(inp, debug=True)
+    ist = hipref.internal_state(outs, inp)
+    o = hipref.to_np(outs)
+    assert np.array_equal(ist["tiles"], ref["tiles_touched"]) and ist["R"] == ref["num_rendered"]
+    assert np.array_equal(ist["ranges"], ref["ranges"]) and np.array_equal(ist["point_list"], ref["point_list"])
+    assert l1(o["color"], ref["color"]) < 1e-6

@@ -1,5 +1,6 @@
 """Randomised parity sweep on the MI355X (not part of the test suite): random sizes / degrees / modes against the oracle.
-python tools/fuzz_parity.py [n_cases] [seed]"""
+python tools/fuzz_parity.py [n_cases] [seed] [only] [big]
+("big" as the fourth argument: frames of 1 000 ... 3 600 tiles, clustered scenes, the library's own choice of wave shape -- the hybrid kernels' range)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,22 +12,28 @@ from tests.test_gpu_parity import add_sources, scene
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # replay ONE case of the sequence and print where the two sides part
+only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] not in ("-", "none") else None          # replay ONE case of the sequence and print where the two sides part
+BIG = len(sys.argv) > 4 and sys.argv[4] == "big"
 worst = {"color": 0.0, "grad": 0.0, "ncontrib": 1.0}
 bad = 0
 for case in range(n_cases):
     P = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000, 9000]))
     W, H = int(rng.integers(8, 320)), int(rng.integers(8, 240))
+    if BIG:
+        P = int(rng.choice([3000, 9000, 20000, 40000]))
+        W, H = int(rng.integers(480, 1281)), int(rng.integers(360, 721))
     deg = int(rng.integers(0, 4)); geo = bool(rng.integers(0, 3) == 0)
     opacity = str(rng.choice(["init", "trained"])); smul = float(rng.choice([0.5, 1.0, 2.5]))
     rasterizer.WAVE_SHAPE = [None, "tile", "quadrant"][int(rng.integers(0, 3))]
+    if BIG:
+        rasterizer.WAVE_SHAPE = None
     sseed = int(rng.integers(0, 10**6))
     n_src, Lb = (int(rng.integers(1, 6)), int(rng.integers(1, 9))) if geo else (1, 4)
     if only is not None and case != only:          # consume the same draws as the full run
         rng.standard_normal((3, H, W))
         if geo: rng.standard_normal((3, H, W)); rng.standard_normal((1, H, W)); rng.standard_normal((15, H, W))
         continue
-    inp = scene(P=P, W=W, H=H, deg=deg, seed=sseed, opacity=opacity, planes=geo, scale_mul=smul)
+    inp = scene(P=P, W=W, H=H, deg=deg, seed=sseed, opacity=opacity, planes=geo, scale_mul=smul * (3.0 if BIG else 1.0))
     if geo:
         inp = add_sources(inp, n_src=n_src, L=Lb)
     ref = oracle.forward(inp, cull=True)
@@ -69,6 +76,26 @@ for case in range(n_cases):
         print("     worst Gaussian %d: %s HIP %s oracle %s twin %s | 1 - b^2/(ac) = %.2e, radius %d" % (i, k, a[i].ravel()[:5], np.asarray(rb[k])[i].ravel()[:5], np.asarray(b1[k])[i].ravel()[:5], 1 - co[1] ** 2 / max(co[0] * co[2], 1e-30), ref["radii"][i]))
     if only is not None:
         HW = H * W
+        if not ok:          # where the lists part
+            print("     R HIP %d oracle %d; radii equal %s; tiles_touched equal %s" % (ist["R"], ref["num_rendered"], np.array_equal(o["radii"], ref["radii"]), np.array_equal(ist["tiles"], ref["tiles_touched"])))
+            dt = np.flatnonzero(ist["tiles"] != ref["tiles_touched"])
+            for i in dt[:6]:
+                print("     Gaussian %d: tiles HIP %d oracle %d, rect %s, radius %d, mean2D %s conic_opacity %s tmask %s" % (i, ist["tiles"][i], ref["tiles_touched"][i], ref["rect4"][i], ref["radii"][i], ref["means2D"][i], ref["conic_opacity"][i], ref["tmask"][i]))
+            if np.array_equal(ist["ranges"], ref["ranges"]):
+                d = np.flatnonzero(ist["point_list"] != ref["point_list"])
+                print("     ranges equal; %d list positions differ, first %s" % (d.size, d[:8]))
+                for j in d[:4]:
+                    t = int(np.searchsorted(ref["ranges"][:, 1], j, side="right"))
+                    a, b = int(ist["point_list"][j]), int(ref["point_list"][j])
+                    print("       pos %d (tile %d): HIP id %d depth %.9g | oracle id %d depth %.9g" % (j, t, a, ref["depths"][a], b, ref["depths"][b]))
+            else:
+                dr = np.flatnonzero((ist["ranges"] != ref["ranges"]).any(axis=1))
+                print("     ranges differ at %d tiles, first %s" % (dr.size, dr[:8]))
+                for t in dr[:3]:
+                    ha = set(ist["point_list"][ist["ranges"][t, 0]:ist["ranges"][t, 1]].tolist()); oa = set(ref["point_list"][ref["ranges"][t, 0]:ref["ranges"][t, 1]].tolist())
+                    print("       tile %d (x %d y %d): HIP %d entries, oracle %d; only HIP %s only oracle %s" % (t, t % ((W + 15) // 16), t // ((W + 15) // 16), len(ha), len(oa), sorted(ha - oa)[:5], sorted(oa - ha)[:5]))
+                    for i in (sorted(ha - oa) + sorted(oa - ha))[:3]:
+                        print("         Gaussian %d: rect %s radius %d mean2D %s conic_opacity %s tmask %s tiles HIP %d oracle %d" % (i, ref["rect4"][i], ref["radii"][i], ref["means2D"][i], ref["conic_opacity"][i], ref["tmask"][i], ist["tiles"][i], ref["tiles_touched"][i]))
         print("     n_contrib differs at pixels", np.flatnonzero(ist["n_contrib"] != ref["n_contrib"])[:10], "final_T max diff %.2e" % np.abs(ist["final_T"] - ref["final_T"]).max())
         dcol = np.abs(o["color"] - ref["color"]).max(0).ravel()
         for pix in np.argsort(-dcol)[:3]:
