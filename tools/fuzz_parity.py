@@ -1,6 +1,7 @@
 """Randomised parity sweep on the MI355X (not part of the test suite): random sizes / degrees / modes against the oracle.
 python tools/fuzz_parity.py [n_cases] [seed] [only] [big]
-("big" as the fourth argument: frames of 1 000 ... 3 600 tiles, clustered scenes, the library's own choice of wave shape -- the hybrid kernels' range)"""
+("big" as the fourth argument: frames of 1 000 ... 3 600 tiles, the library's own choice of wave shape -- the hybrid kernels' range; "trained": those
+frames with random anisotropy / cluster / log-normal sizes, synthetic.make_gaussians' knobs)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,7 @@ from tests.test_gpu_parity import add_sources, scene
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] not in ("-", "none") else None          # replay ONE case of the sequence and print where the two sides part
-BIG = len(sys.argv) > 4 and sys.argv[4] == "big"
+BIG = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] in ("big", "trained") else None          # "trained": big frames + random anisotropy / cluster / size spread
 worst = {"color": 0.0, "grad": 0.0, "ncontrib": 1.0}
 bad = 0
 for case in range(n_cases):
@@ -33,7 +34,17 @@ for case in range(n_cases):
         rng.standard_normal((3, H, W))
         if geo: rng.standard_normal((3, H, W)); rng.standard_normal((1, H, W)); rng.standard_normal((15, H, W))
         continue
-    inp = scene(P=P, W=W, H=H, deg=deg, seed=sseed, opacity=opacity, planes=geo, scale_mul=smul * (3.0 if BIG else 1.0))
+    if BIG == "trained":          # the trained generator's knobs as well (drawn from a generator of their own: the other modes' sequences stay what they were)
+        r2 = np.random.default_rng(sseed)
+        aniso = [None, "plane", "needle", "mixed"][int(r2.integers(0, 4))]; cl = float(r2.choice([0.0, 0.3, 0.5])); sig = float(r2.choice([0.0, 1.0]))
+        inp = syn.make_scene(P, W, H, sh_degree=deg, seed=sseed, opacity=opacity, with_planes=geo, anisotropy=aniso, scale_sigma=sig, cluster=cl)
+        mul = smul * (3.0 if sig == 0.0 else 6.0)
+        inp["scales"] = (inp["scales"] * mul).astype(np.float32)
+        if geo:
+            inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
+        print("     case %d: anisotropy %s cluster %.1f sigma %.0f" % (case, aniso, cl, sig))
+    else:
+        inp = scene(P=P, W=W, H=H, deg=deg, seed=sseed, opacity=opacity, planes=geo, scale_mul=smul * (3.0 if BIG else 1.0))
     if geo:
         inp = add_sources(inp, n_src=n_src, L=Lb)
     ref = oracle.forward(inp, cull=True)
@@ -53,7 +64,7 @@ for case in range(n_cases):
     else:
         (outs["color"] * torch.as_tensor(g, device="cuda")).sum().backward()
         rb = oracle.backward(inp, ref, g)
-    gr = 0.0
+    gr = 0.0; explained = False
     names = {"dL_dmeans3D": "means3D", "dL_dopacity": "opacities", "dL_dscales": "scales"}
     if geo:
         names["dL_dall_map"] = "all_map"
@@ -67,6 +78,9 @@ for case in range(n_cases):
             b1 = oracle.backward(inp, r1, g, gn, gdp, gw) if geo else oracle.backward(inp, r1, g)
         allk = {"dL_dmeans3D": "means3D", "dL_dmeans2D": "means2D", "dL_dopacity": "opacities", "dL_dsh": "shs", "dL_dscales": "scales", "dL_drotations": "rotations"}
         if geo: allk["dL_dall_map"] = "all_map"
+        # ill-conditioned Gaussians (needles, giant planes: conics within 1e-4 of singular): a gradient counts as explained when the kernels are no farther
+        # from the oracle than three times what the oracle's own fma / no-fma builds differ by (the bar of tests/test_gpu_anisotropic.py before the float64 arbiter)
+        explained = all(rel_l2(lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape), rb[k]) <= max(1e-3, 3.0 * rel_l2(b1[k], rb[k])) for k, v in allk.items() if np.abs(rb[k]).sum() > 0)
         print("     case %d detail (HIP vs oracle | oracle fma vs no-fma): " % case + ", ".join(
             "%s %.1e|%.1e" % (v, rel_l2(lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape), rb[k]), rel_l2(b1[k], rb[k])) for k, v in allk.items() if np.abs(rb[k]).sum() > 0))
         k = "dL_dall_map" if geo else "dL_dscales"
@@ -106,7 +120,7 @@ for case in range(n_cases):
                 print("     %s max diff %.2e at pixel %d; low/high HIP %s oracle (%d, %d); sum_w %.6g / %.6g; valid HIP %s oracle %s" % (k, dk[pix], pix, ist["low_high"][pix], ref["cache_low"][pix], ref["cache_high"][pix],
                       ist["sum_w"][pix], ref["cache_sum_w"][pix], ist["valid_idx"][:, pix], ref["valid_src_idx"][:, pix]))
     worst["color"] = max(worst["color"], dc); worst["grad"] = max(worst["grad"], gr); worst["ncontrib"] = min(worst["ncontrib"], nc)
-    flag = ok and dc < 1e-5 and gr < (2e-2 if geo else 5e-3) and nc > 0.995
+    flag = ok and dc < 1e-5 and (gr < (2e-2 if geo else 5e-3) or explained) and nc > 0.995
     bad += not flag
     print("%s case %2d: P=%5d %3dx%3d deg=%d geo=%d shape=%-8s R=%7d | lists %s colour L1 %.1e n_contrib eq %.4f grad relL2 %.1e"
           % ("ok  " if flag else "FAIL", case, P, W, H, deg, geo, rasterizer.WAVE_SHAPE, ist["R"], ok, dc, nc, gr), flush=True)
