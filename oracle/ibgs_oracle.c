@@ -181,7 +181,12 @@ static int sh_basis(int deg, const float* d, float* B)
  * 0.1 % + 1e-3 safety margin, far above fp32 rounding of `power`) are dropped.  All arithmetic
  * is +,-,*,/,sqrt in fp32 so that gcc and hipcc (-ffp-contract=off) agree exactly.
  * ---------------------------------------------------------------------------------------- */
-static float ln_portable(float x_in)           /* |error| < 2e-6 for x >= 1; basic IEEE ops only */
+#if defined(__GNUC__) && !defined(__clang__)
+#define ORC_DECISION __attribute__((noinline, optimize("fp-contract=off")))
+#else
+#define ORC_DECISION __attribute__((noinline))
+#endif
+static ORC_DECISION float ln_portable(float x_in)           /* |error| < 2e-6 for x >= 1; basic IEEE ops only */
 {
     const orc_f32 x = (orc_f32)x_in;
     uint32_t u; memcpy(&u, &x, 4);
@@ -214,14 +219,19 @@ void orc_power_skips(long long* out) { out[0] = g_power_skips[0]; out[1] = g_pow
  * ~30 operations per ROW instead of ~50 per tile; the same tiles as a closest-point test per tile, up to the 0.01 px slack below.
  * (ibgs_amd/csrc/common.h: CullRows / cull_rows_setup / cull_row_run -- the same operations in the same order.) */
 typedef struct { float px, py, B, det, invA, aq, ymax, ystar; int x0, x1; } CullRows;
-static void cull_rows_setup(CullRows* j, float px, float py, float A, float B, float C, float det, float qmax, int x0, int x1)
+/* The tile cull takes DECISIONS, and two places take the same ones: the count in tile_cull and the emission in orc_bin.  They must agree in EVERY build of this
+ * file -- in the fma-contracted twin gcc was free to contract A C - B B one way at one site and another way at the other, and its binning then emitted a
+ * different number of entries than its preprocess had counted (orc_bin: -2).  So the helpers below are never contracted and never inlined into contracted code
+ * (the HIP side does the same: `#pragma clang fp contract(off)` in common.h), and the determinant has one home. */
+static ORC_DECISION float cull_det(float A, float B, float C) { return A * C - B * B; }
+static ORC_DECISION void cull_rows_setup(CullRows* j, float px, float py, float A, float B, float C, float det, float qmax, int x0, int x1)
 {
     j->px = px; j->py = py; j->B = B; j->det = det; j->x0 = x0; j->x1 = x1;
     j->invA = 1.0f / A; j->aq = A * qmax;
     j->ymax = sqrtf(j->aq / det); j->ystar = -B * sqrtf(qmax / (C * det));
 }
 /* tiles [*t0, *t1] of tile row ty (inside the tightened rectangle's columns [x0, x1)); returns 0 when the row holds none */
-static int cull_row_run(const CullRows* j, int ty, int* t0_out, int* t1_out)
+static ORC_DECISION int cull_row_run(const CullRows* j, int ty, int* t0_out, int* t1_out)
 {
     const float Y0 = (float)(ty * 16) - j->py, Y1 = Y0 + 15.0f;
     const float yb0 = fmaxf_(Y0, -j->ymax), yb1 = fminf_(Y1, j->ymax);
@@ -234,7 +244,7 @@ static int cull_row_run(const CullRows* j, int ty, int* t0_out, int* t1_out)
     *t0_out = t0; *t1_out = t1;
     return t1 >= t0;
 }
-static inline float cull_qmax(float o) { return 2.0f * ln_portable(255.0f * o) * 1.001f + 0.001f; }
+static ORC_DECISION float cull_qmax(float o) { return 2.0f * ln_portable(255.0f * o) * 1.001f + 0.001f; }
 
 /* In: pixel centre, cov2D diagonal (with the 0.3), conic, opacity, reference rectangle.
  * Out: tightened rectangle and which of its tiles survive:
@@ -259,7 +269,7 @@ static uint32_t tile_cull(float px, float py, float sxx, float syy, float A, flo
     if (tx1 <= tx0 || ty1 <= ty0) { *x1 = *x0; *y1 = *y0; for (int k = 0; k < CULL_WORDS; k++) mask[k] = 0; return 0; }
     *x0 = tx0; *x1 = tx1; *y0 = ty0; *y1 = ty1;
     const int w = tx1 - tx0, h = ty1 - ty0;
-    const float det = A * C - B * B;
+    const float det = cull_det(A, B, C);
     if (!(A > 0.0f) || !(C > 0.0f) || !(det > 0.0f)) return (uint32_t)(w * h);
     const int big = w * h > CULL_MAX_TILES;
     uint64_t m[CULL_WORDS] = {0, 0, 0, 0}; uint32_t cnt = 0;
@@ -403,7 +413,7 @@ int orc_bin(int P, int64_t R, const int32_t* radii, const int32_t* rect4, const 
         if (dense && tmask[CULL_WORDS * i] == 0ull) {          /* culled row by row (tile_cull): the same runs, recomputed */
             const float A = conic_opacity[4 * i], B = conic_opacity[4 * i + 1], C = conic_opacity[4 * i + 2];
             CullRows j;
-            cull_rows_setup(&j, means2D[2 * i], means2D[2 * i + 1], A, B, C, A * C - B * B, cull_qmax(conic_opacity[4 * i + 3]), x0, x1);
+            cull_rows_setup(&j, means2D[2 * i], means2D[2 * i + 1], A, B, C, cull_det(A, B, C), cull_qmax(conic_opacity[4 * i + 3]), x0, x1);
             for (int y = y0; y < y1; y++) {
                 int t0, t1;
                 if (!cull_row_run(&j, y, &t0, &t1)) continue;
