@@ -1,0 +1,25 @@
+"""Random sweep of `renderer.render(render_geo=True)` with the plane glue fused into the kernels (not part of the suite): image, normals and every
+parameter gradient against the oracle pushed through the reference-style torch glue (tests/test_gpu_fused_planes.py's check) at random sizes and seeds.
+python tools/fuzz_fused.py [n_cases] [seed]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.metrics import l1, rel_l2
+from tests.test_gpu_fused_planes import _oracle_chain, _run, _scene
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n_cases):
+    P = int(rng.choice([500, 2500, 6000])); W, H = int(rng.integers(96, 520)), int(rng.integers(80, 340)); seed = int(rng.integers(0, 10**6)); learnt = bool(rng.integers(0, 2))
+    dev, g, cams, scene, pipe, args, bg = _scene(P=P, W=W, H=H, seed=seed)
+    o_fus, g_fus = _run(True, learnt, g, dev, cams, scene, pipe, args, bg)
+    ref, g_orc = _oracle_chain(learnt, g, dev, cams, scene, bg)
+    dc, dn = l1(o_fus["render"].cpu().numpy(), ref["color"]), l1(o_fus["rendered_normal"].cpu().numpy(), ref["normal_map"])
+    names = ["_xyz", "_rotation", "_scaling", "_opacity", "_features_dc"] + (["_normal", "_offset"] if learnt else [])
+    errs = {n: (rel_l2(g_fus[n], g_orc[n]) if g_orc[n] is not None and np.abs(g_orc[n]).sum() > 0 else float("nan")) for n in names}
+    worst = max(v for v in errs.values() if v == v) if any(v == v for v in errs.values()) else 0.0
+    ok = dc < 1e-6 and dn < 1e-5 and worst < 5e-3
+    bad += not ok
+    print("%s case %2d: P %d %dx%d seed %d learnt %d | colour %.1e normal %.1e grads %s" % ("ok  " if ok else "FAIL", case, P, W, H, seed, learnt, dc, dn, {k: "%.1e" % v for k, v in errs.items()}), flush=True)
+print("failures:", bad)
