@@ -96,7 +96,7 @@ def internal_state(outs, inp):
     st["R"] = Rr
     if Rr > 0:
         # the arena may have been carved for a rendered_hint >= R (include/ibgs_rast.h): recover that size from its length
-        lo, hi = Rr, 2 * Rr + (1 << 20)
+        lo, hi = Rr, max(2 * Rr + (1 << 20), bb.size // 4 + 1)          # (the hint may come from a much denser scene of the same size: the capacity is bounded by the arena itself)
         while lo < hi:
             mid = (lo + hi) // 2
             if lib.ibgs_required_binning(mid, W, H) >= bb.size:

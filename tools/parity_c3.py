@@ -3,7 +3,8 @@ C3 bench workload -- image L1 / max / PSNR difference, per-pixel counter agreeme
 
 python tools/parity_c3.py                 the near-isotropic bench scene, init and trained-like opacities (profiles/r02_parity_c3.txt)
 python tools/parity_c3.py plane needle    anisotropic variants of the same scene (synthetic.make_gaussians), with the oracle's own
-                                          fma / no-fma difference beside every number and its count of `power > 0` skips
+                                          fma / no-fma difference beside every number, its count of `power > 0` skips, and both fp32 sides against
+                                          the float64 build of the oracle (the arbiter: |HIP - f64| against |oracle fp32 - f64| per gradient)
 python tools/parity_c3.py geo plane       the geo path (4 sources, L = 4; source images random, source depths the oracle's own depth-only
                                           renders at a quarter of the views' resolution upsampled -- the oracle walks 2 M pixels per pass)"""
 import os, sys, time
@@ -78,5 +79,11 @@ for aniso, opacity in cases:
               % (l1(r1["color"], ref["color"]), np.abs(r1["color"] - ref["color"]).max(), (r1["n_contrib"] == ref["n_contrib"]).mean(),
                  r1["num_rendered"] == ref["num_rendered"] and np.array_equal(r1["point_list"], ref["point_list"])))
         print("   ... grads rel L2:", {k: float("%.2e" % rel_l2(b1[k], rb[k])) for k in names})
+        # the float64 build of the same C source as the arbiter (round 4): how far is each fp32 side from it?
+        with oracle.variant("f64"):
+            r64 = oracle.forward(inp, cull=True); b64 = oracle.backward(inp, r64, g, gn, gd, gw)
+        hip = {k: lv[v].grad.cpu().numpy().reshape(np.asarray(rb[k]).shape).astype(np.float64) for k, v in names.items()}
+        print("   against the float64 build: image mean L1 HIP %.3e oracle fp32 %.3e" % (l1(col, r64["color"]), l1(ref["color"], r64["color"])))
+        print("   ... grads rel L2, HIP | oracle fp32 (ratio):", {k: "%.1e | %.1e (%.2f)" % (rel_l2(hip[k], b64[k]), rel_l2(rb[k], b64[k]), rel_l2(hip[k], b64[k]) / max(rel_l2(rb[k], b64[k]), 1e-30)) for k in names})
     del outs, lv
     torch.cuda.empty_cache()
