@@ -5,6 +5,7 @@ python tools/parity_c3.py                 the near-isotropic bench scene, init a
 python tools/parity_c3.py plane needle    anisotropic variants of the same scene (synthetic.make_gaussians), with the oracle's own
                                           fma / no-fma difference beside every number, its count of `power > 0` skips, and both fp32 sides against
                                           the float64 build of the oracle (the arbiter: |HIP - f64| against |oracle fp32 - f64| per gradient)
+python tools/parity_c3.py [geo] trainer   the scene of bench.py's `trained_geo` line (plane-like, heavy-tailed, clustered, trained opacities)
 python tools/parity_c3.py geo plane       the geo path (4 sources, L = 4; source images random, source depths the oracle's own depth-only
                                           renders at a quarter of the views' resolution upsampled -- the oracle walks 2 M pixels per pass)"""
 import os, sys, time
@@ -22,7 +23,10 @@ modes = [m for m in modes if m != "geo"]
 cases = [(None, "init"), (None, "trained")] if not modes else [(m, "trained") for m in modes]
 names = {"dL_dmeans3D": "means3D", "dL_dsh": "shs", "dL_dopacity": "opacities", "dL_dscales": "scales", "dL_drotations": "rotations", "dL_dmeans2D": "means2D"}
 for aniso, opacity in cases:
-    inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity, anisotropy=aniso, with_planes=GEO)
+    if aniso == "trainer":          # the `trained_geo` scene of bench.py: plane-like, log-normal sizes (sigma 1), 30 % in one blob, trained opacities
+        inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity, anisotropy="plane", scale_sigma=1.0, cluster=0.3, with_planes=GEO)
+    else:
+        inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=3, seed=c["seed"], opacity=opacity, anisotropy=aniso, with_planes=GEO)
     if GEO:
         W, H = c["W"], c["H"]
         srcs = [syn.make_camera(W, H, azimuth_deg=a) for a in (7.0, -7.0, 14.0, -14.0)]
