@@ -512,8 +512,7 @@ __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint3
 // thread, the 1024 strip sums scanned through LDS.  Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after
 // its memset).
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
-                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
-                                                           uint32_t* __restrict__ meta /* may be null: [12] = list entries of the frame (the hybrid colour kernel, render_fwd.hip) */)
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
 {
     // Every wave owns a contiguous range of tiles and walks it 64 tiles at a time: coalesced loads and stores, a wave-level scan per step.
     // (A strip of consecutive tiles per THREAD made every lane touch its own cache line, per step: 11 us at 1080p, 54 us for the 32 640 tiles
@@ -552,7 +551,7 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t*
 #pragma unroll
     for (int k = 0; k < KEEP; k++) if (k < nsteps) step(k, v[k]);          // (wave-uniform condition)
     for (int k = KEEP; k < nsteps; k++) { const int t = w0 + k * 64 + lane; step(k, t < w1 ? tile_start[t] : 0u); }
-    if (tid == 1023) { tile_start[ntiles] = run; counters[0] = run; if (meta) meta[12] = min(run, cap); }      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
+    if (tid == 1023) { tile_start[ntiles] = run; counters[0] = run; }      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
 }
 
 // One wave per chunk: ids to their final slots, in order.  Per round of 64 entries the wave transposes the bit matrix (row = entry,
@@ -690,7 +689,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
-                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), meta);
+                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll));
     IBGS_HIP(hipGetLastError());
     return 0;
 }

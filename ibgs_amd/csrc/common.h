@@ -68,7 +68,7 @@ struct ImgState {
     uint32_t* low_high;    // HW x 2 (geo) min / max contributor of the median buffer
     int32_t* valid_idx;    // 5 x HW (geo)
     float* valid_w;        // 5 x HW (geo)
-    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = waves per tile of the forward variant that wrote tile_walked, [11] = 1 when the caller's tile_order_hint holds a valid order, [12] = list entries of the frame (binning)
+    uint32_t* meta;        // 32 words written by the forward for the backward: [0] = buffer_length of a geo pass, [10] = waves per tile of the forward variant that wrote tile_walked, [11] = 1 when the caller's tile_order_hint holds a valid order
     uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
     uint32_t* tile_walked; // tiles x 4   how far the forward walked every tile's list (largest n_contrib), per wave of the tile ([tile * waves + wave]) = the backward's work there
     uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)

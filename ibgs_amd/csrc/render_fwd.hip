@@ -40,7 +40,7 @@ struct FwdParams {
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
     int hybrid_grid1;    // ... its first hybrid_grid1 workgroups are the tiles' first waves (hybrid_item, common.h)
-    int hybrid;          // > 0: render_fwd_color_hybrid_kernel; the value is the split threshold in per cent of a SIMD's fair share (HYBRID_THETA)
+    int hybrid;          // 1: render_fwd_color_hybrid_kernel
     const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by an extra workgroup of cell_place_kernel: meta[11]; nullptr: the tile map
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
@@ -578,7 +578,10 @@ __global__ void __launch_bounds__(64, 8) render_fwd_color_hybrid_kernel(FwdParam
             if (tile >= p.ntiles) return;
         }
         else if (!hybrid_item_mapped(p.tmap, blockIdx.x, p.hybrid_grid1, p.cam.gx, p.ntiles / p.cam.gx, tile, sub)) return;
-        split = hybrid_split(p.ranges[2 * tile + 1] - p.ranges[2 * tile], p.meta[12], (uint32_t)p.hybrid);          // no measurement: by the length of the list
+        // no measurement to go by: four quadrant waves for every tile, what the library did on such frames before the hybrid kernels.  (The length of the
+        // tile's list is no substitute: right on even scenes with initial opacities, but with trained opacities most of a long list is never walked and the
+        // heavy tiles are the UNsaturated ones -- 800 x 800, trained: 0.28 ms by length against 0.16 ms for all-quadrant and for the backward's flags.)
+        split = true;
     }
     if (split) {
         if (sub == 0) render_fwd_body<MODE_COLOR, 1, 4, 0>(p, tile, 0, s_rec);
@@ -640,7 +643,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
         const bool small = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles());
         const bool forced = (a.flags & (IBGS_FLAG_QUADRANT_WAVES | IBGS_FLAG_TILE_WAVES)) != 0;
         if (small && !forced && p.n_views <= 1 && nt >= HYBRID_MIN_TILES) {
-            p.hybrid = hybrid_theta();
+            p.hybrid = 1;
             if (a.tile_order_hint) {          // (the same camera's last backward order, as for the tile-wave kernel below)
                 p.order = a.tile_order_hint;
                 p.hybrid_grid1 = (p.ntiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;

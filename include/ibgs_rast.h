@@ -62,8 +62,8 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                         tile (geo); default: only when the frame has >= 4096 tiles */
 #define IBGS_FLAG_QUADRANT_WAVES 64u /* blend kernels: always one wave per 8x8 quadrant.  Default for frames of fewer than 4096 tiles: geo passes
                                         this; colour passes choose PER TILE on the device -- one wave, or four quadrant waves for a tile whose
-                                        work exceeds half of a SIMD's fair share of the frame's (the forward goes by the length of the tile's list
-                                        or, given tile_order_hint, by the last backward's choice; the backward by how far the forward walked it) */
+                                        work exceeds half of a SIMD's fair share of the frame's (the backward goes by how far the forward walked the
+                                        tile's list; the forward by that backward's choice when it is given tile_order_hint, else four waves everywhere) */
 
 #define IBGS_PLANE_NONE 0
 #define IBGS_PLANE_LEARNT 1

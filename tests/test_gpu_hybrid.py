@@ -1,7 +1,6 @@
-"""The hybrid colour kernels (frames of fewer than 4 096 tiles, no wave shape forced): per tile either one wave or four quadrant waves,
-chosen on the device -- by the forward from the length of the tile's list, or, when the caller hands it the order the same camera's last backward
-left (rasterizer.ORDER_HINT), from that backward's choice; by the backward from how far the forward walked the list (bit 31 of the tile's word in the
-launch order).  Any mixture must give the oracle's image and gradients; the deterministic mode's slab holds four rows per list entry whichever
+"""The hybrid colour kernels (frames of 768 ... 4 095 tiles, no wave shape forced): per tile either one wave or four quadrant waves,
+chosen on the device -- by the backward from how far the forward walked the tile's list (bit 31 of the tile's word in the launch order), by the forward
+from that flag when the caller hands it the order the same camera's last backward left (rasterizer.ORDER_HINT); without one it splits every tile.  Any mixture must give the oracle's image and gradients; the deterministic mode's slab holds four rows per list entry whichever
 shape walked it."""
 import numpy as np
 import pytest
@@ -65,13 +64,12 @@ def test_mixture_of_tile_and_quadrant_waves(opacity):
     gb = oracle.backward(inp, ref, g)
     rasterizer._order_hints.clear()
     st = hipref.settings_from(inp, "cuda", False)
-    # first call of this camera: no order to go by, the forward decides on the lists' lengths
+    # first call of this camera: no measurement to go by -- every tile is walked by four quadrant waves (what the library did before the hybrid kernels)
     o, ist, leaves, meta, walked, order = step(inp, g, st)
-    assert meta[10] == 4 and meta[11] == 0 and meta[12] == ref["num_rendered"]
+    assert meta[10] == 4 and meta[11] == 0
     n = ist["ranges"][:, 1].astype(np.int64) - ist["ranges"][:, 0]
     split = (walked[:, 1:] > 0).any(axis=1)          # (a tile wave leaves words 1..3 at zero; a split tile's quadrants all see something in this scene)
-    assert split.sum() > 4 and (~split & (n > 0)).sum() > nt // 4, ("no mixture", split.sum(), nt)
-    assert n[split].min() > n[~split].max(), "the forward's choice follows the length of the list"
+    assert split[n > 64].all(), "a tile of the first call was walked by one wave"
     check_color(o, ist, ref); check_grads(leaves, gb)
     # the backward left its order: every tile once, heavy ones flagged
     tiles = order[order != 0xFFFFFFFF]
@@ -85,8 +83,7 @@ def test_mixture_of_tile_and_quadrant_waves(opacity):
     assert meta2[11] == 1, "the hint was not accepted"
     split2 = (walked2[:, 1:] > 0).any(axis=1)
     assert not split2[~flagged].any() and split2[flagged].all(), "the forward's shapes are not the backward's flags"
-    if opacity == "trained":          # (saturating pixels: how far a list is walked and how long it is are different things)
-        assert not np.array_equal(split2, split), "lengths and walks chose the same tiles: the scene does not tell the two rules apart"
+    assert (~split2 & (n > 64)).sum() > nt // 4, "the second call walked (nearly) every tile with four waves: no mixture"
     check_color(o2, ist2, ref); check_grads(leaves2, gb)
     assert np.array_equal(np.sort(order2 & ~np.uint32(SPLIT)), np.sort(order & ~np.uint32(SPLIT)))
 
@@ -110,13 +107,12 @@ def test_deterministic_backward_under_a_mixture():
         assert torch.equal(a, runs[2][lk].grad), lk          # same mixture of shapes (the previous backward's flags), no atomics: the same bits
         b = atomic[lk].grad
         if float(b.abs().max()) > 0:
-            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-4, lk          # (atomic order, and another mixture of shapes: the first call went by list lengths)
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-4, lk          # (atomic order, and another mixture of shapes: the first call split every tile)
             assert rel_l2(runs[0][lk].grad.cpu().numpy(), b.cpu().numpy()) < 1e-4, lk
 
 
 def test_image_bits_do_not_depend_on_the_mixture():
-    """first call (shapes by list length), second call (the backward's flags), forced quadrant waves through the hybrid kernel's own rule
-    (IBGS_HYBRID_THETA is read at load time, so that one is not varied here): the image and the per-pixel state are bit-identical."""
+    """first call (every tile split), second call (the backward's flags: most tiles walked by one wave): the image and the per-pixel state are bit-identical."""
     inp = uneven_scene(seed=97, opacity="trained")
     g = rnd((3, inp["H"], inp["W"]), 7)
     rasterizer._order_hints.clear()
