@@ -233,6 +233,7 @@ struct RSlot {
     uint32_t* host; hipEvent_t ev;
     uint32_t* part; size_t part_cap;          // deferred sizing: the preprocess kernel's per-wave tile sums + the depth sort's error flag (pinned, grown on demand)
     uint32_t* stats; hipEvent_t ev_stats; bool stats_pending;          // R as the binning counted it, -, C: diagnostics, read when somebody asks (ibgs_last_forward_stats)
+    bool flag_pending;                                                 // stats[3] = the depth sort's error flag of the last hinted forward, not looked at yet (check_sort_flag)
     hipStream_t copy_stream; hipEvent_t ev_mark;          // the read-backs run on a stream of their own, behind a marker of the caller's stream: a copy queued INTO the
                                                           // caller's stream is a blit kernel between two barriers there (~25 us of the step)
 };
@@ -265,6 +266,20 @@ static int rslot_reserve_part(RSlot* rs, size_t words)
     const size_t cap = words + words / 4 + 1024;
     if (hipHostMalloc(&p, cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the tile sums failed"); return -IBGS_ERR_HIP; }
     rs->part = static_cast<uint32_t*>(p); rs->part_cap = cap;
+    return 0;
+}
+
+// The depth sort's error flag of a hinted forward travels back behind the binning, together with the diagnostics, and nobody waits for it inside
+// that call (round 5: the tiles-touched sums leave right after the preprocess kernel, so that the host is released while the GPU is still sorting).
+// It is looked at by the next entry into the library on this thread -- a backward only if the words have already arrived -- and reported THERE: an
+// asynchronous error, like HIP's own.  (The look-back of the onesweep passes times out only if a workgroup is starved for seconds.)
+static int check_sort_flag(RSlot* rs, bool wait)
+{
+    if (!rs || !rs->flag_pending) return 0;
+    if (!wait && hipEventQuery(rs->ev_stats) != hipSuccess) return 0;
+    IBGS_HIP(hipEventSynchronize(rs->ev_stats));
+    rs->flag_pending = false;
+    if (rs->stats[3]) { set_error("depth sort of the previous forward: decoupled look-back timed out (its lists were mis-ordered)"); return -IBGS_ERR_HIP; }
     return 0;
 }
 
@@ -340,10 +355,27 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     ImgState im = ImgState::carve(a.img, a.W, Hn, nullptr);
     const int gx = (a.W + TILE - 1) / TILE, gy = nv * ((a.H + TILE - 1) / TILE);
 
-    { StageTimer t(s, IBGS_STAGE_PREPROCESS); if ((rc = launch_preprocess(s, a, g))) return rc; }
-    if ((rc = stage_check(s, debug, "preprocess"))) return rc;
     const bool deferred = a.rendered_hint > 0 && !debug;
     const size_t nwaves = (size_t)nv * (((size_t)a.P + 63) / 64);          // words of per-wave tile sums the preprocess kernel wrote; the depth sort's error flag follows them
+    RSlot* rs = rslot();
+    if (!rs) return -IBGS_ERR_HIP;
+    if ((rc = check_sort_flag(rs, true))) return rc;
+    { StageTimer t(s, IBGS_STAGE_PREPROCESS);
+      if ((rc = launch_preprocess(s, a, g, deferred ? 1 : 0))) return rc;
+      if (deferred) {
+          // R = the sum of the tiles touched, final as soon as the geometry kernel is: its per-wave sums leave for the host HERE, on the copy stream, while
+          // the caller's stream goes on with the SH colours and the depth sort.  (Until round 4 they left behind the sort, together with its error flag:
+          // on small frames the host then sat out five sort launches' worth of GPU latency -- ~45 us of a 0.34 ms call pair, profiles/r05_host_split.txt --
+          // before it could queue the loss and the backward.)
+          if ((rc = rslot_reserve_part(rs, nwaves + 1))) return rc;
+          IBGS_HIP(hipEventRecord(rs->ev_mark, s));
+          IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
+          IBGS_HIP(hipMemcpyAsync(rs->part, g.tile_partial, nwaves * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
+          IBGS_HIP(hipEventRecord(rs->ev, rs->copy_stream));
+          if ((rc = launch_preprocess(s, a, g, 2))) return rc;
+      }
+    }
+    if ((rc = stage_check(s, debug, "preprocess"))) return rc;
     { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
       // (the preprocess kernel has zeroed the sort's scratch, its look-back error flag -- [Pn + 1], or the word behind the tile sums when R is
       // sized from a hint: that one travels back together with them --, and [Pn + 3], [Pn + 4])
@@ -362,15 +394,6 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     { StageTimer t(s, IBGS_STAGE_SCAN);
       // (the total does not depend on the order: the per-Gaussian counts are scanned as they lie)
       if (!deferred && (rc = exclusive_scan_u32(s, g.tiles, g.offsets, (size_t)Pn, g.hist, g.hist_elems, true))) return rc; }
-    RSlot* rs = rslot();
-    if (!rs) return -IBGS_ERR_HIP;
-    if (deferred) {
-        if ((rc = rslot_reserve_part(rs, nwaves + 1))) return rc;
-        IBGS_HIP(hipEventRecord(rs->ev_mark, s));
-        IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
-        IBGS_HIP(hipMemcpyAsync(rs->part, g.tile_partial, (nwaves + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
-        IBGS_HIP(hipEventRecord(rs->ev, rs->copy_stream));
-    }
     auto exact_R = [&](int64_t* R_out) -> int {       // synchronous path: R from the scanned tile counts
         IBGS_HIP(hipMemcpyAsync(rs->host, g.offsets + Pn, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));      // R and the depth sort's error flag
         IBGS_HIP(hipEventRecord(rs->ev, s));
@@ -394,7 +417,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             IBGS_HIP(hipEventRecord(rs->ev_mark, s));
             IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
             IBGS_HIP(hipMemcpyAsync(rs->stats, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
+            IBGS_HIP(hipMemcpyAsync(rs->stats + 3, g.tile_partial + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));          // the depth sort's error flag (check_sort_flag)
             IBGS_HIP(hipEventRecord(rs->ev_stats, rs->copy_stream));
+            rs->flag_pending = true;
         }
         { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b))) return rc; }
         if ((rc = stage_check(s, debug, "binning"))) return rc;
@@ -412,7 +437,6 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     g_stats_slot = rs; rs->stats_pending = false;
     if (deferred) {
         IBGS_HIP(hipEventSynchronize(rs->ev));
-        if (rs->part[nwaves]) { set_error("depth sort: decoupled look-back timed out (lists would be mis-ordered)"); return -IBGS_ERR_HIP; }
         uint64_t sum = 0;
         for (size_t w = 0; w < nwaves; w++) sum += rs->part[w];
         R = (int64_t)sum;          // exact, whatever the binning could fit (a coarse entry stands for at least one pair: C <= R, so R <= cap means nothing was dropped)
@@ -422,6 +446,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             // second callback) and redo binning + render with the exact size (every output element is rewritten).  Same results
             // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
+            if ((rc = check_sort_flag(rs, true))) return rc;
             if ((rc = tail(R, false))) return rc;
         } else rs->stats_pending = true;
     }
@@ -436,6 +461,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     hipStream_t s = reinterpret_cast<hipStream_t>(a.stream);
     const bool debug = (a.flags & IBGS_FLAG_DEBUG) != 0;
     if (a.P <= 0) return 0;                                       // rasterize_points.cu:221
+    { int frc = check_sort_flag(g_stats_slot, false); if (frc) return frc; }
     if (!a.geom || !a.img || (!a.binning && a.R > 0)) { set_error("backward needs the forward's arenas"); return -IBGS_ERR_INVALID; }
     if (!a.grad_acc) { set_error("grad_acc scratch required"); return -IBGS_ERR_INVALID; }
     if (!a.dL_dmean2D || (!a.dL_dmean2D_abs && !(a.flags & IBGS_FLAG_NO_ABS_GRAD)) || !a.dL_dopacity || !a.dL_dmean3D) {

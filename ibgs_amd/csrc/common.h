@@ -394,7 +394,7 @@ constexpr int HYBRID_MIN_TILES = 768;
 inline int hybrid_max_tiles() { static const int v = getenv("IBGS_HYBRID_MAX_TILES") ? atoi(getenv("IBGS_HYBRID_MAX_TILES")) : 4096; return v; }
 inline int hybrid_theta() { static const int v = getenv("IBGS_HYBRID_THETA") ? atoi(getenv("IBGS_HYBRID_THETA")) : HYBRID_THETA; return v > 0 ? v : HYBRID_THETA; }      // (the env: experiments)
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g);
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0);
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
 
 // device-wide primitives (scan_sort.hip)

@@ -512,8 +512,8 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
     present[i] = z > 0.2f ? 1 : 0;
 }
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g)
-{
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase)
+{   // phase 0: everything; 1: the geometry kernel(s) alone -- after them the tiles-touched sums are final; 2: what phase 1 left out (the SH colours)
     PreParams p;
     p.P = a.P; p.D = a.D; p.M = a.M;
     p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
@@ -543,12 +543,11 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         // registers (120 VGPRs, 4 waves per SIMD against 65 / 7) whether it runs or not: 73 -> ~50 us per source view of a test-time frame
         const bool no_sh = a.render_depth_only || a.colors_precomp || !a.shs;
         if (split) {
-            hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
-            hipLaunchKernelGGL(sh_color_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
-        } else if (no_sh) {
-            hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
-        } else {
-            hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, s, p, cam);
+            if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
+            if (phase != 1) hipLaunchKernelGGL(sh_color_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        } else if (phase != 2) {
+            if (no_sh) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
+            else hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, s, p, cam);
         }
     }
     IBGS_HIP(hipGetLastError());

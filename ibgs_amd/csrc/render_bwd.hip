@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams
 }
 // Hybrid (frames of fewer tiles than wave slots; render_fwd.hip has the forward's twin and the reasoning): four workgroups per tile; where the forward
 // walked the tile's list further than `hybrid` per cent of a SIMD's fair share of all walks, each takes a quadrant, elsewhere the first takes the tile.
-// The forward left four walk lengths per tile (meta[10] = 4) and their sum in tile-wave units (meta[13]); after any other forward every tile is split.
+// The forward left four walk lengths per tile (meta[10] = 4; tile_order_kernel sums them and marks the tiles to split); after any other forward every tile is split.
 template <bool ABS>
 __global__ void __launch_bounds__(64, 8) render_bwd_color_hybrid_kernel(BwdParams p)
 {
@@ -844,7 +844,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
             if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo4_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
             else hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
         } else if (!big && !(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
-            // small frames: per tile one wave or four (render_bwd_geo_hybrid_kernel), the tiles' first waves in the balanced (snake) order
+            // small frames: per tile one wave or four (render_bwd_geo_hybrid_kernel), the tiles' first waves heaviest first (slot_rounds = 4: plain descending order)
             const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
             { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
               hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out, hybrid_theta()); }

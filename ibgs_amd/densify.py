@@ -122,3 +122,132 @@ def prune_and_extend_optimizer(optimizer, keep_mask=None, extension=None, extra=
         g["params"][0] = newp
         result[g["name"]] = newp
     return result, new_extra
+
+
+# ---- the reference's densification POLICY on top of the fused pass ---------------------------------------------------------------------------
+# scene/gaussian_model.py:471-522 (densify_and_split), :549-577 (densify_and_clone), :580-597 (densify_and_prune) select rows and build the new
+# ones with plain torch ops; the point set then changes through `prune_and_extend_optimizer` (one pass per change instead of a torch.cat / boolean
+# index per tensor and per Adam moment).  The selection functions below are device-agnostic torch code and reproduce the reference decision for
+# decision, quirks included (tests/golden/densify.npz holds the reference's own masks, new rows and final state for three runs):
+#   * every `densification_postfix` zeroes the per-point statistics INCLUDING max_radii2D (:463-468), and the split always calls it, so the
+#     final prune's screen-size test `max_radii2D > max_screen_size` (:593) only ever sees zeros;
+#   * the clone is skipped entirely -- no postfix, statistics untouched -- when nothing is selected (:562), the split is not (:505-519);
+#   * the caps compare `selected + n` with `max_all_points` and re-select by a quantile of the masked gradients with a strict `>` (:487-503, :554-560).
+class DensifyConfig:
+    """The four `training_args` fields the policy reads (scene/gaussian_model.py:217-223; defaults of arguments/__init__.py:99-116)."""
+
+    def __init__(self, percent_dense=0.001, abs_split_radii2D_threshold=20, max_abs_split_points=50_000, max_all_points=5_000_000):
+        self.percent_dense, self.abs_split_radii2D_threshold = percent_dense, abs_split_radii2D_threshold
+        self.max_abs_split_points, self.max_all_points = max_abs_split_points, max_all_points
+
+
+STAT_NAMES = ("xyz_gradient_accum", "xyz_gradient_accum_abs", "denom", "denom_abs", "max_radii2D", "max_weight")
+
+
+def _rotation_matrix(q):
+    """utils/general_utils.py:81-102 (`build_rotation`): normalises the quaternion (w, x, y, z), then the usual matrix."""
+    q = q / torch.sqrt((q * q).sum(dim=1, keepdim=True))
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).view(-1, 3, 3)
+
+
+def _named(optimizer):
+    return {g["name"]: g["params"][0] for g in optimizer.param_groups}
+
+
+def select_clone(p, grads, grad_threshold, scene_extent, cfg):
+    """Rows `densify_and_clone` duplicates (:549-560): small Gaussians with a large mean screen-space gradient, capped by a quantile."""
+    n = p["xyz"].shape[0]
+    sel = torch.norm(grads, dim=-1) >= grad_threshold
+    sel = torch.logical_and(sel, torch.max(torch.exp(p["scaling"]), dim=1).values <= cfg.percent_dense * scene_extent)
+    if sel.sum() + n > cfg.max_all_points:
+        g = grads.squeeze().clone()
+        g[~sel] = 0
+        sel = g > torch.quantile(g, 1.0 - (cfg.max_all_points - n) / float(n))
+    return sel
+
+
+def clone_rows(p, sel, sampler=torch.normal):
+    """The appended rows of `densify_and_clone` (:563-575): raw copies, the position moved by one draw from the Gaussian itself."""
+    stds = torch.exp(p["scaling"][sel])
+    samples = sampler(mean=torch.zeros((stds.size(0), 3), device=stds.device), std=stds)
+    ext = {k: v.detach()[sel] for k, v in p.items()}
+    ext["xyz"] = torch.bmm(_rotation_matrix(p["rotation"].detach()[sel]), samples.unsqueeze(-1)).squeeze(-1) + p["xyz"].detach()[sel]
+    return ext
+
+
+def select_split(p, grads, grad_threshold, grads_abs, grad_abs_threshold, scene_extent, max_radii2D, cfg):
+    """Rows `densify_and_split` replaces by N children (:471-503); `grads`, `grads_abs`, `max_radii2D` may be shorter than the point set
+    (rows appended by the clone come after them and count as zero)."""
+    n = p["xyz"].shape[0]
+    dev = p["xyz"].device
+    pad = lambda t: torch.cat((t.reshape(-1), torch.zeros(n - t.numel(), device=dev)))
+    g, ga, mr = pad(grads), pad(grads_abs), pad(max_radii2D)
+    big = torch.max(torch.exp(p["scaling"]), dim=1).values > cfg.percent_dense * scene_extent
+    sel = torch.logical_and(g >= grad_threshold, big)
+    if sel.sum() + n > cfg.max_all_points:
+        g[~sel] = 0
+        sel = g > torch.quantile(g, 1.0 - (cfg.max_all_points - n) / float(n))
+    else:
+        ga[sel] = 0
+        ga[~(big & (mr > cfg.abs_split_radii2D_threshold))] = 0
+        sel_abs = ga >= grad_abs_threshold
+        limited = min(cfg.max_all_points - n - sel.sum(), cfg.max_abs_split_points)
+        if sel_abs.sum() > limited:
+            sel_abs = ga > torch.quantile(ga, 1.0 - limited / float(n))
+        sel = torch.logical_or(sel, sel_abs)
+    return sel
+
+
+def split_rows(p, sel, sampler=torch.normal, N=2):
+    """The N children per selected row (:505-518): positions drawn from the parent, scales divided by 0.8 N, everything else copied."""
+    stds = torch.exp(p["scaling"].detach()[sel]).repeat(N, 1)
+    samples = sampler(mean=torch.zeros((stds.size(0), 3), device=stds.device), std=stds)
+    rots = _rotation_matrix(p["rotation"].detach()[sel]).repeat(N, 1, 1)
+    ext = {k: v.detach()[sel].repeat(*([N] + [1] * (v.dim() - 1))) for k, v in p.items()}
+    ext["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + p["xyz"].detach()[sel].repeat(N, 1)
+    ext["scaling"] = torch.log(stds / (0.8 * N))
+    return ext
+
+
+def select_prune(p, max_radii2D, min_opacity, extent, max_screen_size):
+    """Rows the last step of `densify_and_prune` removes (:589-596): transparent, or too large on screen / in the world."""
+    mask = (torch.sigmoid(p["opacity"]) < min_opacity).squeeze()
+    if max_screen_size:
+        mask = torch.logical_or(torch.logical_or(mask, max_radii2D > max_screen_size), torch.exp(p["scaling"]).max(dim=1).values > 0.1 * extent)
+    return mask
+
+
+def densify_and_prune(optimizer, stats, max_grad, abs_max_grad, min_opacity, extent, max_screen_size, cfg=None, sampler=torch.normal,
+                      surgery=None):
+    """`GaussianModel.densify_and_prune` (scene/gaussian_model.py:580-597) over an optimiser with the reference's eight named groups.
+    stats: dict with STAT_NAMES (accumulators (n, 1), max_radii2D / max_weight (n,)).  Three data-movement passes (clone = append; split =
+    append the children AND drop the parents in one pass; prune) through `surgery` (default: `prune_and_extend_optimizer`, HIP).
+    Returns ({group name: new Parameter}, new stats dict)."""
+    cfg = cfg or DensifyConfig()
+    surgery = surgery or prune_and_extend_optimizer
+    with torch.no_grad():
+        grads = stats["xyz_gradient_accum"] / stats["denom"]
+        grads_abs = stats["xyz_gradient_accum_abs"] / stats["denom_abs"]
+        grads[grads.isnan()] = 0.0
+        grads_abs[grads_abs.isnan()] = 0.0
+        max_radii2D = stats["max_radii2D"].clone()
+        stats = dict(stats)
+
+        def fresh(n):          # densification_postfix (:463-468)
+            dev = grads.device
+            return {k: torch.zeros((n, 1) if k in STAT_NAMES[:4] else (n,), device=dev) for k in STAT_NAMES}
+
+        p = _named(optimizer)
+        sel = select_clone(p, grads, max_grad, extent, cfg)
+        if sel.sum() > 0:
+            p, _ = surgery(optimizer, None, clone_rows(p, sel, sampler))
+            stats = fresh(p["xyz"].shape[0])
+        sel = select_split(p, grads, max_grad, grads_abs, abs_max_grad, extent, max_radii2D, cfg)
+        p, _ = surgery(optimizer, ~sel, split_rows(p, sel, sampler))
+        stats = fresh(p["xyz"].shape[0])
+        mask = select_prune(p, stats["max_radii2D"], min_opacity, extent, max_screen_size)
+        p, extra = surgery(optimizer, ~mask, None, extra=[stats[k] for k in STAT_NAMES])
+        return p, dict(zip(STAT_NAMES, extra))

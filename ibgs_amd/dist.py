@@ -514,6 +514,16 @@ class ShardedOptimizerStep:
         self.last_bytes = 0
         self.state_is_gathered = True          # nothing is sharded before the first step
         self._agree = None
+        for g in optimizer.param_groups:          # the update below is plain Adam from lr / betas / eps (the reference's only use, gaussian_model.py:241)
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                raise NotImplementedError("ShardedOptimizerStep covers Adam without weight_decay / amsgrad / maximize (group %r)" % g.get("name"))
+        # after step() only this rank's rows of exp_avg / exp_avg_sq are current: a state_dict() taken then would save stale moments for the others
+        # (gather_state() is a collective, and checkpoints are often written by rank 0 alone: raise rather than start an all-gather the others never join)
+        if hasattr(optimizer, "register_state_dict_pre_hook"):
+            def _guard(opt, me=self):
+                if not me.state_is_gathered:
+                    raise RuntimeError("ShardedOptimizerStep: the Adam moments are sharded over the ranks; call gather_state() on EVERY rank before optimizer.state_dict()")
+            optimizer.register_state_dict_pre_hook(_guard)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             if dist.get_backend(group) == "gloo":
                 self._agree = group if group is not None else dist.group.WORLD

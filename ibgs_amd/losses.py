@@ -31,7 +31,7 @@ class _L1(torch.autograd.Function):
                 sc = _scratch[key] = torch.empty(lib.ibgs_required_l1(), dtype=torch.uint8, device=x.device)
             # value AND gradient sign(x - y) / N in the one pass over x and y (when a gradient will be asked for): the backward then only has to
             # scale it by the incoming gradient -- and not even that when the term enters the total with weight one
-            grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            grad = torch.empty_like(x) if (ctx.needs_input_grad[0] and torch.is_grad_enabled()) else None          # (needs_input_grad ignores no_grad())
             rc = lib.ibgs_l1_loss(stream, x.numel(), x.data_ptr(), y.data_ptr(), None if grad is None else grad.data_ptr(), loss.data_ptr(), sc.data_ptr(), sc.numel())
         if rc < 0:
             raise RuntimeError("ibgs_l1_loss failed (%d): %s" % (rc, _lib.last_error()))

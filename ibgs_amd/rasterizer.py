@@ -201,8 +201,24 @@ def _tex_packed(device, nbytes, source=None):
 TEX_CACHE = True
 
 
+def _tensor_version(t):
+    """The autograd version counter, or None when the tensor has none to read: inference tensors raise RuntimeError ("Inference tensors do not
+    track version counter"), which `getattr(t, "_version", None)` does not swallow.  None = uncacheable: such a stack is packed on every call."""
+    try:
+        return t._version
+    except (RuntimeError, AttributeError):
+        return None
+
+
+def invalidate_tex_cache():
+    """Forget every cached source-RGBA pack.  The cache notices writes through the version counter only; a write that does not bump it
+    (`src_images.data.copy_(...)`, a raw kernel filling a persistent buffer) must be followed by this call."""
+    for buf in _tex_scratch.values():
+        buf._ibgs_src = None
+
+
 def _tex_cached(device, nbytes, source):
-    if not TEX_CACHE:
+    if not TEX_CACHE or source[1] is None:
         return None
     key = _stream_key(device) + ("tex",)
     buf = _tex_scratch.get(key)
@@ -406,7 +422,7 @@ class _CModule:
                     # the packed RGBA of the sources goes to the per-stream scratch; the ticket lets the backward of this call
                     # skip its own pack when no other geo call used the scratch in between (the training loop's normal case)
                     nbytes = lib.ibgs_required_tex(int(nb_src_images), W, H)
-                    source = (src_images, getattr(src_images, "_version", None), int(nb_src_images), W, H)
+                    source = (src_images, _tensor_version(src_images), int(nb_src_images), W, H)
                     hit = _tex_cached(device, nbytes, source)
                     if hit is not None:
                         tex, _CModule.last_tex = hit
@@ -690,6 +706,9 @@ def rasterize_depth_batch(means3D, opacities, scales, rotations, cov3D_precomp, 
     return depths, radii
 
 
+_EMPTY = torch.Tensor([])          # never written, never returned: the stand-in for "not provided"
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
@@ -728,7 +747,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         # outputs that the loss does not touch arrive as None instead of freshly zero-filled planes
         ctx.set_materialize_grads(False)
-        none = torch.Tensor([])
+        none = _EMPTY
         ctx.save_for_backward(out_normal_map, out_median_intersected_depth, out_warped_image, colors_precomp,
                               all_maps, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               plane_normal if plane_normal is not None else none, plane_offset if plane_offset is not None else none,
@@ -832,18 +851,19 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
+        # the reference's "empty CPU tensor = not provided" (DPR/.../__init__.py:304-316): ONE shared empty tensor instead of up to six fresh ones per call
         if shs is None:
-            shs = torch.Tensor([])
+            shs = _EMPTY
         if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
+            colors_precomp = _EMPTY
         if scales is None:
-            scales = torch.Tensor([])
+            scales = _EMPTY
         if rotations is None:
-            rotations = torch.Tensor([])
+            rotations = _EMPTY
         if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
+            cov3D_precomp = _EMPTY
         if all_map is None:
-            all_map = torch.Tensor([])
+            all_map = _EMPTY
 
         return rasterize_gaussians(means3D, means2D, means2D_abs, shs, colors_precomp, opacities, scales,
                                    rotations, cov3D_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode)

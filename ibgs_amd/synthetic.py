@@ -50,13 +50,9 @@ def look_at_camera(eye, target=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)):
     return R, t
 
 
-def make_camera(W, H, fovx=0.6911, azimuth_deg=0.0, elevation_deg=20.0, radius=4.0, znear=0.01, zfar=100.0):
-    az = math.radians(azimuth_deg); el = math.radians(elevation_deg)
-    eye = radius * np.array([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az), math.sin(el)])
-    R, t = look_at_camera(eye)
-    focal = W / (2.0 * math.tan(fovx / 2.0))
-    fovy = 2.0 * math.atan(H / (2.0 * focal))
-    w2c = world_to_view(R, t)
+def camera_from_pose(W, H, R, t, fovx, fovy, znear=0.01, zfar=100.0):
+    """The matrices `Camera.__init__` derives from a pose (scene/cameras.py:102-105): R camera-to-world rotation, t world-to-camera translation."""
+    w2c = world_to_view(np.asarray(R, np.float64), np.asarray(t, np.float64))
     world_view_transform = np.ascontiguousarray(w2c.T)                       # transposed, cameras.py:102
     proj = projection_matrix(znear, zfar, fovx, fovy)
     full_proj_transform = (world_view_transform @ proj.T).astype(np.float32)  # cameras.py:104
@@ -65,8 +61,17 @@ def make_camera(W, H, fovx=0.6911, azimuth_deg=0.0, elevation_deg=20.0, radius=4
         "W": int(W), "H": int(H), "FoVx": fovx, "FoVy": fovy,
         "tanfovx": math.tan(fovx * 0.5), "tanfovy": math.tan(fovy * 0.5),
         "viewmatrix": world_view_transform, "projmatrix": np.ascontiguousarray(full_proj_transform),
-        "campos": camera_center, "R": R.astype(np.float32), "T": t.astype(np.float32),
+        "campos": camera_center, "R": np.asarray(R, np.float32), "T": np.asarray(t, np.float32),
     }
+
+
+def make_camera(W, H, fovx=0.6911, azimuth_deg=0.0, elevation_deg=20.0, radius=4.0, znear=0.01, zfar=100.0):
+    az = math.radians(azimuth_deg); el = math.radians(elevation_deg)
+    eye = radius * np.array([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az), math.sin(el)])
+    R, t = look_at_camera(eye)
+    focal = W / (2.0 * math.tan(fovx / 2.0))
+    fovy = 2.0 * math.atan(H / (2.0 * focal))
+    return camera_from_pose(W, H, R, t, fovx, fovy, znear, zfar)
 
 
 def quat_to_rotmat(q):

@@ -163,3 +163,44 @@ def test_edge_cases_and_errors():
         densify.compact_append([t], None, [torch.ones(2, 4, device="cuda")])
     with pytest.raises(RuntimeError):
         densify.compact_append([t.cpu()])
+
+
+# ---- against the reference's own densify_and_prune (tests/golden/densify.npz; round 5) ----------------------------------------------------------
+from tests import golden_densify as gd  # noqa: E402
+
+GOLD = gd.load()
+
+
+@pytest.mark.parametrize("tag", gd.RUNS)
+def test_fused_pass_replays_the_reference_surgery_bit_for_bit(tag):
+    """Every `densification_postfix` / `prune_points` call the reference made (scene/gaussian_model.py:397-469), replayed through the fused HIP pass
+    on FusedAdam: parameters, exp_avg, exp_avg_sq, step counts and the per-point statistics end in the reference's state, bit for bit."""
+    opt, stats = gd.build(GOLD, tag, FusedAdam, "cuda")
+    groups = [str(g) for g in GOLD["groups"]]
+    for i, kind in enumerate(str(c) for c in GOLD[tag + "calls"]):
+        if kind == "cat":
+            ext = {n: torch.as_tensor(GOLD["%scall%d_new_%s" % (tag, i, n)], device="cuda") for n in groups}
+            p, _ = densify.prune_and_extend_optimizer(opt, None, ext)
+            n = p["xyz"].shape[0]
+            stats = {k: torch.zeros((n, 1) if k in densify.STAT_NAMES[:4] else (n,), device="cuda") for k in densify.STAT_NAMES}
+        else:
+            keep = ~torch.as_tensor(GOLD["%scall%d_mask" % (tag, i)], device="cuda")
+            p, extra = densify.prune_and_extend_optimizer(opt, keep, None, extra=[stats[k] for k in densify.STAT_NAMES])
+            stats = dict(zip(densify.STAT_NAMES, extra))
+    gd.check_after(GOLD, tag, opt, stats)
+
+
+@pytest.mark.parametrize("tag", gd.RUNS)
+def test_densify_and_prune_on_the_gpu_is_the_reference_s(tag):
+    """The whole `densify.densify_and_prune` on the MI355X (selection in torch-HIP, three fused data-movement passes) fed the reference's normal
+    draws: the reference's decisions (masks, new rows) and the reference's final state."""
+    opt, stats = gd.build(GOLD, tag, FusedAdam, "cuda")
+    log = []
+    a = GOLD["densify_args"]
+    p, new_stats = densify.densify_and_prune(opt, stats, float(a[0]), float(a[1]), float(a[2]), float(a[3]), float(a[4]), cfg=gd.config(GOLD, tag),
+                                             sampler=gd.replay_sampler(GOLD, tag, "cuda"), surgery=gd.logging_surgery(densify.prune_and_extend_optimizer, log))
+    gd.check_decisions(GOLD, tag, log)
+    gd.check_after(GOLD, tag, opt, new_stats, xyz_tol=2e-6)
+    for g in opt.param_groups:          # and the optimiser still steps (FusedAdam on the new Parameters)
+        g["params"][0].grad = torch.ones_like(g["params"][0])
+    opt.step()

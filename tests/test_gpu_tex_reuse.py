@@ -98,3 +98,36 @@ def test_forward_packs_once_per_source_stack():
         rasterizer.TEX_CACHE = old
     for x, y in zip(d, e):
         assert torch.equal(x, y)
+
+
+def test_inference_tensors_and_unversioned_writes():
+    """(a) under `torch.inference_mode()` a tensor has no version counter to read (RuntimeError, not AttributeError) -- such a stack is
+    packed on every call instead of crashing the forward; (b) a write that does not move the counter (`.data.copy_`) is invisible to the cache
+    until `rasterizer.invalidate_tex_cache()` is called (INTEGRATION.md)."""
+    from tests import hipref
+    from tests.scenes import add_sources, scene as mk
+    inp = add_sources(mk(P=1200, W=96, H=64, deg=1, seed=6, opacity="trained", planes=True, scale_mul=1.6), n_src=2, L=4)
+    lv = hipref.leaf_inputs(inp, "cuda", requires_grad=False)
+
+    def fwd(settings):
+        return rasterizer.GaussianRasterizer(settings)(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
+                                                       shs=lv["shs"], scales=lv["scales"], rotations=lv["rotations"], all_map=lv["all_map"])
+    st = hipref.settings_from(inp, "cuda")
+    with torch.no_grad():
+        want = [t.clone() for t in fwd(st)]
+    with torch.inference_mode():
+        st_inf = hipref.settings_from(inp, "cuda")          # created inside: inference tensors
+        w0 = rasterizer._tex_writes[0]
+        a = fwd(st_inf); b = fwd(st_inf)
+        assert rasterizer._tex_writes[0] == w0 + 2, "inference tensors carry no version counter: packed per call"
+        for x, y, z in zip(a, b, want):
+            assert torch.equal(x, y) and torch.equal(x, z)
+    with torch.no_grad():
+        fwd(st)
+        w0 = rasterizer._tex_writes[0]
+        st.src_images.data.copy_(st.src_images * 0.5)          # no version bump: the cache cannot see it ...
+        stale = fwd(st)
+        assert rasterizer._tex_writes[0] == w0 and torch.equal(stale[5], want[5])
+        rasterizer.invalidate_tex_cache()                      # ... until told
+        fresh = fwd(st)
+        assert rasterizer._tex_writes[0] == w0 + 1 and not torch.equal(fresh[5], want[5])
