@@ -166,7 +166,7 @@ class Workload:
     CLUSTER = 0.0          # defaults of the scene shape (--cluster / --anisotropy / --scale-sigma); a Workload may be given its own
     ANISOTROPY = None
     SCALE_SIGMA = 0.0
-    torch_l1 = False
+    torch_l1 = True          # the loss of every timed step is the reference's own expression (utils/loss_utils.py:23-24); the one-pass fused L1 is an extra key
 
     def __init__(self, cfg, view, dev, opacity, geo, forward_only, target_seed, cluster=None, anisotropy="default", scale_sigma=None):
         c = syn.CONFIGS[cfg]
@@ -249,12 +249,11 @@ class Workload:
         for v in self.leaves.values():
             v.grad = None
         outs = self._call()
-        if self.torch_l1:
-            loss = torch.abs(outs[0] - self.target).mean()          # utils/loss_utils.py:23-24 as the reference writes it
-        else:
-            loss = l1_loss(outs[0], self.target)      # the same value and gradient in one pass each (ibgs_amd.losses)
+        # utils/loss_utils.py:23-24 as the reference writes it, or the same value and gradient in one pass each (ibgs_amd.losses; SURVEY section 2: out of scope)
+        l1 = (lambda x, y: torch.abs(x - y).mean()) if self.torch_l1 else l1_loss
+        loss = l1(outs[0], self.target)
         if self.geo:   # every differentiable geo output takes part: normal map, median depth, warped source colours
-            loss = loss + l1_loss(outs[2], self.geo_targets[0]) + l1_loss(outs[3], self.geo_targets[1]) + l1_loss(outs[5], self.geo_targets[2])
+            loss = loss + l1(outs[2], self.geo_targets[0]) + l1(outs[3], self.geo_targets[1]) + l1(outs[5], self.geo_targets[2])
         self.R = outs[0].grad_fn.num_rendered
         if backward is None:
             loss.backward()
@@ -274,7 +273,7 @@ class Workload:
             + ((", anisotropy=%s" % self.anisotropy) if self.anisotropy else "") \
             + ((", log-normal sizes sigma=%g" % self.scale_sigma) if self.scale_sigma > 0 else "")
         return "%s: %d random-init Gaussians, %dx%d, SH degree %d, rasterizer %s, opacity=%s%s, one view per GPU%s" % (
-            self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target (ibgs_amd.losses.l1_loss: value + gradient in one pass)",
+            self.cfg, self.P, self.W, self.H, c["sh_degree"], "forward only" if self.forward_only else "fwd+bwd, L1 loss vs fixed random target (torch: abs().mean(), the reference's utils/loss_utils.py:23-24)",
             opacity + shape,
             ", render_geo n_src=4 L=4" if self.geo else "", (", RCCL gradient exchange (%s)" % exchange) if world > 1 else "")
 
@@ -349,7 +348,22 @@ def measure(wl, step, steps, warmup, world, n_stage_steps=3, n_fwd=10):
             "kernel_ms": tm[kstage][0] / max(tm[kstage][1], 1), "fwd_ms": fwd_ms, "stages": stages}
 
 
-def roofline(wl, m, workload_tag):
+def walked_entries(wl):
+    """List entries the blend kernels really visit in one pass of `wl`: per tile, how far the forward walked its list (the largest contributor index of any
+    pixel; one word per wave of the tile in the image arena -- ImgState::tile_walked, the words the backward orders its launch by)."""
+    for v in wl.leaves.values():
+        v.grad = None
+    out = wl._call()[0]
+    img = out.grad_fn.saved_tensors[-1]
+    lib = _lib.load()
+    tiles = ((wl.W + 15) // 16) * ((wl.H + 15) // 16)
+    off, moff = lib.ibgs_img_offset(wl.W, wl.H, b"tile_walked"), lib.ibgs_img_offset(wl.W, wl.H, b"meta")
+    ipt = int(img[moff:moff + 128].view(torch.int32)[10].item())          # waves per tile of the forward variant that ran: the words lie at [tile * ipt + wave]
+    tw = img[off:off + tiles * ipt * 4].view(torch.int32).view(tiles, ipt)
+    return int(tw.max(dim=1).values.to(torch.int64).sum().item())
+
+
+def roofline(wl, m, workload_tag, walked=None):
     """Roofline object of the dominant kernel.  The blend kernels are VALU-issue bound: `bound` says so and
     `valu` holds the issue-rate fraction; achieved / peak / frac stay the HBM figures of SURVEY 8(d) (algorithmic bytes of
     that launch / its live hipEvent duration / 8 TB/s)."""
@@ -374,12 +388,28 @@ def roofline(wl, m, workload_tag):
         if "SQ_INSTS_VALU_MFMA_MOPS_F32" in ctr or "SQ_VALU_MFMA_BUSY_CYCLES" in ctr:
             mfma = {"busy_cycles": ctr.get("SQ_VALU_MFMA_BUSY_CYCLES"), "mops_f32": ctr.get("SQ_INSTS_VALU_MFMA_MOPS_F32"), "source": src}
     step_bytes = b_fwd if wl.forward_only else b_fwd + b_bwd
-    return {"bound": "valu", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": src if traffic is not None else None,
-            "algorithmic_bytes_per_launch": kbytes, "kernel_ms": k_ms,
-            "valu": valu, "valu_note": None if valu is not None else src,
-            "mfma_utilisation": 0.0 if mfma is None else mfma,   # no kernel of this path is a dense contraction (DESIGN.md "MFMA", measured probe)
-            "step_algorithmic_bytes": step_bytes, "step_frac": step_bytes / (m["ms_step"] * 1e-3) / HBM_PEAK}
+    rf = {"bound": "valu", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": src if traffic is not None else None,
+          "algorithmic_bytes_per_launch": kbytes, "kernel_ms": k_ms,
+          "valu": valu, "valu_note": None if valu is not None else src,
+          "mfma_utilisation": 0.0 if mfma is None else mfma,   # no kernel of this path is a dense contraction (DESIGN.md "MFMA", measured probe)
+          "step_algorithmic_bytes": step_bytes, "step_frac": step_bytes / (m["ms_step"] * 1e-3) / HBM_PEAK}
+    # ... beside the fraction on the bytes the PMC passes saw the whole step move (SURVEY's model credits an R-sized 64-bit sort this design does not run)
+    stm = None if wl.forward_only else step_traffic_measured(workload_tag)
+    rf["step_frac_measured"] = None if stm is None else stm["bytes_per_step"] / (m["ms_step"] * 1e-3) / HBM_PEAK
+    rf["step_traffic_measured"] = stm
+    if walked is not None and k_ms > 0:
+        # SURVEY's R x 40 (+ 20 geo) B charges every list entry; the blend walks a list only until its pixels are opaque (trained scenes: ~10 % of the
+        # entries).  `walked` = the entries the kernel really visits (sum over tiles of how far the forward walked the list: ImgState::tile_walked).  The
+        # kernel's fraction is quoted on max(bytes of the walked entries, bytes the counters saw); the SURVEY-model figure keeps its own name.
+        per_entry = 40 + (20 if wl.geo else 0)
+        wbytes = kbytes - (R - walked) * per_entry
+        best = max(wbytes, traffic or 0.0)
+        rf.update({"walked_entries": int(walked), "walked_fraction_of_R": walked / max(R, 1), "walked_bytes_per_launch": wbytes,
+                   "survey_model": {"achieved": achieved, "frac": achieved * 1e9 / HBM_PEAK, "bytes_per_launch": kbytes},
+                   "achieved": best / (k_ms * 1e-3) / 1e9, "frac": best / (k_ms * 1e-3) / HBM_PEAK,
+                   "frac_basis": "measured traffic" if (traffic or 0.0) >= wbytes else "walked entries"})
+    return rf
 
 
 def cpu_baseline(inp, c):
@@ -472,6 +502,139 @@ def test_frame(dev, c):
         ms = (time.perf_counter() - t0) / n * 1e3
     return {"ms_per_frame": ms, "fps": 1000.0 / ms,
             "workload": "%d Gaussians, %dx%d: 4 source depth maps in one batched depth-only pass + the main render_geo pass (n_src 4, L 4), learnt normals, no gradients" % (P, W, H)}
+
+
+def gpu_kernel_sum_ms(fn, n):
+    """Sum of the durations of EVERY kernel and copy the GPU ran during `n` calls of `fn` (the library's and torch's), per call: torch.profiler's device
+    events (roctracer).  What a step would take if the host never made the GPU wait.  None when the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+        tot = 0.0
+        for e in prof.events():
+            if e.device_type == torch.autograd.DeviceType.CUDA:
+                tot += float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0))
+        return tot / n * 1e-3 if tot > 0 else None
+    except Exception as ex:   # noqa: BLE001
+        sys.stderr.write("bench.py: torch.profiler unavailable (%s): no kernel sums\n" % ex)
+        return None
+
+
+def timed_wall_ms(fn, n, warmup=5):
+    for _ in range(warmup):
+        fn()
+    fence(1); t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    fence(1)
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def small_frame(dev, steps):
+    """A frame below the size at which the step is the GPU's alone: 1 M trained-opacity Gaussians at 1280 x 720 (3 600 tiles, the hybrid
+    kernels' range), colour pass forward + L1 + backward: wall clock per step against the sum of its kernels -- the difference is what host / launch
+    overhead and the wait for R still expose.  Extra key; never `value`."""
+    wl = Workload("C3_720p", 0, dev, "trained", False, False, 1234)
+    wall = timed_wall_ms(wl.local_step, steps, warmup=10)
+    ksum = gpu_kernel_sum_ms(wl.local_step, 5)
+    _lib.timing_enable(_lib.STAGES)
+    for _ in range(3):
+        wl.local_step()
+    torch.cuda.synchronize()
+    stages = {k: v[0] / 3.0 for k, v in _lib.timing_collect().items()}
+    _lib.timing_enable([])
+    c = wl.c
+    return {"workload": "%d trained-opacity Gaussians, %dx%d, SH degree %d, colour pass fwd + L1 (torch) + bwd" % (c["P"], c["W"], c["H"], c["sh_degree"]),
+            "steps": steps, "ms_per_step": wall, "kernel_sum_ms": ksum, "host_exposed_ms": None if ksum is None else max(0.0, wall - ksum),
+            "num_rendered": int(wl.R), "stages_ms": stages}
+
+
+class TrainIteration:
+    """ONE iteration as the reference's trainer runs it in steady state (train.py:287-430), at C3 size on the `trained_geo` scene: `renderer.render(
+    render_geo=True, return_depth_normal=True)` through the fused plane glue with 4 cached source depths, L1 against the view's image, backward, the depth
+    cache write (:298-299), the densification statistics (:400-405; written without the reference's boolean-index host syncs), `optimizer.step()` +
+    `zero_grad` (:421-424), cameras round-robin."""
+    ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation",
+            "normal": "_normal", "offset": "_offset"}
+    LRS = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20.0, "opacity": 2.5e-2, "scaling": 5e-3, "rotation": 1e-3, "normal": 1e-3, "offset": 1.6e-5}   # arguments/__init__.py:90-98
+
+    def __init__(self, dev, c, opt_cls):
+        from ibgs_amd import renderer, simple_scene
+        self.renderer = renderer
+        P, W, H = c["P"], c["W"], c["H"]
+        self.P, self.dev = P, dev
+        g = syn.make_gaussians(P, c["seed"], sh_degree=3, max_coeffs=16, opacity="trained", anisotropy="plane", scale_sigma=1.0, cluster=0.3)
+        rng = np.random.default_rng(0)
+        g["normal"] = rng.normal(size=(P, 3)).astype(np.float32); g["offset"] = (0.01 * rng.normal(size=(P, 1))).astype(np.float32)
+        self.cams = simple_scene.orbit_cameras(W, H, n_views=8, device=dev, nearest=4)
+        self.scene = simple_scene.SimpleScene(self.cams, images=torch.rand(8, 3, H, W, device=dev), device=dev)
+        self.pipe, self.args = simple_scene.default_pipe(), simple_scene.default_args()
+        self.bg = torch.zeros(3, device=dev)
+        self.pc = simple_scene.SimpleGaussians(g, sh_degree=3, device=dev)
+        self.opt = opt_cls([{"params": [getattr(self.pc, self.ATTR[k])], "lr": lr, "name": k} for k, lr in self.LRS.items()], lr=0.0, eps=1e-15)   # gaussian_model.py:227-241
+        with torch.no_grad():
+            self.scene.rendered_depth_list = renderer.render_depth_batch(self.cams, self.pc, self.scene, self.pipe, self.args, self.bg, True, 4, 4)
+        self.st = {"accum": torch.zeros(P, 1, device=dev), "accum_abs": torch.zeros(P, 1, device=dev), "denom": torch.zeros(P, 1, device=dev),
+                   "max_radii2D": torch.zeros(P, device=dev)}
+        self.it = 0
+
+    def __call__(self):
+        k = self.it % 8
+        self.it += 1
+        st, scene = self.st, self.scene
+        out = self.renderer.render(self.cams[k], self.pc, scene, self.pipe, self.args, self.bg, True, 4, 4, render_geo=True, return_depth_normal=True)
+        loss = torch.abs(out["render"] - scene.original_image_list[k]).mean()
+        loss.backward()
+        with torch.no_grad():
+            scene.rendered_depth_list[k] = out["median_intersected_depth"].detach()
+            vis = out["visibility_filter"]
+            st["max_radii2D"] = torch.where(vis, torch.max(st["max_radii2D"], out["radii"].float()), st["max_radii2D"])
+            v = vis.unsqueeze(1)
+            st["accum"] += torch.where(v, torch.norm(out["viewspace_points"].grad[:, :2], dim=-1, keepdim=True), 0.0)
+            st["accum_abs"] += torch.where(v, torch.norm(out["viewspace_points_abs"].grad[:, :2], dim=-1, keepdim=True), 0.0)
+            st["denom"] += v
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+
+    def densify_pass(self, keep):
+        """The every-100th pass (:407-410): prune the rows outside `keep`, append as many (P stays what it was): all parameters, both Adam moments, the statistics."""
+        from ibgs_amd import densify
+        st = self.st
+        n_app = self.P - int(keep.sum().item())
+        ext = {gr["name"]: gr["params"][0].detach()[:n_app].clone() for gr in self.opt.param_groups}
+        new, extra = densify.prune_and_extend_optimizer(self.opt, keep, ext, extra=[st["accum"], st["accum_abs"], st["denom"], st["max_radii2D"]])
+        for kname, a_ in self.ATTR.items():
+            setattr(self.pc, a_, new[kname])
+        st["accum"], st["accum_abs"], st["denom"], st["max_radii2D"] = extra
+
+
+def train_iter(dev, c, steps):
+    """`TrainIteration` timed: wall clock per iteration against the sum of its kernels (the library's and torch's), with FusedAdam and with the reference's
+    torch.optim.Adam; and one `compact_append` pass (1 % of the points pruned, as many appended) as the trainer runs it every 100th iteration.  Never `value`."""
+    from ibgs_amd.optim import FusedAdam
+    res = {}
+    for name, opt_cls in (("fused_adam", FusedAdam), ("torch_adam", torch.optim.Adam)):
+        ti = TrainIteration(dev, c, opt_cls)
+        wall = timed_wall_ms(ti, steps, warmup=10)
+        ksum = gpu_kernel_sum_ms(ti, 4)
+        res[name] = {"ms_per_iter": wall, "kernel_sum_ms": ksum, "host_exposed_ms": None if ksum is None else max(0.0, wall - ksum)}
+        if opt_cls is FusedAdam:
+            keep = torch.rand(ti.P, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) > 0.01
+            ti.densify_pass(keep); fence(1)
+            t0 = time.perf_counter(); ti.densify_pass(keep); fence(1)
+            res["densify_pass_ms"] = (time.perf_counter() - t0) * 1e3
+            ti(); fence(1)          # the iteration still runs on the new Parameters
+        del ti
+        torch.cuda.empty_cache()
+    res["ms_per_iter_incl_densify_every_100"] = res["fused_adam"]["ms_per_iter"] + res["densify_pass_ms"] / 100.0
+    res["workload"] = ("%d trained plane-like Gaussians (30 %% in one blob, log-normal sizes), %dx%d, SH 3: renderer.render(render_geo, fused plane map, 4 cached sources, L 4, "
+                       "depth normal) + L1 + backward + depth cache + densification statistics + optimizer.step(), 8 cameras round-robin" % (c["P"], c["W"], c["H"]))
+    res["steps"] = steps
+    return res
 
 
 def self_launch(a, argv):
@@ -622,17 +785,17 @@ def main():
     skip = set(filter(None, os.environ.get("IBGS_BENCH_SKIP", "").split(",")))          # diagnostics: leave named extras out (torch_l1, abs, hint, impl, hop)
     if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
         from ibgs_amd import rasterizer as _r
-        # (e) the same step with the reference's own L1 expression (six small torch kernels) instead of the one-pass loss: what part of
-        # the step time is the rasterizer's and what the loss's
-        Workload.torch_l1 = "torch_l1" not in skip
+        # (e) the same step with the one-pass fused L1 (ibgs_amd.losses: value + gradient in one kernel each) instead of the reference's expression (six
+        # small torch kernels): what the out-of-scope loss costs the step.  Never `value` (round 5: until round 4 the fused loss WAS the timed step's)
+        Workload.torch_l1 = "fused_l1" in skip
         for _ in range(3):
             wl.local_step()
         fence(1); t0 = time.perf_counter()
         for _ in range(a.steps):
             wl.local_step()
         fence(1)
-        extras["ms_per_step_with_torch_l1"] = (time.perf_counter() - t0) / a.steps * 1e3
-        Workload.torch_l1 = False
+        extras["ms_per_step_with_fused_l1"] = (time.perf_counter() - t0) / a.steps * 1e3
+        Workload.torch_l1 = True
         # (f) the same step when nobody asks for the densification statistic |dL/dmean2D| (means2D_abs without requires_grad: after densify_until_iter,
         # train.py:400-410, and at test time): IBGS_FLAG_NO_ABS_GRAD, the colour blend skips the two |.| moments.  Never `value`.
         wl.leaves["means2D_abs"].requires_grad_("abs" in skip)
@@ -687,7 +850,7 @@ def main():
 
     def geo_object(gwl, opacity, gsteps):
         gm = measure(gwl, gwl.local_step, gsteps, 10, 1, n_fwd=5)
-        grf = roofline(gwl, gm, workload_tag(a.config, True, False, opacity, gwl.cluster, gwl.anisotropy, gwl.scale_sigma))
+        grf = roofline(gwl, gm, workload_tag(a.config, True, False, opacity, gwl.cluster, gwl.anisotropy, gwl.scale_sigma), walked=walked_entries(gwl))
         with torch.no_grad():
             radii = gwl._call()[1]
             big = int((radii > 128).sum().item()); vis = int((radii > 0).sum().item())
@@ -715,6 +878,10 @@ def main():
 
     if world == 1 and not (a.geo or a.forward_only) and not a.no_extras:
         extras["test_frame"] = test_frame(dev, wl.c)
+        if "small_frame" not in skip:
+            extras["small_frame"] = small_frame(dev, max(10, min(30, a.steps)))
+        if "train_iter" not in skip and a.config == "C3":
+            extras["train_iter"] = train_iter(dev, wl.c, max(8, min(16, a.steps)))
     if rank == 0:
         rf = roofline(wl, m, workload_tag(a.config, a.geo, a.forward_only, a.opacity, a.cluster, a.anisotropy, a.scale_sigma))
         out = {
