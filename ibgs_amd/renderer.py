@@ -244,6 +244,48 @@ def find_closest_frames(viewpoint_camera, scene, args):
     return np.array(order)
 
 
+# What render() derives from the scene's per-view tables for a (reference camera, chosen sources) pair does not change while the tables do not: the
+# stack of source images (4 x 3 x H x W: a 100 MB copy per call at 1080p, and a NEW tensor object each time -- which also defeats the rasterizer's
+# one-pack-per-source-stack cache, rasterizer.TEX_CACHE: +1 pack kernel) and the pose algebra (two LU inversions through rocSOLVER: ~15 small kernels).  Both
+# are kept per (tables' identity + version counters, camera matrix identity + version, chosen indices); an in-place write to a table moves its version
+# counter and drops the entry.  Same tensors, same arithmetic -- computed once.  SOURCE_CACHE_BYTES bounds the image stacks kept (least recently used first out).
+SOURCE_CACHE_BYTES = 8 << 30
+_src_cache = {}          # key -> [stacked images, ref_to_src_list, src_cam_pos]
+
+
+def _version(t):
+    try:
+        return t._version
+    except (RuntimeError, AttributeError):
+        return None
+
+
+def _cached_sources(scene, viewpoint_camera, chosen, dev):
+    imgs, w2s_all, V = scene.original_image_list, scene.world_view_transforms, viewpoint_camera.world_view_transform
+    vers = (_version(imgs), _version(w2s_all), _version(V))
+    if None in vers:          # inference tensors: nothing to key on
+        return None, None
+    key = (id(imgs), id(w2s_all), id(V), tuple(int(i) for i in chosen), str(dev))
+    ent = _src_cache.get(key)
+    if ent is not None and ent[0] == vers and ent[1][0] is imgs and ent[1][1] is w2s_all and ent[1][2] is V:
+        _src_cache[key] = _src_cache.pop(key)          # most recently used last
+        return ent, key
+    return None, key
+
+
+def _remember_sources(key, scene, viewpoint_camera, src_images, ref_to_src_list, src_cam_pos):
+    if key is None:
+        return
+    imgs, w2s_all, V = scene.original_image_list, scene.world_view_transforms, viewpoint_camera.world_view_transform
+    _src_cache.pop(key, None)
+    _src_cache[key] = [(_version(imgs), _version(w2s_all), _version(V)), (imgs, w2s_all, V), src_images, ref_to_src_list, src_cam_pos]
+    total = sum(e[2].numel() * e[2].element_size() for e in _src_cache.values())
+    while total > SOURCE_CACHE_BYTES and len(_src_cache) > 1:
+        k0 = next(iter(_src_cache))
+        e = _src_cache.pop(k0)
+        total -= e[2].numel() * e[2].element_size()
+
+
 def _rows(t, idx):
     """t[idx] for a short Python list of indices WITHOUT letting torch build the index tensor on the host: that is a pageable host-to-device
     copy, i.e. a wait for everything queued on the stream (the previous pass's render), after which the glue's small kernels run one by one on
@@ -274,7 +316,8 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
                 chosen = random.sample(list(nearest), nb_src_frames)
             else:
                 chosen = list(nearest[:nb_src_frames])
-            src_images = _rows(scene.original_image_list, chosen)
+            cached, ckey = _cached_sources(scene, viewpoint_camera, chosen, dev)
+            src_images = cached[2] if cached is not None else _rows(scene.original_image_list, chosen)
             if do_render_src_depth:
                 # the reference loops render_depth over the sources (:245-253); here they share ONE rasterizer pass
                 src_rendered_depths = render_depth_batch([scene.getTrainCameras()[i] for i in chosen], pc, scene, pipe, args, bg_color,
@@ -282,15 +325,19 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
                                                          scaling_modifier, override_color)
             else:
                 src_rendered_depths = _rows(scene.rendered_depth_list, chosen)
-            world_to_src = _rows(scene.world_view_transforms, chosen).to(dev)
-            # (torch.inverse looks at its `info` result on the host, i.e. waits for the whole queue -- here the batched depth pass -- in the middle of
-            # the frame, and the GPU then idles while the main pass is being queued; inv_ex is the same LU without that look)
-            src_to_world = torch.linalg.inv_ex(world_to_src).inverse
-            ref_to_world = torch.linalg.inv_ex(viewpoint_camera.world_view_transform.T.to(dev)).inverse
-            ref_to_src_list = world_to_src @ ref_to_world.unsqueeze(0)
-            src_cam_pos = src_to_world[:, :3, 3].contiguous()
+            if cached is not None:
+                ref_to_src_list, src_cam_pos = cached[3], cached[4]
+            else:
+                world_to_src = _rows(scene.world_view_transforms, chosen).to(dev)
+                # (torch.inverse looks at its `info` result on the host, i.e. waits for the whole queue -- here the batched depth pass -- in the middle of
+                # the frame, and the GPU then idles while the main pass is being queued; inv_ex is the same LU without that look)
+                src_to_world = torch.linalg.inv_ex(world_to_src).inverse
+                ref_to_world = torch.linalg.inv_ex(viewpoint_camera.world_view_transform.T.to(dev)).inverse
+                ref_to_src_list = world_to_src @ ref_to_world.unsqueeze(0)
+                src_cam_pos = src_to_world[:, :3, 3].contiguous()
+                src_images = src_images.to(dev)
+                _remember_sources(ckey, scene, viewpoint_camera, src_images, ref_to_src_list, src_cam_pos)
             src_rendered_depths = src_rendered_depths.to(dev)
-            src_images = src_images.to(dev)
     else:
         nb_src_frames, ref_to_src_list, src_images, src_rendered_depths, src_cam_pos = _no_sources(viewpoint_camera, dev)
 

@@ -218,3 +218,41 @@ def test_c2_and_the_trained_scene_against_the_reference_lists():
     full = oracle.forward(inp, cull=False)
     assert full["num_rendered"] > 1.8 * ref["num_rendered"]
     assert np.array_equal(outs["radii"].cpu().numpy(), full["radii"]) and np.array_equal(full["color"], ref["color"]) and l1(col, full["color"]) < 1e-6
+
+
+def test_render_keeps_source_stacks_and_poses_per_camera():
+    """renderer.render() builds the stack of source images and the ref->src pose algebra once per (camera, sources) while the scene's tables are
+    unchanged: the same tensor objects reach the rasterizer again (whose one-pack-per-stack cache then holds too), results identical; an in-place write
+    to the image table drops the entry."""
+    from ibgs_amd import rasterizer
+    dev, g, pc, cams, scene = _setup()
+    pipe, args = simple_scene.default_pipe(), simple_scene.default_args()
+    bg = torch.tensor([0.1, 0.1, 0.2], device=dev)
+    seen = []
+    real = renderer.GaussianRasterizer
+
+    class Spy(real):
+        def __init__(self, raster_settings):
+            seen.append(raster_settings)
+            super().__init__(raster_settings)
+    renderer.GaussianRasterizer = Spy
+    try:
+        with torch.no_grad():
+            call = lambda: renderer.render(cams[0], pc, scene, pipe, args, bg, True, 3, 4, render_geo=True, return_depth_normal=False)
+            a = call()
+            w0 = rasterizer._tex_writes[0]
+            b = call()
+            assert seen[-1].src_images is seen[-2].src_images and seen[-1].ref_to_src_list is seen[-2].ref_to_src_list and seen[-1].src_cam_pos is seen[-2].src_cam_pos
+            assert rasterizer._tex_writes[0] == w0, "the same stack object: no second RGBA pack"
+            for k in ("render", "warped_image", "cam_feat", "median_intersected_depth"):
+                assert torch.equal(a[k], b[k]), k
+            want = torch.stack([scene.original_image_list[j] for j in cams[0].nearest_id[:3]])
+            assert torch.equal(seen[-1].src_images, want)
+            scene.original_image_list[cams[0].nearest_id[0]].mul_(0.5)          # versioned in-place write to the table: rebuilt, repacked
+            c = call()
+            assert seen[-1].src_images is not seen[-2].src_images and rasterizer._tex_writes[0] == w0 + 1
+            assert not torch.equal(c["warped_image"], a["warped_image"]) and torch.equal(c["render"], a["render"])
+            d = renderer.render(cams[1], pc, scene, pipe, args, bg, True, 3, 4, render_geo=True, return_depth_normal=False)          # another camera: its own entry
+            assert seen[-1].src_images is not seen[-2].src_images and d["render"].shape == a["render"].shape
+    finally:
+        renderer.GaussianRasterizer = real
