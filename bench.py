@@ -779,7 +779,10 @@ def main():
                 # host time of the agreement round trip (the GPU keeps running the backward meanwhile), how often it ran, and how many
                 # parameter gradients still had to be copied into the flat bucket (0 = the backward wrote them there itself)
                 "agree_every": a.agree_every, "agree_host_ms": reducer.last_agree_ms, "agreements": reducer.n_agreements,
-                "grads_copied_into_bucket": reducer.last_packed}
+                "grads_copied_into_bucket": reducer.last_packed,
+                # where in the step the collectives can start: render_bwd leaves per-Gaussian MOMENT rows (16 floats), not gradients -- dL/dmeans3D, dL/dscales,
+                # dL/drotations, dL/dopacity and the clamp-masked dL/dRGB factors all come out of preprocess_bwd (~0.09 ms at 1 M Gaussians), so nothing is final before it
+                "exchange_start_after": "preprocess_bwd"}
 
     extras = {}
     skip = set(filter(None, os.environ.get("IBGS_BENCH_SKIP", "").split(",")))          # diagnostics: leave named extras out (torch_l1, abs, hint, impl, hop)

@@ -454,8 +454,9 @@ def assert_replicas_identical(tensors, group=None, what="parameters"):
 #   4. ALL-GATHER of the updated rows: every rank holds the full, identical parameters again.
 # The optimiser's state tensors stay full-sized (the reference's densification surgery on them keeps working: scene/gaussian_model.py:
 # 377-463) but only a rank's own rows are current: call gather_state() before densify_and_prune, before a checkpoint, and whenever the
-# row ranges change.  Same sums as ViewParallelReducer + a replicated step; with two ranks bit-identical (a + b = b + a), with more ranks
-# up to the summation order of the backend's reduce-scatter.
+# row ranges change.  Same sums as ViewParallelReducer + a replicated step.  Every row's sum is formed on ONE rank (its owner) and travels to the
+# others as bits, so the replicas are identical by construction at any world size; with `ordered` (default) that sum is also formed in rank order,
+# i.e. it equals a single process accumulating the N views one after the other, bit for bit.
 def _rows(P, world, rank):
     chunk = (P + world - 1) // world
     return chunk, min(P, rank * chunk), min(P, (rank + 1) * chunk)
@@ -507,8 +508,14 @@ class ShardedOptimizerStep:
     Every parameter of `optimizer` must be a per-Gaussian tensor (first dimension P); `sh` names the SH leaves whose gradient arrives
     factored (rasterizer.capture_sh_factors), `means3D` the positions.  `expand` / `adam` replace the HIP kernels in the CPU tests."""
 
-    def __init__(self, optimizer, sh=None, means3D=None, group=None, expand=None, adam=None):
+    def __init__(self, optimizer, sh=None, means3D=None, group=None, expand=None, adam=None, ordered=True):
+        """ordered (default): the dense gradients travel by ALL-TO-ALL -- every rank sends each owner its block of rows, point to point -- and the
+        owner adds the N blocks IN RANK ORDER: ((g0 + g1) + g2) + ..., the order of a single process accumulating the views one after the other,
+        whatever the backend and however many ranks (round 5; bit-identical to that sequential sum at any world size, tests/test_dist_gloo.py at
+        world 4).  Same bytes on the wire as a reduce-scatter, and on the xGMI full mesh the pattern SURVEY 8(e) asks for (7 concurrent
+        point-to-point transfers per rank instead of a ring).  ordered=False: the backend's reduce_scatter_tensor and its summation order."""
         self.opt, self._sh, self._means3D, self.group = optimizer, sh, means3D, group
+        self.ordered = bool(ordered)
         self._expand, self._adam = expand, (adam or _fused_adam_rows)
         self.items = None
         self.last_bytes = 0
@@ -604,8 +611,15 @@ class ShardedOptimizerStep:
                 src = flat
             else:
                 src = torch.zeros(chunk * world, k, dtype=flat.dtype, device=flat.device); src[:P] = flat
-            out = torch.empty(chunk, k, dtype=flat.dtype, device=flat.device)
-            dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group)
+            if self.ordered:
+                recv = torch.empty(world, chunk, k, dtype=flat.dtype, device=flat.device)
+                dist.all_to_all_single(recv.view(-1), src.view(-1), group=self.group)          # recv[q] = rank q's gradient of MY rows
+                out = recv[0]
+                for q in range(1, world):          # rank order: the sum a single process would form view by view
+                    out += recv[q]
+            else:
+                out = torch.empty(chunk, k, dtype=flat.dtype, device=flat.device)
+                dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group)
             self.last_bytes += out.numel() * 4 * (world - 1)
             return out[:n]
 

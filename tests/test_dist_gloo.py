@@ -415,3 +415,73 @@ def test_sharded_optimizer_step_equals_the_replicated_step(tmp_path):
         assert res[0][P]["rows"][1] == res[1][P]["rows"][0] and res[1][P]["rows"][1] == P
     # rank 1 captured a view (and has no SH leaf for it), rank 0 none: rank 1 reports its local error, rank 0 raises too instead of waiting in a collective
     assert "sh` leaves hold 0 coefficients" in res[1]["bad"] and "another rank failed its local checks" in res[0]["bad"], [r["bad"] for r in res]
+
+
+# ---- round 5: world 4 -- the sharded step equals ONE process accumulating the four ranks' views in rank order, bit for bit ----------------------
+def _worker_sharded4(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init_from_env(backend="gloo")
+    out = {}
+    M, deg = 16, 3
+    for P in (64, 67):          # rows divide evenly over the four ranks / they do not
+        def fresh():
+            g = torch.Generator().manual_seed(9)
+            return {"xyz": torch.randn(P, 3, generator=g).requires_grad_(True), "f_dc": torch.randn(P, 1, 3, generator=g).requires_grad_(True),
+                    "f_rest": torch.randn(P, M - 1, 3, generator=g).requires_grad_(True), "opa": torch.rand(P, 1, generator=g).requires_grad_(True)}
+
+        def groups(s):
+            return [{"params": [s["xyz"]], "lr": 1e-2, "name": "xyz"}, {"params": [s["f_dc"]], "lr": 3e-3, "name": "f_dc"},
+                    {"params": [s["f_rest"]], "lr": 2e-4, "name": "f_rest"}, {"params": [s["opa"]], "lr": 5e-2, "name": "opacity"}]
+        A, S = fresh(), fresh()          # A: the sharded step over 4 ranks; S: ONE process that sees every rank's views, in rank order
+        optA = torch.optim.Adam(groups(A), lr=0.0, eps=1e-15); optS = torch.optim.Adam(groups(S), lr=0.0, eps=1e-15)
+        sh = vdist.ShardedOptimizerStep(optA, sh=[A["f_dc"], A["f_rest"]], means3D=A["xyz"], expand=_expand_ref, adam=_adam_ref)
+        gens = [torch.Generator().manual_seed(300 + r) for r in range(world)]          # every worker can replay every rank's random stream
+        for step in range(3):
+            per_rank = []
+            for r in range(world):
+                gr = gens[r]
+                views = [{"dcolor": torch.randn(P, 3, generator=gr), "campos": torch.randn(3, generator=gr) * 4.0, "degree": deg, "M": M} for _ in range(2)]
+                per_rank.append((views, torch.randn(P, 3, generator=gr), torch.randn(P, 1, generator=gr)))
+            views, gx, go = per_rank[rank]
+            with sh.capture() as sink:
+                for it in views:
+                    sink.append(dict(it))
+            A["xyz"].grad = gx.clone(); A["opa"].grad = go.clone()
+            sh.step()
+            # the single process: gradients added view by view, rank 0's first
+            gx_s, go_s = per_rank[0][1].clone(), per_rank[0][2].clone()
+            for r in range(1, world):
+                gx_s += per_rank[r][1]; go_s += per_rank[r][2]
+            all_views = [it for r in range(world) for it in per_rank[r][0]]
+            g_sh = _expand_ref(S["xyz"].detach(), torch.stack([it["campos"] for it in all_views]), torch.stack([it["dcolor"] for it in all_views]), deg, M)
+            grads = {"xyz": gx_s, "f_dc": g_sh[:, :1].contiguous(), "f_rest": g_sh[:, 1:].contiguous(), "opa": go_s}
+            entries = []
+            for gdict in optS.param_groups:
+                p = gdict["params"][0]
+                st = optS.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0); st["exp_avg"] = torch.zeros_like(p); st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                key = [k for k, v in S.items() if v is p][0]
+                entries.append({"param": p.data, "grad": grads[key], "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"], "lr": gdict["lr"],
+                                "betas": gdict["betas"], "eps": gdict["eps"], "step": float(st["step"])})
+            _adam_ref(entries)
+        sh.gather_state()
+        out[P] = {"A": {k: v.detach().clone() for k, v in A.items()}, "S": {k: v.detach().clone() for k, v in S.items()},
+                  "mA": {k: optA.state[A[k]]["exp_avg"].clone() for k in A}, "mS": {k: optS.state[S[k]]["exp_avg"].clone() for k in S}}
+    torch.save(out, os.path.join(out_dir, "q%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_at_world_4_equals_one_process_accumulating_in_rank_order(tmp_path):
+    world = 4
+    mp.spawn(_worker_sharded4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, "q%d.pt" % r)) for r in range(world)]
+    for P in (64, 67):
+        for k in ("xyz", "f_dc", "f_rest", "opa"):
+            for r in res:
+                assert torch.equal(r[P]["A"][k], r[P]["S"][k]), (P, k)          # four ranks == one process, bit for bit: the owner adds in rank order
+                assert torch.equal(r[P]["mA"][k], r[P]["mS"][k]), (P, k)
+            for r in res[1:]:
+                assert torch.equal(r[P]["A"][k], res[0][P]["A"][k]), (P, k)      # identical replicas
