@@ -71,6 +71,11 @@ def normal_from_depth_image(depth, intrinsic, extrinsic=None):
     return n
 
 
+# render(return_depth_normal=True): the depth -> normal map and its normalisation as one HIP kernel each way (ibgs_amd/depthnormal.py).  False = the
+# reference's torch formulation below, kept as the behavioural definition (tests compare the two).
+FUSED_DEPTH_NORMAL = True
+
+
 def render_normal(viewpoint_cam, depth, offset=None, normal=None, scale=1):
     intrinsic_matrix, extrinsic_matrix = viewpoint_cam.get_calib_matrix_nerf(scale=scale)
     st = max(int(scale / 2) - 1, 0)
@@ -143,8 +148,43 @@ def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
 TRACK_ABS_GRAD = True
 
 
+# The reference builds its two gradient sinks as `torch.zeros_like(xyz, requires_grad=True) + 0` per call (gaussian_renderer/__init__.py:153-159): two
+# fills and two adds of a (P, 3) tensor whose VALUES nobody reads (the rasterizer uses neither; train.py:404-405 reads `.grad` only).  SHARED_SINKS: the
+# zeros are ONE cached read-only buffer per (device, P), and each call gets two fresh non-leaf views of it through a no-op autograd node -- same
+# properties (zeros, requires_grad, not a leaf, retain_grad() works, `.grad` receives dL/dmean2D), no kernel.  False = the reference's expression.
+SHARED_SINKS = True
+_sink_zeros = {}
+
+
+class _SinkView(torch.autograd.Function):
+    """zeros (shared, never written) -> a non-leaf alias that requires grad; nothing flows further back."""
+
+    @staticmethod
+    def forward(ctx, zeros, anchor):
+        return zeros.view_as(zeros)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, None
+
+
 def _sinks(pc):
     xyz = pc.get_xyz
+    if SHARED_SINKS and xyz.is_cuda:
+        key = (xyz.device, tuple(xyz.shape), xyz.dtype)
+        ent = _sink_zeros.get(key)
+        if ent is None:
+            if len(_sink_zeros) > 8:
+                _sink_zeros.clear()
+            ent = _sink_zeros[key] = (torch.zeros_like(xyz, requires_grad=False), torch.zeros(1, device=xyz.device, requires_grad=True))
+        z, anchor = ent
+        a = _SinkView.apply(z, anchor)
+        b = _SinkView.apply(z, anchor) if TRACK_ABS_GRAD else z
+        if a.requires_grad:          # (not under torch.no_grad(): render.py:297)
+            a.retain_grad()
+            if TRACK_ABS_GRAD:
+                b.retain_grad()
+        return a, b
     a = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
     b = (torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0) if TRACK_ABS_GRAD else torch.zeros_like(xyz, dtype=xyz.dtype)
     try:
@@ -362,8 +402,12 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
 
     rendered_normal = out_normal_map[0:3] if render_geo else None
     if return_depth_normal:
-        dn = render_normal(viewpoint_camera, out_median_intersected_depth.squeeze())
-        dn = dn / (torch.norm(dn, dim=0, keepdim=True) + 1e-8)
+        if FUSED_DEPTH_NORMAL and out_median_intersected_depth.is_cuda and all(hasattr(viewpoint_camera, k) for k in ("Fx", "Fy", "Cx", "Cy")):
+            from .depthnormal import depth_normal
+            dn = depth_normal(viewpoint_camera, out_median_intersected_depth.squeeze())          # one kernel (and one in the backward) instead of ~25 each way
+        else:
+            dn = render_normal(viewpoint_camera, out_median_intersected_depth.squeeze())
+            dn = dn / (torch.norm(dn, dim=0, keepdim=True) + 1e-8)
     else:
         dn = None
     if app_model is not None and getattr(pc, "use_app", False):

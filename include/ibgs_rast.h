@@ -318,6 +318,14 @@ int32_t ibgs_l1_grad(void* stream, int64_t n, const float* x, const float* y, co
  * added to the total unweighted) is detected on the device and moves no data: value + gradient of the term then cost ONE pass over x and y. */
 int32_t ibgs_l1_rescale(void* stream, int64_t n, float* grad, const float* scale_dev);
 
+/* Row G(vii) of SURVEY 8(a): the depth -> normal map of the render glue (utils/graphics_utils.py:17-83 `normal_from_depth_image`, offset = None, through
+ * gaussian_renderer/__init__.py:16-26 `render_normal` at scale 1, and the normalisation render() applies to it, :338-342), one kernel each way.
+ * depth: H x W; normal / dL_dnormal: 3 x H x W (planar); dL_ddepth: H x W, every element written.  fx, fy, cx, cy: the pinhole intrinsics of
+ * Camera.get_calib_matrix_nerf (scene/cameras.py:118-121).  The border pixels' normals are zero, as the reference pads them. */
+int32_t ibgs_depth_normal_forward(void* stream, int32_t W, int32_t H, float fx, float fy, float cx, float cy, const float* depth, float* normal);
+int32_t ibgs_depth_normal_backward(void* stream, int32_t W, int32_t H, float fx, float fy, float cx, float cy, const float* depth,
+                                   const float* dL_dnormal, float* dL_ddepth);
+
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other
  * points (exact).  `scratch` >= ibgs_required_knn(P) bytes, caller-owned, transient. */

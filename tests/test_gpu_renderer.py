@@ -238,8 +238,11 @@ def test_render_keeps_source_stacks_and_poses_per_camera():
     renderer.GaussianRasterizer = Spy
     try:
         with torch.no_grad():
+            for j in cams[0].nearest_id:          # cached source depths, so that the warp finds valid sources
+                scene.rendered_depth_list[j] = renderer.render_depth(cams[j], pc, scene, pipe, args, bg, True, 3, 4)
             call = lambda: renderer.render(cams[0], pc, scene, pipe, args, bg, True, 3, 4, render_geo=True, return_depth_normal=False)
             a = call()
+            assert float(a["warped_image"].abs().sum()) > 0
             w0 = rasterizer._tex_writes[0]
             b = call()
             assert seen[-1].src_images is seen[-2].src_images and seen[-1].ref_to_src_list is seen[-2].ref_to_src_list and seen[-1].src_cam_pos is seen[-2].src_cam_pos
