@@ -52,9 +52,15 @@ NO_ABS_GRAD_WHEN_UNUSED = True
 WAVE_SHAPE = None
 
 
+# Experiment (round 5): the geo forward's per-pixel epilogue (median depth, source validity, warp) as its own pixel-parallel kernel behind the blend
+# kernel (IBGS_FLAG_SPLIT_GEO_EPILOGUE).  Bit-identical outputs (tests run both), but slower: inside the blend kernel the epilogue's gathers hide behind other
+# waves' blend loops, alone they do not (C3-geo forward 0.716 -> 0.844 ms).  Default off.
+SPLIT_GEO_EPILOGUE = os.environ.get("IBGS_SPLIT_GEO_EPILOGUE", "0") == "1"
+
+
 def _shape_flag():
     return ({None: 0, "tile": _lib.FLAG_TILE_WAVES, "quadrant": _lib.FLAG_QUADRANT_WAVES}[WAVE_SHAPE]
-            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP))
+            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP) | (_lib.FLAG_SPLIT_GEO_EPILOGUE if SPLIT_GEO_EPILOGUE else 0))
 
 
 # View-parallel training (ibgs_amd/dist.py): while a `capture_sh_factors()` block is active the backward leaves
@@ -181,24 +187,48 @@ def _tex(device, nbytes, what="tex"):
 
 _tex_writes = [0]
 
+# T1 once per SOURCE SET instead of once per call ("build replaces with a cached packed buffer"; the reference packs,
+# allocates and synchronises per forward AND per backward, rasterizer_impl.cu:366, 582).  When a forward is handed the very tensor object
+# whose pack is still held -- same object, same version counter (no in-place write since), same n / W / H -- the pack kernel is skipped
+# (IBGS_FLAG_TEX_PACKED).  Round 5: the packs are kept PER SOURCE STACK (least recently used first out, TEX_CACHE_BYTES in total per stream), not
+# only the last one: a trainer hops between cameras, each with its own stack (renderer.render keeps those per camera), and with one slot every
+# step packed again (40 us per geo forward at 1080p).  A slot keeps a reference to its tensor, so that memory cannot be recycled for another
+# image stack behind the cache's back; a fresh `torch.stack(...)` per call is a different object and packs again (into the shared scratch slot).
+# TEX_CACHE = False: always pack.
+TEX_CACHE = True
+TEX_CACHE_BYTES = 16 << 30
+_tex_pool = {}          # stream key -> OrderedDict[slot -> buffer]; slot = ("src", id(source tensor)) or "scratch"
+
+
+def _tex_slot(device, nbytes, slot):
+    pool = _tex_pool.get(_stream_key(device))
+    if pool is None:
+        if len(_tex_pool) > 8:
+            _tex_pool.clear()
+        pool = _tex_pool[_stream_key(device)] = collections.OrderedDict()
+    buf = pool.get(slot)
+    if buf is None or buf.numel() < nbytes:
+        buf = pool[slot] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    pool.move_to_end(slot)
+    total = sum(x.numel() for x in pool.values())
+    while total > TEX_CACHE_BYTES and len(pool) > 1:
+        k0 = next(iter(pool))
+        if k0 == slot:
+            break
+        total -= pool.pop(k0).numel()
+    return buf
+
 
 def _tex_packed(device, nbytes, source=None):
-    """The per-stream scratch that receives the packed source RGBA (T1), plus a ticket that names this pack: a later call that
-    holds the ticket and finds it still current (`_tex_still(ticket)`) knows that nothing overwrote the buffer in between.
-    `source` = (tensor, its version counter, n, W, H): what is being packed (see _tex_cached)."""
-    buf = _tex(device, nbytes)
+    """The buffer that receives the packed source RGBA (T1), plus a ticket that names this pack: a later call that holds the ticket and finds
+    it still current (`_tex_still(ticket)`) knows that nothing overwrote the buffer in between.
+    `source` = (tensor, its version counter, n, W, H): what is being packed (see _tex_cached); None / unversioned: the shared scratch slot."""
+    slot = ("src", id(source[0])) if (TEX_CACHE and source is not None and source[1] is not None) else "scratch"
+    buf = _tex_slot(device, nbytes, slot)
     _tex_writes[0] += 1
     buf._ibgs_ticket = _tex_writes[0]
     buf._ibgs_src = source
-    return buf, (_stream_key(device) + ("tex",), _tex_writes[0], nbytes)
-
-
-# T1 once per SOURCE SET instead of once per call (SURVEY 8(a) row T1: "build replaces with a cached packed buffer"; the reference packs,
-# allocates and synchronises per forward AND per backward, rasterizer_impl.cu:366, 582).  When a forward is handed the very tensor object
-# whose pack still sits in this stream's scratch -- same object, same version counter (no in-place write since), same n / W / H -- the pack
-# kernel is skipped (IBGS_FLAG_TEX_PACKED).  The scratch keeps a reference to that tensor, so its memory cannot be recycled for another
-# image stack behind the cache's back; a fresh `torch.stack(...)` per call is a different object and packs again.  TEX_CACHE = False: always pack.
-TEX_CACHE = True
+    return buf, (_stream_key(device), slot, _tex_writes[0], nbytes)
 
 
 def _tensor_version(t):
@@ -213,27 +243,31 @@ def _tensor_version(t):
 def invalidate_tex_cache():
     """Forget every cached source-RGBA pack.  The cache notices writes through the version counter only; a write that does not bump it
     (`src_images.data.copy_(...)`, a raw kernel filling a persistent buffer) must be followed by this call."""
-    for buf in _tex_scratch.values():
-        buf._ibgs_src = None
+    for pool in _tex_pool.values():
+        for buf in pool.values():
+            buf._ibgs_src = None
 
 
 def _tex_cached(device, nbytes, source):
     if not TEX_CACHE or source[1] is None:
         return None
-    key = _stream_key(device) + ("tex",)
-    buf = _tex_scratch.get(key)
+    pool = _tex_pool.get(_stream_key(device))
+    slot = ("src", id(source[0]))
+    buf = pool.get(slot) if pool is not None else None
     had = getattr(buf, "_ibgs_src", None) if buf is not None else None
     if had is None or buf.numel() < nbytes or had[0] is not source[0] or had[1:] != source[1:]:
         return None
-    return buf, (key, buf._ibgs_ticket, nbytes)
+    pool.move_to_end(slot)
+    return buf, (_stream_key(device), slot, buf._ibgs_ticket, nbytes)
 
 
 def _tex_still(ticket, device, nbytes):
     if ticket is None:
         return None
-    key, serial, had = ticket
-    buf = _tex_scratch.get(key)
-    if buf is None or key != _stream_key(device) + ("tex",) or had < nbytes or getattr(buf, "_ibgs_ticket", None) != serial:
+    skey, slot, serial, had = ticket
+    pool = _tex_pool.get(skey)
+    buf = pool.get(slot) if pool is not None else None
+    if buf is None or skey != _stream_key(device) or had < nbytes or getattr(buf, "_ibgs_ticket", None) != serial:
         return None
     return buf
 

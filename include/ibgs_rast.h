@@ -89,6 +89,9 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                            csrc/common.h: conic_is_risky) and drop the pairs it drops; with this flag every Gaussian
                                            takes the fast path and such pairs are blended with alpha ~= opacity */
 
+#define IBGS_FLAG_SPLIT_GEO_EPILOGUE 2048u /* ibgs_forward, render_geo (experiment, round 5): run the per-pixel epilogue (median depth, source validity, warp;
+                                              forward.cu:507-663) as its own pixel-parallel kernel behind the blend kernel instead of inside it.  Bit-identical outputs;
+                                              SLOWER on MI355X (C3-geo forward 0.716 -> 0.844 ms, trained 0.367 -> 0.392: alone, the gathers have nothing to hide behind) */
 #define IBGS_FLAG_NO_ABS_GRAD 1024u /* ibgs_backward only: dL_dmean2D_abs is not wanted (it may be NULL and is not written).  It is the densification statistic of
                                        train.py:400-410 (sum over pixels of |dL/dmean2D| per Gaussian, backward.cu:793-804): nobody reads it after
                                        densify_until_iter or at test time.  The colour blend then skips the two |.| moments (conic x d per quadrant, two fma per

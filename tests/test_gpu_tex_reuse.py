@@ -43,14 +43,30 @@ def test_backward_reuses_or_repacks_the_source_rgba():
         assert rasterizer._tex_writes[0] == before, "an isolated backward must not pack again"
         alone[v] = _grads(pc)
 
-    # two forwards, then the two backwards: view 0's pack was overwritten by view 1's forward
+    # two forwards, then the two backwards.  Round 5: every source stack keeps its own pack (up to TEX_CACHE_BYTES), so neither backward packs again ...
     pc_a, loss_a = _forward(0, g, dev, cams, scene, pipe, args, bg)
     pc_b, loss_b = _forward(1, g, dev, cams, scene, pipe, args, bg)
     before = rasterizer._tex_writes[0]
-    loss_a.backward()
-    assert rasterizer._tex_writes[0] == before + 1, "view 0's backward has to pack its own sources again"
-    loss_b.backward()                                  # ... which overwrote view 1's pack in turn
-    assert rasterizer._tex_writes[0] == before + 2
+    loss_a.backward(); loss_b.backward()
+    assert rasterizer._tex_writes[0] == before, "each stack's pack is still held: no backward packs again"
+    for v, pc in ((0, pc_a), (1, pc_b)):
+        got = _grads(pc)
+        for n in NAMES:
+            assert rel_l2(got[n], alone[v][n]) < 1e-5, (v, n, rel_l2(got[n], alone[v][n]))
+    # ... and with room for ONE pack only (the behaviour until round 4): view 0's pack is evicted by view 1's forward
+    old_cap = rasterizer.TEX_CACHE_BYTES
+    rasterizer.TEX_CACHE_BYTES = 1
+    rasterizer._tex_pool.clear()          # (packs held from above would simply be found again: eviction happens when a pack is ADDED)
+    try:
+        pc_a, loss_a = _forward(0, g, dev, cams, scene, pipe, args, bg)
+        pc_b, loss_b = _forward(1, g, dev, cams, scene, pipe, args, bg)
+        before = rasterizer._tex_writes[0]
+        loss_a.backward()
+        assert rasterizer._tex_writes[0] == before + 1, "view 0's backward has to pack its own sources again"
+        loss_b.backward()                                  # ... which evicted view 1's pack in turn
+        assert rasterizer._tex_writes[0] == before + 2
+    finally:
+        rasterizer.TEX_CACHE_BYTES = old_cap
     for v, pc in ((0, pc_a), (1, pc_b)):
         got = _grads(pc)
         for n in NAMES:
