@@ -58,6 +58,7 @@ class ForwardArgs(ctypes.Structure):
         ("plane_normal", c_float_p), ("plane_offset", c_float_p), ("plane_mode", ctypes.c_int32),
         ("n_views", ctypes.c_int32), ("view_tanfovx", ctypes.c_float * 8), ("view_tanfovy", ctypes.c_float * 8),
         ("tile_order_hint", ctypes.c_void_p),
+        ("binning", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
     ]
 
 

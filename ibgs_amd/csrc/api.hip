@@ -8,6 +8,9 @@
 // Everything is enqueued on the caller's stream; no device-wide synchronisation, no allocation
 // (arenas are caller-owned), no persistent library state.
 #include "common.h"
+#include <sched.h>
+#include <time.h>
+#include <string.h>
 #include <cstdlib>
 #include <stdlib.h>
 #include <stdio.h>
@@ -151,6 +154,29 @@ static int stage_check(hipStream_t s, bool debug, const char* what)
     return 0;
 }
 
+// R of a hinted forward without a copy, an event or a second stream (round 5): ONE workgroup adds up the per-wave tile sums the preprocess kernel left and stores
+// the total, then a ticket, straight into pinned host memory; the host polls the ticket (ibgs_forward).  The four runtime calls it replaces -- event
+// record, stream wait, copy, event record -- cost the forward ~12 us of host time, and the copy engine's own latency on top.  The ticket counts in
+// DEVICE memory (a kernel argument could not change from call to call were this sequence ever replayed from a graph); the host knows which one it waits for.
+__global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __restrict__ partial, uint32_t nwords, uint32_t* __restrict__ seq_dev, volatile uint32_t* host_words)
+{
+    __shared__ unsigned long long s_w[16];
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < nwords; i += 1024) sum += partial[i];
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; w++) t += s_w[w];
+        host_words[0] = (uint32_t)t; host_words[1] = (uint32_t)(t >> 32);
+        __threadfence_system();                                   // the total is visible to the host before the ticket is
+        const uint32_t ticket = *seq_dev + 1u;
+        *seq_dev = ticket;
+        __hip_atomic_store(const_cast<uint32_t*>(host_words) + 2, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace ibgs
 
 using namespace ibgs;
@@ -231,11 +257,10 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
 // belongs to the device that was current when it was created, so a thread that drives several GPUs needs one per device.
 struct RSlot {
     uint32_t* host; hipEvent_t ev;
-    uint32_t* part; size_t part_cap;          // deferred sizing: the preprocess kernel's per-wave tile sums + the depth sort's error flag (pinned, grown on demand)
-    uint32_t* stats; hipEvent_t ev_stats; bool stats_pending;          // R as the binning counted it, -, C: diagnostics, read when somebody asks (ibgs_last_forward_stats)
-    bool flag_pending;                                                 // stats[3] = the depth sort's error flag of the last hinted forward, not looked at yet (check_sort_flag)
-    hipStream_t copy_stream; hipEvent_t ev_mark;          // the read-backs run on a stream of their own, behind a marker of the caller's stream: a copy queued INTO the
-                                                          // caller's stream is a blit kernel between two barriers there (~25 us of the step)
+    uint32_t* stats; bool stats_pending;          // R as the binning counted it, -, C: diagnostics the binning's last kernel stores HERE (pinned host words), read when somebody asks
+    bool flag_pending;                                                 // stats[3] = the depth sort's STICKY error word, stored by that kernel too; a hinted forward has not been vouched for yet
+    hipStream_t last_stream;                                           // the stream of that forward (ibgs_last_forward_stats drains it before it reads)
+    uint32_t* seq_dev; uint32_t seq_host;                              // ticket counter of rendered_note_kernel (device word) and the last ticket the host has waited for
 };
 static RSlot* rslot()
 {
@@ -248,38 +273,28 @@ static RSlot* rslot()
         void* p = nullptr;
         if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
         if (hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
-        if (hipEventCreateWithFlags(&slot.ev_stats, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
-        if (hipEventCreateWithFlags(&slot.ev_mark, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&slot.copy_stream, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipHostFree(p); set_error("hipStreamCreate for the read-backs failed"); return nullptr;
-        }
         slot.host = static_cast<uint32_t*>(p);
+        memset(p, 0, 64);          // (stats[3] is a sticky error word the GPU only ever sets; host[2] the last ticket)
+        void* sq = nullptr;
+        if (hipMalloc(&sq, 64) != hipSuccess || hipMemset(sq, 0, 64) != hipSuccess) { set_error("hipMalloc for the ticket word failed"); return nullptr; }
+        slot.seq_dev = static_cast<uint32_t*>(sq); slot.seq_host = 0;
         slot.stats = slot.host + 8;
     }
     return &slot;
 }
-static int rslot_reserve_part(RSlot* rs, size_t words)
-{
-    if (rs->part_cap >= words) return 0;
-    if (rs->part) (void)hipHostFree(rs->part);
-    rs->part = nullptr; rs->part_cap = 0;
-    void* p = nullptr;
-    const size_t cap = words + words / 4 + 1024;
-    if (hipHostMalloc(&p, cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the tile sums failed"); return -IBGS_ERR_HIP; }
-    rs->part = static_cast<uint32_t*>(p); rs->part_cap = cap;
-    return 0;
-}
-
-// The depth sort's error flag of a hinted forward travels back behind the binning, together with the diagnostics, and nobody waits for it inside
-// that call (round 5: the tiles-touched sums leave right after the preprocess kernel, so that the host is released while the GPU is still sorting).
-// It is looked at by the next entry into the library on this thread -- a backward only if the words have already arrived -- and reported THERE: an
-// asynchronous error, like HIP's own.  (The look-back of the onesweep passes times out only if a workgroup is starved for seconds.)
-static int check_sort_flag(RSlot* rs, bool wait)
+// The depth sort's error word of a hinted forward is stored into pinned host memory by the binning's last kernel (tile_ranges_kernel), together with
+// the diagnostics; nobody queues anything for it and nobody waits for it inside that call (round 5: the tiles-touched sums leave right after the
+// preprocess kernel, so that the host is released while the GPU is still sorting).  The word is sticky.  It is looked at by the next entry into the
+// library on this thread at a point where the stream has provably passed that kernel -- after the next forward's wait for ITS R -- or, without
+// waiting, by a backward that finds it set, and reported THERE: an asynchronous error, like HIP's own.  (The look-back of the onesweep passes times
+// out only if a workgroup is starved for seconds.)
+static int check_sort_flag(RSlot* rs)
 {
     if (!rs || !rs->flag_pending) return 0;
-    if (!wait && hipEventQuery(rs->ev_stats) != hipSuccess) return 0;
-    IBGS_HIP(hipEventSynchronize(rs->ev_stats));
-    rs->flag_pending = false;
-    if (rs->stats[3]) { set_error("depth sort of the previous forward: decoupled look-back timed out (its lists were mis-ordered)"); return -IBGS_ERR_HIP; }
+    if (*(volatile uint32_t*)(rs->stats + 3)) {
+        rs->stats[3] = 0u; rs->flag_pending = false;
+        set_error("depth sort of an earlier forward: decoupled look-back timed out (its lists were mis-ordered)"); return -IBGS_ERR_HIP;
+    }
     return 0;
 }
 
@@ -289,8 +304,8 @@ static thread_local int64_t g_last_stats[3] = {0, -1, 0};
 static thread_local RSlot* g_stats_slot = nullptr;
 void ibgs_last_forward_stats(int64_t* out)
 {
-    if (g_stats_slot && g_stats_slot->stats_pending) {          // the coarse count travelled back on its own; nobody waited for it
-        if (hipEventSynchronize(g_stats_slot->ev_stats) == hipSuccess) g_last_stats[1] = (int64_t)g_stats_slot->stats[2];
+    if (g_stats_slot && g_stats_slot->stats_pending) {          // the coarse count sits in pinned host memory once the binning of that forward has run
+        if (hipStreamSynchronize(g_stats_slot->last_stream) == hipSuccess) g_last_stats[1] = (int64_t)*(volatile uint32_t*)(g_stats_slot->stats + 2);
         g_stats_slot->stats_pending = false;
     }
     out[0] = g_last_stats[0]; out[1] = g_last_stats[1]; out[2] = g_last_stats[2];
@@ -359,19 +374,16 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     const size_t nwaves = (size_t)nv * (((size_t)a.P + 63) / 64);          // words of per-wave tile sums the preprocess kernel wrote; the depth sort's error flag follows them
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
-    if ((rc = check_sort_flag(rs, true))) return rc;
     { StageTimer t(s, IBGS_STAGE_PREPROCESS);
       if ((rc = launch_preprocess(s, a, g, deferred ? 1 : 0))) return rc;
       if (deferred) {
-          // R = the sum of the tiles touched, final as soon as the geometry kernel is: its per-wave sums leave for the host HERE, on the copy stream, while
-          // the caller's stream goes on with the SH colours and the depth sort.  (Until round 4 they left behind the sort, together with its error flag:
-          // on small frames the host then sat out five sort launches' worth of GPU latency -- ~45 us of a 0.34 ms call pair, profiles/r05_host_split.txt --
-          // before it could queue the loss and the backward.)
-          if ((rc = rslot_reserve_part(rs, nwaves + 1))) return rc;
-          IBGS_HIP(hipEventRecord(rs->ev_mark, s));
-          IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
-          IBGS_HIP(hipMemcpyAsync(rs->part, g.tile_partial, nwaves * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
-          IBGS_HIP(hipEventRecord(rs->ev, rs->copy_stream));
+          // R = the sum of the tiles touched, final as soon as the geometry kernel is: a one-workgroup kernel adds the per-wave sums up HERE and stores the
+          // total + a ticket into pinned host memory, while the stream goes on with the SH colours and the depth sort.  (Until round 4 the sums left
+          // behind the sort, by a copy on a second stream, together with the sort's error flag: on small frames the host then sat out five sort launches'
+          // worth of GPU latency -- ~45 us of a 0.34 ms call pair, profiles/r05_host_split.txt -- before it could queue the loss and the backward.)
+          hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, g.tile_partial, (uint32_t)nwaves, rs->seq_dev, rs->host);
+          IBGS_HIP(hipGetLastError());
+          rs->seq_host++;          // the ticket that kernel will write
           if ((rc = launch_preprocess(s, a, g, 2))) return rc;
       }
     }
@@ -408,19 +420,17 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
 
     auto tail = [&](int64_t n, bool read_back) -> int {
         int rc;
-        char* bin_mem = a.binning_alloc(ibgs_required_binning(n, a.W, Hn), a.binning_user);
+        // the hinted pass may use an arena the caller sized for the hint beforehand (ibgs_forward_args.binning: no call back into the caller, which
+        // through ctypes costs ~10 us); anything else -- no hint, a too small hint -- asks binning_alloc
+        const size_t need = ibgs_required_binning(n, a.W, Hn);
+        char* bin_mem = (read_back && a.binning && a.binning_bytes >= need) ? a.binning : a.binning_alloc(need, a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
-        { StageTimer t(s, IBGS_STAGE_EMIT); if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta, nv))) return rc; }
-        if (read_back) {
-            // diagnostics nobody waits for (ibgs_last_forward_stats): R as the binning counted it, -, the coarse slots in use
-            IBGS_HIP(hipEventRecord(rs->ev_mark, s));
-            IBGS_HIP(hipStreamWaitEvent(rs->copy_stream, rs->ev_mark, 0));
-            IBGS_HIP(hipMemcpyAsync(rs->stats, g.offsets + Pn, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));
-            IBGS_HIP(hipMemcpyAsync(rs->stats + 3, g.tile_partial + nwaves, sizeof(uint32_t), hipMemcpyDeviceToHost, rs->copy_stream));          // the depth sort's error flag (check_sort_flag)
-            IBGS_HIP(hipEventRecord(rs->ev_stats, rs->copy_stream));
-            rs->flag_pending = true;
-        }
+        // hinted pass: the binning's last kernel leaves R as it counted it, the coarse slots in use and the depth sort's error word in pinned host memory
+        // (diagnostics nobody waits for: ibgs_last_forward_stats; the error word: check_sort_flag)
+        { StageTimer t(s, IBGS_STAGE_EMIT);
+          if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta, nv, read_back ? g.tile_partial + nwaves : nullptr, read_back ? rs->stats : nullptr))) return rc; }
+        if (read_back) { rs->flag_pending = true; rs->last_stream = s; }
         { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b))) return rc; }
         if ((rc = stage_check(s, debug, "binning"))) return rc;
         const float4* rgba = nullptr;
@@ -432,13 +442,38 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         { StageTimer t(s, IBGS_STAGE_RENDER_FWD); if ((rc = launch_render_forward(s, a, g, b, im, rgba))) return rc; }
         return stage_check(s, debug, "render");
     };
+    const bool prev_pending = rs->flag_pending;          // a hinted forward before this one whose sort nobody has vouched for yet
     if ((rc = tail(cap, deferred))) return rc;
     g_last_stats[1] = -1; g_last_stats[2] = 0;
     g_stats_slot = rs; rs->stats_pending = false;
     if (deferred) {
-        IBGS_HIP(hipEventSynchronize(rs->ev));
-        uint64_t sum = 0;
-        for (size_t w = 0; w < nwaves; w++) sum += rs->part[w];
+        {   // wait for the ticket: a few thousand polls of one pinned cache line, then yield between polls; bounded (a lost ticket must not hang the trainer)
+            volatile uint32_t* tk = rs->host + 2;
+            const uint32_t want = rs->seq_host;
+            uint64_t spins = 0;
+            struct timespec t0; bool timed = false;
+            while (__atomic_load_n(const_cast<uint32_t*>(tk), __ATOMIC_ACQUIRE) != want) {
+                if (++spins > 4000) {
+                    if (!timed) { clock_gettime(CLOCK_MONOTONIC, &t0); timed = true; }
+                    sched_yield();
+                    if ((spins & 1023) == 0) {
+                        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+                        if (t1.tv_sec - t0.tv_sec > 5) {          // long wait: legitimate while the stream still has work in front of the note kernel
+                            if (hipStreamQuery(s) == hipErrorNotReady) { t0 = t1; continue; }
+                            IBGS_HIP(hipStreamSynchronize(s));          // the stream is empty (or broken): the ticket must be there now
+                            if (*tk == want) break;
+                            set_error("ibgs_forward: the device never reported R (ticket %u, last seen %u)", want, *tk); return -IBGS_ERR_HIP;
+                        }
+                    }
+                }
+            }
+        }
+        // (this stream has now passed every kernel of the forwards before this one: their sticky error word is final)
+        if (prev_pending && *(volatile uint32_t*)(rs->stats + 3)) {
+            rs->stats[3] = 0u;
+            set_error("depth sort of the previous forward: decoupled look-back timed out (its lists were mis-ordered)"); return -IBGS_ERR_HIP;
+        }
+        const uint64_t sum = (uint64_t)rs->host[0] | ((uint64_t)rs->host[1] << 32);
         R = (int64_t)sum;          // exact, whatever the binning could fit (a coarse entry stands for at least one pair: C <= R, so R <= cap means nothing was dropped)
         if (R > cap) {
             g_last_stats[2] = 1;
@@ -446,7 +481,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             // second callback) and redo binning + render with the exact size (every output element is rewritten).  Same results
             // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
-            if ((rc = check_sort_flag(rs, true))) return rc;
+            if ((rc = check_sort_flag(rs))) return rc;          // (the stream is drained: this forward's own word is final too)
             if ((rc = tail(R, false))) return rc;
         } else rs->stats_pending = true;
     }
@@ -461,7 +496,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     hipStream_t s = reinterpret_cast<hipStream_t>(a.stream);
     const bool debug = (a.flags & IBGS_FLAG_DEBUG) != 0;
     if (a.P <= 0) return 0;                                       // rasterize_points.cu:221
-    { int frc = check_sort_flag(g_stats_slot, false); if (frc) return frc; }
+    { int frc = check_sort_flag(g_stats_slot); if (frc) return frc; }          // (no wait: reports the word if the GPU has already set it)
     if (!a.geom || !a.img || (!a.binning && a.R > 0)) { set_error("backward needs the forward's arenas"); return -IBGS_ERR_INVALID; }
     if (!a.grad_acc) { set_error("grad_acc scratch required"); return -IBGS_ERR_INVALID; }
     if (!a.dL_dmean2D || (!a.dL_dmean2D_abs && !(a.flags & IBGS_FLAG_NO_ABS_GRAD)) || !a.dL_dopacity || !a.dL_dmean3D) {

@@ -512,7 +512,9 @@ __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint3
 // thread, the 1024 strip sums scanned through LDS.  Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after
 // its memset).
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
-                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap)
+                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
+                                                           const uint32_t* __restrict__ sort_flag /* the depth sort's error word, or nullptr */,
+                                                           uint32_t* __restrict__ host_note /* pinned HOST words or nullptr: [0] R, [2] C, [3] |= sort error */)
 {
     // Every wave owns a contiguous range of tiles and walks it 64 tiles at a time: coalesced loads and stores, a wave-level scan per step.
     // (A strip of consecutive tiles per THREAD made every lane touch its own cache line, per step: 11 us at 1080p, 54 us for the 32 640 tiles
@@ -551,7 +553,12 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t*
 #pragma unroll
     for (int k = 0; k < KEEP; k++) if (k < nsteps) step(k, v[k]);          // (wave-uniform condition)
     for (int k = KEEP; k < nsteps; k++) { const int t = w0 + k * 64 + lane; step(k, t < w1 ? tile_start[t] : 0u); }
-    if (tid == 1023) { tile_start[ntiles] = run; counters[0] = run; }      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
+    if (tid == 1023) {
+        tile_start[ntiles] = run; counters[0] = run;      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
+        // what the host looks at LATER without having queued anything for it (api.hip, round 5: the copies, events and the stream wait that carried these words
+        // cost the forward ~10 us of host time): diagnostics and the depth sort's sticky error word, stored straight into pinned host memory
+        if (host_note) { host_note[0] = run; host_note[2] = counters[2]; if (sort_flag && *sort_flag) host_note[3] = 1u; }
+    }
 }
 
 // One wave per chunk: ids to their final slots, in order.  Per round of 64 entries the wave transposes the bit matrix (row = entry,
@@ -647,7 +654,7 @@ static int place_block_ranks(int P, size_t cnt_elems, int ncells)
 // Part 1: everything up to the tile ranges and the counters the host reads back (R, C); part 2 (launch_binning_scatter) writes the
 // lists.  Split so that the host's read-back can be queued between them and is served while scatter + render still run.
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
-                   const uint32_t* order_hint, uint32_t* meta, int n_views)
+                   const uint32_t* order_hint, uint32_t* meta, int n_views, const uint32_t* sort_flag, uint32_t* host_note)
 {
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy, ntiles = gx * gy;
     uint32_t* counters = g.offsets + P;               // R, depth sort error flag, C: what the host reads back in ONE copy (api.hip)
@@ -689,7 +696,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
-                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll));
+                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), sort_flag, host_note);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -422,7 +422,8 @@ void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatt
 // part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
                    const uint32_t* order_hint = nullptr, uint32_t* meta = nullptr /* meta[11] = 1 when the hint is a valid tile order */,
-                   int n_views = 1 /* batched depth views: P = n_views x instances, gy = n_views x rows */);
+                   int n_views = 1 /* batched depth views: P = n_views x instances, gy = n_views x rows */,
+                   const uint32_t* sort_flag = nullptr, uint32_t* host_note = nullptr /* pinned host words the last kernel leaves R, C and the sort's error word in */);
 constexpr int ORDER_CLASSES = 1024;          // SIMDs of the chip = classes of the balanced launch order (render_bwd.hip)
 int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
 

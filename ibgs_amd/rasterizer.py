@@ -485,12 +485,18 @@ class _CModule:
                 hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
                 prev = (max(hist) if isinstance(hist, list) else int(hist)) if hist else 0
                 a.rendered_hint = (prev + prev // 4 + 4096) if prev > 0 else 0
+                pre = None
+                if prev > 0:          # the arena for the hinted pass, allocated HERE: no call back from the library into Python (~10 us through ctypes)
+                    pre = torch.empty(lib.ibgs_required_binning(int(a.rendered_hint), W, H), dtype=torch.uint8, device=device)
+                    a.binning = pre.data_ptr(); a.binning_bytes = pre.numel()
                 rc = lib.ibgs_forward(ctypes.byref(a))
                 if rc < 0:
                     if "err" in holder:
                         raise holder["err"]
                     raise RuntimeError("ibgs_forward failed (%d): %s" % (rc, _lib.last_error()))
                 rendered = int(rc)
+                if pre is not None and "t" not in holder:
+                    binningBuffer = pre          # (a too small hint: the repeated pass asked the callback, whose tensor holds the lists)
                 if len(_last_rendered) > 64:
                     _last_rendered.clear()
                 hist = _last_rendered.get(hkey)

@@ -191,6 +191,11 @@ typedef struct ibgs_forward_args {
      * the variants with one wave per tile / half tile (large frames: colour and render_geo passes) and by the per-tile choice of small colour frames,
      * not by render_depth_only. */
     const uint32_t* tile_order_hint;
+    /* Optional (may be NULL / 0): a binning arena the caller allocated beforehand for rendered_hint, >= ibgs_required_binning(rendered_hint, W, H) bytes.
+     * The hinted pass then uses it instead of calling binning_alloc (a call back into the host language: ~10 us through ctypes); a forward without a
+     * hint, and the repeated pass after a too small hint, still call binning_alloc.  The arena the lists ended up in is `binning` iff the return value
+     * R <= rendered_hint and this field was large enough. */
+    char* binning; size_t binning_bytes;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {

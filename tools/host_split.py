@@ -37,9 +37,26 @@ class Timed:
 names = ("color", "normal_map", "median_depth", "warped_image")
 g = {"color": torch.randn(3, 64, 64, device=dev), "normal_map": torch.randn(3, 64, 64, device=dev), "median_depth": torch.randn(1, 64, 64, device=dev),
      "warped_image": torch.randn(15, 64, 64, device=dev)}
+# layer by layer: time inside _C.rasterize_gaussians / _backward (marshalling + the C call), inside the autograd Function's forward / backward (the former + ctx
+# bookkeeping), and the call as the trainer sees it (the latter + torch's dispatch: Module.__call__, Function.apply, the autograd engine's thread hop)
+layers = {"C.fwd": [], "C.bwd": [], "Fn.fwd": [], "Fn.bwd": []}
+
+
+def timed_static(cls, name, key):
+    fn = getattr(cls, name)
+
+    def wrapper(*a, **k):
+        t0 = time.perf_counter(); r = fn(*a, **k); layers[key].append((time.perf_counter() - t0) * 1e6)
+        return r
+    setattr(cls, name, staticmethod(wrapper))
+    return fn
+
+
 for timed in (False, True):
     if timed:
         lib.ibgs_forward, lib.ibgs_backward = Timed(real_f, "fwd"), Timed(real_b, "bwd")
+        timed_static(rz._CModule, "rasterize_gaussians", "C.fwd"); timed_static(rz._CModule, "rasterize_gaussians_backward", "C.bwd")
+        timed_static(rz._RasterizeGaussians, "forward", "Fn.fwd"); timed_static(rz._RasterizeGaussians, "backward", "Fn.bwd")
     tf, tb = [], []
     for it in range(400):
         for v in lv.values():
@@ -67,4 +84,8 @@ for timed in (False, True):
         cf, cb = med(acc["fwd"][50:]), med(acc["bwd"][50:])
         print("   inside the C library: ibgs_forward %.1f us, ibgs_backward %.1f us; Python / torch / autograd around them: forward %.1f us, backward %.1f us"
               % (cf, cb, med(tf) - cf, med(tb) - cb))
+        m = {k: med(v[50:]) for k, v in layers.items()}
+        print("   layers (medians, us): forward  call %.1f > Function.forward %.1f > _C.rasterize_gaussians %.1f > ibgs_forward %.1f" % (med(tf), m["Fn.fwd"], m["C.fwd"], cf))
+        print("                         backward call %.1f > Function.backward %.1f > _C.rasterize_gaussians_backward %.1f > ibgs_backward %.1f   (the call includes the loss's own backward)"
+              % (med(tb), m["Fn.bwd"], m["C.bwd"], cb))
 lib.ibgs_forward, lib.ibgs_backward = real_f, real_b
