@@ -96,7 +96,7 @@ def algorithmic_bytes(P, R, HW, Mc, tiles, geo=False, n_src=0):
 
 
 def implementation_bytes(P, kept, R, C, HW, Mc):
-    """Bytes THIS design moves per step (DESIGN.md "Algorithmic bytes of the implementation"): SURVEY's model charges the reference's
+    """Bytes THIS design moves per step (docs/EXPERIMENTS.md "Bytes of the implementation"): SURVEY's model charges the reference's
     R-sized 64-bit sort (R x 24 B x 6 passes); here the sort is P-sized and the lists are placed directly.
     kept = Gaussians with tiles, C = coarse binning entries (one per Gaussian and 8 x 8-tile cell)."""
     pre = P * (44 + 12 * Mc) + P * (64 + 16 + 4 + 4 + 24 + 1 + 8)          # inputs; record, footprint, depth, tiles, cov3D, clamp bits, sort pair

@@ -319,7 +319,7 @@ __device__ __forceinline__ PlaneEval plane_eval(int mode, const float* __restric
 // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own 4 MB L2 (MI355X_MICROARCH.md).  Which tiles share
 // an XCD decides (i) whether the two halves of a 128-byte line of an output plane -- 32 pixels = two tiles side by side -- meet in ONE
 // L2 and leave as a full line, (ii) how much of the source textures' halo the geo epilogue's gathers find already cached, (iii) how
-// evenly a non-uniform image spreads over the chip.  Three layouts, chosen per kernel by measurement:
+// evenly a non-uniform image spreads over the chip.  Three layouts, chosen per kernel by measurement (docs/EXPERIMENTS.md section 7):
 //   RR     item = workgroup id: neighbouring items on different XCDs (best balance, every output line split over two L2s)
 //   GROUP  runs of `g` consecutive items per XCD: with g x (waves per tile) covering 2+ tiles, output lines are completed in one L2
 //   BLOCK  bx x by tile blocks per XCD (2-D locality for the gathers)

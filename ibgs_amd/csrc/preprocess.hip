@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
 // LDS sets the occupancy): round h parks rows 32h .. 32h + 31, lane 32h + r reads row r back.  Every load instruction covers one
 // contiguous kilobyte, every cache line is fetched once.  In the step it runs at ~3 TB/s of useful bytes -- what a 100-200 MB read gets
 // right after kernels that left the caches full of dirty lines (tests/csrc/probe_read_bw.hip "cold": 2.9 TB/s; 6.2 TB/s when nothing
-// has to drain), whatever its occupancy or load shape (three variants measured).  The evaluation is the oracle's, operation by
+// has to drain), whatever its occupancy or load shape (three variants measured, docs/EXPERIMENTS.md section 7).  The evaluation is the oracle's, operation by
 // operation and in its order (this file is compiled without contraction): colours and clamp flags stay bit-identical.  Writes quad 2 of
 // the render record and the clamp bits.
 constexpr int SHC_ROW = 52;          // LDS words per row: 48 coefficients + 4 words of padding

@@ -150,7 +150,7 @@ def _dev_f32(t, device):
     if t is None or t.numel() == 0:
         return None
     # the common case first -- an fp32, contiguous, 16-byte-aligned tensor that already lives on the device -- in as few Python-level calls as possible
-    # (this runs ~30 times per step; DESIGN.md section 7, host time)
+    # (this runs ~30 times per step; docs/EXPERIMENTS.md section 7, host time)
     if t.dtype is torch.float32 and t.device == device and t.is_contiguous() and not (t.data_ptr() & 15):
         return t
     if t.device != device:

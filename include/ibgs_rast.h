@@ -363,7 +363,7 @@ int32_t ibgs_compact_apply(void* stream, int32_t n_tensors, const ibgs_compact_t
                            const char* scratch);
 
 /* Introspection for tests: byte offsets of the named sub-arrays inside the arenas.
- * Returns -1 for an unknown name. Names: see DESIGN.md "Arena layout". */
+ * Returns -1 for an unknown name. Names: see DESIGN.md section 2. */
 int64_t ibgs_geom_offset(int32_t P, const char* name);
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name);
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name);

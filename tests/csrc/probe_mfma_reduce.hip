@@ -1,4 +1,4 @@
-// Can the matrix pipe take the backward's 12-value wave reduction off the VALU?  
+// Can the matrix pipe take the backward's 12-value wave reduction off the VALU?  (docs/EXPERIMENTS.md section 7, round 3.)
 // Every wave runs ITER rounds of { ~120 independent v_fma (the blend arithmetic's stand-in), then a reduction of 12 per-lane values over
 // the 64 lanes }: (0) no reduction, (1) the butterfly transpose-reduce of ibgs_amd/csrc/wave_reduce.h, (2) thirteen v_mfma_f32_16x16x4_f32:
 // twelve accumulate D[i][c] += sum_k V_c[16 k + i] (B = one-hot column c, shifted from c - 1 by a DPP row_shr:1), three adds fold D's four

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """NOT runnable in this repository's environment: it needs a CUDA machine with the REFERENCE's own rasterizer installed
 (`pip install submodules/diff-plane-rasterization` inside a checkout of HoangChuongNguyen/ibgs) and NOT this repository's shim of the
-same name on PYTHONPATH.  It closes the one gap DESIGN.md section 4 names: it runs the reference's CUDA operator on the seeded C1
+same name on PYTHONPATH.  It closes the one gap DESIGN.md section 5 names: it runs the reference's CUDA operator on the seeded C1
 inputs that tests/golden/make_oracle_snapshot.py freezes the oracle on, and writes the same fields to tests/golden/reference_c1.npz.
 With that file committed, tests/test_oracle_snapshot.py::test_oracle_against_the_reference_snapshot compares the oracle with the
 reference's own output (it is skipped while the file is absent).

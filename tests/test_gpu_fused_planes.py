@@ -13,7 +13,7 @@ from tests.metrics import l1, rel_l2
 pytestmark = pytest.mark.gpu
 
 # Relative-L2 bars of the geo gradients against the oracle.  1e-3 is BASELINE.md's bar; a term gets a looser one only with a
-# measured reason (filled in from the GPU runs of this round).
+# measured reason (filled in from the GPU runs of this round, see docs/EXPERIMENTS.md section 3).
 GEO_BAR = {}
 
 

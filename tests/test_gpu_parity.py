@@ -56,7 +56,7 @@ def check_stages(ist, o, ref):
 def check_color(o, ist, ref, frac_contrib=2e-4):
     """The north star's image bar is on the MEAN (1e-4 L1 per pixel; asserted a hundred times tighter).  A single pixel may differ by up to
     alpha_min * T = 0.004 when a Gaussian sits at alpha = 1/255 to the last bit and the two exp implementations fall on different sides of the
-    reference's skip test (DESIGN.md section 3) -- hence the separate, looser bound on the maximum."""
+    reference's skip test (DESIGN.md section 4) -- hence the separate, looser bound on the maximum."""
     assert l1(o["color"], ref["color"]) <= L1_TOL * 1e-2
     assert float(np.abs(o["color"] - ref["color"]).max()) < 5e-3
     bad = (ist["n_contrib"] != ref["n_contrib"]).mean()

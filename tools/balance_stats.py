@@ -1,4 +1,4 @@
-"""How evenly does the colour backward's work fall on the 1 024 SIMDs?  
+"""How evenly does the colour backward's work fall on the 1 024 SIMDs?  (docs/EXPERIMENTS.md section 7, round 3.)
 One wave per tile, every tile resident at once (8 160 waves on 8 192 slots at 1080p): the kernel ends when the most loaded SIMD is done.
 Per-tile work from the deterministic backward's slab (which list entries were PROCESSED, = reduced and added) and from the forward's
 n_contrib (how far each tile's list is WALKED): cost model 230 instructions per processed entry, 60 per walked-only entry (ISA counts).

@@ -1,4 +1,4 @@
-"""How much would a 32 x 16 super-tile backward share?  (the measured basis of the bound on VERDICT item 3.)
+"""How much would a 32 x 16 super-tile backward share?  (docs/EXPERIMENTS.md section 7, round 3: the measured basis of the bound on VERDICT item 3.)
 Runs the C3 colour backward in deterministic mode, whose slab holds one row per (list entry, wave of its tile) -- rows the backward never
 wrote stay zero -- and counts, among the PROCESSED (Gaussian, tile) entries, those whose Gaussian is also processed in the horizontal
 partner tile (tiles 2k, 2k + 1 of a row) and in the vertical one."""

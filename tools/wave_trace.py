@@ -1,4 +1,4 @@
-"""Where and when did the waves of the blend kernels run?  (diagnostic build)
+"""Where and when did the waves of the blend kernels run?  (diagnostic build, docs/EXPERIMENTS.md section 7 round 3)
 Builds a copy of the library with -DIBGS_TRACE_WAVES (every workgroup of render_fwd_kernel / render_bwd_color_kernel stamps its SIMD and its
 start / end on the 100 MHz clock), runs C3 forward + backward once, and reports per kernel: how many waves each SIMD got, when the SIMDs
 finished relative to the kernel's span (a SIMD that is done at 60 % idles for the rest), i.e. what perfect balance could buy.
