@@ -59,6 +59,7 @@ class ForwardArgs(ctypes.Structure):
         ("n_views", ctypes.c_int32), ("view_tanfovx", ctypes.c_float * 8), ("view_tanfovy", ctypes.c_float * 8),
         ("tile_order_hint", ctypes.c_void_p),
         ("binning", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
+        ("shs_rest", c_float_p),
     ]
 
 
@@ -104,6 +105,7 @@ class BackwardArgs(ctypes.Structure):
         ("det_scratch", ctypes.c_void_p), ("det_scratch_bytes", ctypes.c_size_t),
         ("buffer_length", ctypes.c_int32),
         ("tile_order_out", ctypes.c_void_p),
+        ("shs_rest", c_float_p), ("dL_dsh_rest", c_float_p),
     ]
 
 

@@ -332,6 +332,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     // rows of 16 coefficients are fetched with 16-byte loads (preprocess.hip, preprocess_bwd.hip): the base must be 16-byte aligned (any torch
     // allocation is; a view that starts in the middle of one may not be)
     if (a.shs && a.M == 16 && (reinterpret_cast<uintptr_t>(a.shs) & 15u)) { set_error("shs (M = 16) must be 16-byte aligned"); return -IBGS_ERR_INVALID; }
+    if (a.shs_rest && (!a.shs || a.M < 2 || (reinterpret_cast<uintptr_t>(a.shs_rest) & 15u) || (reinterpret_cast<uintptr_t>(a.shs) & 15u))) {
+        set_error("shs_rest needs shs (the DC coefficients), M >= 2 and 16-byte aligned arrays"); return -IBGS_ERR_INVALID;
+    }
     if (a.render_geo && a.render_depth_only) { set_error("render_geo together with render_depth_only is not supported"); return -IBGS_ERR_INVALID; }
     if (a.plane_mode != IBGS_PLANE_NONE) {
         if (a.all_map) { set_error("give either all_map or plane_mode, not both"); return -IBGS_ERR_INVALID; }
@@ -503,6 +506,10 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         set_error("missing gradient output"); return -IBGS_ERR_INVALID;
     }
     if (a.shs && !a.dL_dsh && !(a.flags & IBGS_FLAG_SH_FACTORED)) { set_error("dL_dsh required"); return -IBGS_ERR_INVALID; }
+    if (a.shs_rest && (!a.shs || a.M < 2 || (!(a.flags & IBGS_FLAG_SH_FACTORED) && !a.dL_dsh_rest)
+                       || ((reinterpret_cast<uintptr_t>(a.shs_rest) | reinterpret_cast<uintptr_t>(a.shs) | reinterpret_cast<uintptr_t>(a.dL_dsh_rest) | reinterpret_cast<uintptr_t>(a.dL_dsh)) & 15u))) {
+        set_error("shs_rest needs shs, M >= 2, dL_dsh_rest and 16-byte aligned arrays"); return -IBGS_ERR_INVALID;
+    }
     if (a.shs && a.M == 16 && ((reinterpret_cast<uintptr_t>(a.shs) & 15u) || (a.dL_dsh && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u)))) {
         set_error("shs / dL_dsh (M = 16) must be 16-byte aligned"); return -IBGS_ERR_INVALID;
     }

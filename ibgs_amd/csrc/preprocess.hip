@@ -27,7 +27,8 @@ __constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 struct PreParams {
     int P, D, M;
     const float* means3D; const float* scales; const float* rotations; const float* opacities;
-    const float* shs; const float* cov3D_precomp; const float* colors_precomp; const float* all_map;
+    const float* shs; const float* shs_rest;          // shs_rest != nullptr: shs holds the DC coefficient (P x 1 x 3), shs_rest the other M - 1 (P x (M - 1) x 3)
+    const float* cov3D_precomp; const float* colors_precomp; const float* all_map;
     const float* plane_normal; const float* plane_offset; int plane_mode;
     int inst0;          // batched views: index of this view's first instance in the per-instance outputs (view * P)
     int tile_row0;      // ... and its first row in the stacked tile grid (view * ceil(H/16))
@@ -260,7 +261,12 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
                     float shv[48];
                     const float* sh = p.shs + (size_t)i * p.M * 3;
                     const int need = 3 * nb;
-                    if (p.M == 16) {
+                    if (p.shs_rest) {          // DC and the rest in two arrays (the model's f_dc / f_rest as they are): plain per-lane loads
+                        const float* sr = p.shs_rest + (size_t)i * (p.M - 1) * 3;
+                        const float* sd = p.shs + (size_t)i * 3;
+#pragma unroll
+                        for (int k = 0; k < 48; k++) if (k < need) shv[k] = k < 3 ? sd[k] : sr[k - 3];
+                    } else if (p.M == 16) {
                         const float4* r4 = reinterpret_cast<const float4*>(sh);
 #pragma unroll
                         for (int v = 0; v < 12; v++) {
@@ -425,7 +431,55 @@ __global__ void __launch_bounds__(256) sh_color_kernel(PreParams p, Cam cam)
     const int nb = (D + 1) * (D + 1);
     const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
     float shv[48];
-    if (M == 16) {
+    if (p.shs_rest && M == 16 && first + 64 <= p.P) {
+        // DC and the rest in two arrays (the reference model's `_features_dc` (P, 1, 3) and `_features_rest` (P, 15, 3) as they are: no torch.cat, no
+        // second copy of 192 B per Gaussian).  Same scheme as below: the wave's 64 rows are one contiguous block per array -- 64 x 180 B = 720 float4 of
+        // rest, 64 x 12 B = 48 float4 of DC, 768 = 12 x 64 pieces, all loads coalesced and in flight together -- parked in LDS in two rounds of 32 rows
+        // (360 + 24 = 384 = 6 x 64 pieces per round), in the SAME row layout [dc(3), rest(45)], so everything behind the transpose is unchanged.  A piece
+        // straddles rows (45 floats per row), so it is scattered word by word.  Pieces that hold nothing a live Gaussian needs at this degree are skipped.
+        const float4* rest4 = reinterpret_cast<const float4*>(p.shs_rest + (size_t)first * 45);
+        const float4* dc4 = reinterpret_cast<const float4*>(p.shs + (size_t)first * 3);
+        const int nrest = 3 * nb - 3;          // floats of a rest row the active degree reads
+        float4 v[12];
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int h = it / 6, qp = (it % 6) * 64 + lane;          // piece of round h
+            bool need = false;
+            if (qp < 360) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = 4 * qp + k, r = e / 45, c = e - 45 * r; need = need || (((alive_m >> (32 * h + r)) & 1ull) && c < nrest); }
+                v[it] = need ? rest4[360 * h + qp] : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = 4 * (qp - 360) + k; need = need || ((alive_m >> (32 * h + e / 3)) & 1ull); }
+                v[it] = need ? dc4[24 * h + (qp - 360)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int qp = it * 64 + lane;
+                const float4 q = v[h * 6 + it];
+                const float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (qp < 360) { const int e = 4 * qp + k, r = e / 45, c = e - 45 * r; s_sh[r * SHC_ROW + 3 + c] = f[k]; }
+                    else { const int e = 4 * (qp - 360) + k, r = e / 3, c = e - 3 * r; s_sh[r * SHC_ROW + c] = f[k]; }
+                }
+            }
+            if ((lane >> 5) == h) {
+                const float4* row4 = reinterpret_cast<const float4*>(s_sh + (lane & 31) * SHC_ROW);
+#pragma unroll
+                for (int k = 0; k < 12; k++) { const float4 q = row4[k]; shv[4 * k] = q.x; shv[4 * k + 1] = q.y; shv[4 * k + 2] = q.z; shv[4 * k + 3] = q.w; }
+            }
+        }
+    } else if (p.shs_rest) {          // other coefficient counts / the last, partial wave: plain per-lane loads from the two arrays
+        const float* sr = p.shs_rest + (size_t)i * (M - 1) * 3;
+        const float* sd = p.shs + (size_t)i * 3;
+#pragma unroll
+        for (int k = 0; k < 48; k++) shv[k] = (alive && k < 3 * nb) ? (k < 3 ? sd[k] : sr[k - 3]) : 0.f;
+    } else if (M == 16) {
         const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)first * 12;
         const int nq = min(64, p.P - first) * 12;          // float4 pieces of this wave's block
         float4 v[12];
@@ -517,7 +571,7 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     PreParams p;
     p.P = a.P; p.D = a.D; p.M = a.M;
     p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
-    p.shs = a.shs; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
+    p.shs = a.shs; p.shs_rest = a.shs_rest; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
     p.plane_normal = a.plane_normal; p.plane_offset = a.plane_offset; p.plane_mode = a.plane_mode;
     p.scale_modifier = a.scale_modifier; p.depth_only = a.render_depth_only;
     p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.fp = g.fp; p.tmask_hi = g.tmask_hi;

@@ -20,14 +20,14 @@ __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 
 struct PreBwdParams {
     int P, D, M;
-    const float* means3D; const int32_t* radii; const float* shs; const uint8_t* clamped;
+    const float* means3D; const int32_t* radii; const float* shs; const float* shs_rest; const uint8_t* clamped;          // shs_rest: see ibgs_backward_args
     const float* scales; const float* rotations; float scale_modifier;
     const float* cov3D;        // precomputed input or the forward's computed one
     float* gacc;               // P x 16 moment rows written by render_bwd.hip (re-zeroed here when clear_gacc)
     int clear_gacc;
     const float* rec;          // P x 16 forward records (conic, opacity)
     float* dL_dmean2D; float* dL_dmean2D_abs; float* dL_dconic; float* dL_dopacity; float* dL_dcolors;
-    float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+    float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dsh_rest; float* dL_dscale; float* dL_drot;
     const float* plane_normal; const float* plane_offset; int plane_mode;     // fused plane-map glue (common.h)
     float* dL_dplane_normal; float* dL_dplane_offset;
 };
@@ -101,11 +101,64 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         if (p.dL_dplane_offset) p.dL_dplane_offset[i] = 0.f;
         p.dL_dmean3D[3 * i] = 0.f; p.dL_dmean3D[3 * i + 1] = 0.f; p.dL_dmean3D[3 * i + 2] = 0.f;
         if (p.dL_dcov3D) for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
-        if (!FAST16 && WRITE_SH && p.shs) { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
+        if (!FAST16 && WRITE_SH && p.shs) {
+            if (p.shs_rest) {
+                float* gd = p.dL_dsh + (size_t)i * 3; float* gr = p.dL_dsh_rest + (size_t)i * (p.M - 1) * 3;
+                gd[0] = gd[1] = gd[2] = 0.f;
+                for (int k = 0; k < 3 * (p.M - 1); k++) gr[k] = 0.f;
+            } else { float* gsh = p.dL_dsh + (size_t)i * p.M * 3; for (int k = 0; k < 3 * p.M; k++) gsh[k] = 0.f; }
+        }
         if (p.scales) {
             p.dL_dscale[3 * i] = 0.f; p.dL_dscale[3 * i + 1] = 0.f; p.dL_dscale[3 * i + 2] = 0.f;
             p.dL_drot[4 * i] = 0.f; p.dL_drot[4 * i + 1] = 0.f; p.dL_drot[4 * i + 2] = 0.f; p.dL_drot[4 * i + 3] = 0.f;
         }
+    }
+    if (FAST16 && p.shs_rest && p.shs) {
+        // DC and the rest in two arrays (ibgs_backward_args.shs_rest): the wave's 64 rows are one contiguous block per array (720 + 48 float4 = 12 x 64
+        // pieces), fetched with coalesced 16-B loads -- pieces that hold nothing of a Gaussian that needs its coefficients are skipped -- and scattered
+        // word by word into the rows [dc(3), rest(45)] of the transpose buffer, from which each lane then reads its own row (the combined layout's per-lane
+        // 16-B loads need 16-byte aligned rows; 180-byte rows are not).  Full blocks only: the last, partial block is not FAST16's (launcher).
+        const int lane = threadIdx.x;
+        const uint64_t vism = __builtin_amdgcn_ballot_w64(vis);
+        const int i0 = blockIdx.x * 64;
+        const float4* rest4 = reinterpret_cast<const float4*>(p.shs_rest + (size_t)i0 * 45);
+        const float4* dc4 = reinterpret_cast<const float4*>(p.shs + (size_t)i0 * 3);
+        float* s_w = reinterpret_cast<float*>(s_t);
+        const int nrows = min(64, p.P - i0);          // (the last block may be partial: its pieces end with the arrays; lanes beyond them are not `vis`)
+        float4 v[12];
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int q = it * 64 + lane;
+            bool need = false;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 720) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) need = need || ((vism >> ((4 * q + k) / 45)) & 1ull);
+                if (need) {
+                    if (4 * q + 3 < nrows * 45) v[it] = rest4[q];
+                    else { const float* sp = p.shs_rest + (size_t)i0 * 45; float* f = &v[it].x; for (int k = 0; k < 4; k++) if (4 * q + k < nrows * 45) f[k] = sp[4 * q + k]; }
+                }
+            } else {
+                const int qd = q - 720;
+#pragma unroll
+                for (int k = 0; k < 4; k++) need = need || ((vism >> ((4 * qd + k) / 3)) & 1ull);
+                if (need) {
+                    if (4 * qd + 3 < nrows * 3) v[it] = dc4[qd];
+                    else { const float* sp = p.shs + (size_t)i0 * 3; float* f = &v[it].x; for (int k = 0; k < 4; k++) if (4 * qd + k < nrows * 3) f[k] = sp[4 * qd + k]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int q = it * 64 + lane;
+            const float f[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (q < 720) { const int e = 4 * q + k, r = e / 45, c = e - 45 * r; s_w[r * 52 + 3 + c] = f[k]; }
+                else { const int e = 4 * (q - 720) + k, r = e / 3, c = e - 3 * r; s_w[r * 52 + c] = f[k]; }
+            }
+        }
+        __syncthreads();
     }
     if (vis) {
 
@@ -256,13 +309,19 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         const float dorig[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
         const float len = sqrtf(dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2]);
         const float x = dorig[0] / len, y = dorig[1] / len, z = dorig[2] / len;
-        const float* shg = p.shs + (size_t)i * p.M * 3;
+        const float* shg = p.shs + (size_t)i * (p.shs_rest ? 1 : p.M) * 3;          // (split: the DC row; SHK reads the others from shs_rest)
         float* gsh = p.dL_dsh + (size_t)i * p.M * 3;
         float shv[FAST16 ? 48 : 1];
         if (FAST16) {
-            const float4* r4 = reinterpret_cast<const float4*>(shg);
+            if (p.shs_rest) {          // staged by the whole wave before this branch (below the kernel's head): the lane's row [dc(3), rest(45)] out of LDS
+                const float4* row4 = s_t + (size_t)threadIdx.x * 13;
 #pragma unroll
-            for (int v = 0; v < 12; v++) { const float4 q = r4[v]; shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w; }
+                for (int v = 0; v < 12; v++) { const float4 q = row4[v]; shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w; }
+            } else {
+                const float4* r4 = reinterpret_cast<const float4*>(shg);
+#pragma unroll
+                for (int v = 0; v < 12; v++) { const float4 q = r4[v]; shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w; }
+            }
         }
         const uint8_t cb = p.clamped[i];
         float g[3];
@@ -279,6 +338,11 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
             for (int k = 0; k < 16; k++) {
                 if (k < nb) { gv[3 * k] = B[k] * g[0]; gv[3 * k + 1] = B[k] * g[1]; gv[3 * k + 2] = B[k] * g[2]; }
             }
+        } else if (p.shs_rest) {
+            float* gd = p.dL_dsh + (size_t)i * 3; float* gr = p.dL_dsh_rest + (size_t)i * (p.M - 1) * 3;
+            gd[0] = B[0] * g[0]; gd[1] = B[0] * g[1]; gd[2] = B[0] * g[2];
+            for (int k = 1; k < nb; k++) { gr[3 * (k - 1)] = B[k] * g[0]; gr[3 * (k - 1) + 1] = B[k] * g[1]; gr[3 * (k - 1) + 2] = B[k] * g[2]; }
+            for (int k = 3 * (nb - 1); k < 3 * (p.M - 1); k++) gr[k] = 0.f;
         } else {
             for (int k = 0; k < nb; k++) {
                 gsh[3 * k] = B[k] * g[0]; gsh[3 * k + 1] = B[k] * g[1]; gsh[3 * k + 2] = B[k] * g[2];
@@ -288,7 +352,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         float gd[3] = {0, 0, 0};
         if (D > 0) {
             float dx3[3], dy3[3], dz3[3];
-#define SHK(k, ch) (FAST16 ? shv[3 * (k) + (ch)] : shg[3 * (k) + (ch)])
+#define SHK(k, ch) (FAST16 ? shv[3 * (k) + (ch)] : ((p.shs_rest && (k) > 0) ? p.shs_rest[((size_t)i * (p.M - 1) + ((k) - 1)) * 3 + (ch)] : shg[3 * (k) + (ch)]))
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 dx3[ch] = -bC1 * SHK(3, ch); dy3[ch] = -bC1 * SHK(1, ch); dz3[ch] = bC1 * SHK(2, ch);
@@ -353,7 +417,38 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     }
     }   // vis
 
-    if (FAST16 && WRITE_SH && p.shs) {
+    if (FAST16 && WRITE_SH && p.shs && p.shs_rest) {
+        // ... and out again the same way: rows [dc(3), rest(45)] into the transpose buffer, the block's two contiguous pieces of dL/dsh (48 + 720 float4)
+        // gathered word by word and stored with coalesced 16-B writes
+        const int lane = threadIdx.x;
+        __syncthreads();          // (every lane has read its coefficient row)
+#pragma unroll
+        for (int v = 0; v < 12; v++) s_t[lane * 13 + v] = make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
+        __syncthreads();
+        const int i0 = blockIdx.x * 64;
+        const float* s_w = reinterpret_cast<const float*>(s_t);
+        float4* dr = reinterpret_cast<float4*>(p.dL_dsh_rest + (size_t)i0 * 45);
+        float4* dd = reinterpret_cast<float4*>(p.dL_dsh + (size_t)i0 * 3);
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int q = it * 64 + lane;
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (q < 720) { const int e = 4 * q + k, r = e / 45, c = e - 45 * r; f[k] = s_w[r * 52 + 3 + c]; }
+                else { const int e = 4 * (q - 720) + k, r = e / 3, c = e - 3 * r; f[k] = s_w[r * 52 + c]; }
+            }
+            const int nrows = min(64, p.P - i0);
+            if (q < 720) {
+                if (4 * q + 3 < nrows * 45) dr[q] = make_float4(f[0], f[1], f[2], f[3]);
+                else { float* op = p.dL_dsh_rest + (size_t)i0 * 45; for (int k = 0; k < 4; k++) if (4 * q + k < nrows * 45) op[4 * q + k] = f[k]; }
+            } else {
+                const int qd = q - 720;
+                if (4 * qd + 3 < nrows * 3) dd[qd] = make_float4(f[0], f[1], f[2], f[3]);
+                else { float* op = p.dL_dsh + (size_t)i0 * 3; for (int k = 0; k < 4; k++) if (4 * qd + k < nrows * 3) op[4 * qd + k] = f[k]; }
+            }
+        }
+    } else if (FAST16 && WRITE_SH && p.shs) {
         const int lane = threadIdx.x;
 #pragma unroll
         for (int v = 0; v < 12; v++) s_t[lane * 13 + v] = make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
@@ -374,13 +469,13 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
 {
     PreBwdParams p;
     p.P = a.P; p.D = a.D; p.M = a.M;
-    p.means3D = a.means3D; p.radii = a.radii; p.shs = a.shs; p.clamped = g.clamped;
+    p.means3D = a.means3D; p.radii = a.radii; p.shs = a.shs; p.shs_rest = a.shs_rest; p.clamped = g.clamped;
     p.scales = a.scales; p.rotations = a.rotations; p.scale_modifier = a.scale_modifier;
     p.cov3D = a.cov3D_precomp ? a.cov3D_precomp : g.cov3D;
     p.gacc = a.grad_acc; p.rec = g.rec; p.clear_gacc = (a.flags & IBGS_FLAG_CLEAR_GRAD_ACC) ? 1 : 0;
     p.dL_dmean2D = a.dL_dmean2D; p.dL_dmean2D_abs = a.dL_dmean2D_abs; p.dL_dconic = a.dL_dconic;
     p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
-    p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;
+    p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dsh_rest = a.dL_dsh_rest; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;
     p.plane_normal = a.plane_normal; p.plane_offset = a.plane_offset; p.plane_mode = a.plane_mode;
     p.dL_dplane_normal = a.dL_dplane_normal; p.dL_dplane_offset = a.dL_dplane_offset;
     const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);

@@ -367,9 +367,10 @@ class _CModule:
                             cov3D_precomp, all_map, viewmatrix, projmatrix, ref_to_src_list, src_cam_pos,
                             src_images, src_rendered_depths, nb_src_images, buffer_length,
                             depth_error_threshold, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, render_geo, render_depth_only, debug, plane=None):
+                            campos, prefiltered, render_geo, render_depth_only, debug, plane=None, sh_rest=None):
         """The reference's 29 positional arguments; `plane` = (raw_normal or None, raw_offset or None, mode) is this
-        library's extension (fused plane-map glue, include/ibgs_rast.h) and replaces `all_map`."""
+        library's extension (fused plane-map glue, include/ibgs_rast.h) and replaces `all_map`; `sh_rest`: `sh` holds the DC coefficient only
+        (P, 1, 3) and `sh_rest` the others (P, M - 1, 3) -- the model's two arrays instead of their torch.cat (ibgs_forward_args.shs_rest)."""
         lib = _lib.load()
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:69-71
@@ -383,6 +384,7 @@ class _CModule:
             stream = torch.cuda.current_stream(device).cuda_stream
             means3D_c = _dev_f32(means3D, device)
             sh_c = _dev_f32(sh, device); colors_c = _dev_f32(colors, device)
+            sh_rest_c = _dev_f32(sh_rest, device) if sh_rest is not None else None
             opacity_c = _dev_f32(opacity, device)
             scales_c = _dev_f32(scales, device); rot_c = _dev_f32(rotations, device)
             cov_c = _dev_f32(cov3D_precomp, device); all_map_c = _dev_f32(all_map, device)
@@ -425,13 +427,13 @@ class _CModule:
             imgBuffer = torch.empty(0, dtype=torch.uint8, device=device)
             rendered = 0
             if P != 0:
-                M = 0 if sh_c is None else int(sh_c.size(1))
+                M = 0 if sh_c is None else int(sh_c.size(1)) + (int(sh_rest_c.size(1)) if sh_rest_c is not None else 0)
                 geomBuffer = torch.empty(lib.ibgs_required_geom(P), dtype=torch.uint8, device=device)
                 imgBuffer = torch.empty(lib.ibgs_required_img(W, H), dtype=torch.uint8, device=device)
                 a, holder, cb = _call_state.forward_args(device)
                 a.stream = stream
                 a.P, a.D, a.M, a.W, a.H = P, int(degree), M, W, H
-                a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c)
+                a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c); a.shs_rest = _ptr(sh_rest_c)
                 a.opacities = _ptr(opacity_c); a.scales = _ptr(scales_c); a.rotations = _ptr(rot_c)
                 a.cov3D_precomp = _ptr(cov_c); a.all_map = _ptr(all_map_c)
                 if plane is not None and plane[2]:
@@ -518,7 +520,7 @@ class _CModule:
                                      src_images, src_rendered_depths, nb_src_images, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_normal_map, dL_dout_median_intersected_depth,
                                      dL_dout_warped_image, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False, buffer_length=0, want_abs=True):
+                                     imageBuffer, render_geo, debug, plane=None, packed_tex=None, skip_unused=False, buffer_length=0, want_abs=True, sh_rest=None):
         """The reference's 34 positional arguments and 10 results; with `plane` (see rasterize_gaussians) two more
         results follow: dL/d raw normal (P, 3) and dL/d raw offset (P, 1).  `buffer_length` (the forward's; not among the reference's
         arguments, 0 = unknown) only sizes the geo backward's scratch table."""
@@ -530,7 +532,9 @@ class _CModule:
         with _on_device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             sh_c = _dev_f32(sh, device)
-            M = int(sh.size(1)) if sh.dim() == 3 else 0     # keeps (0, M, 3) for P == 0 so autograd accepts the shape
+            sh_rest_c = _dev_f32(sh_rest, device) if sh_rest is not None else None
+            M_dc = int(sh.size(1)) if sh.dim() == 3 else 0     # keeps (0, M, 3) for P == 0 so autograd accepts the shape
+            M = M_dc + (int(sh_rest.size(1)) if sh_rest is not None else 0)          # (sh_rest: `sh` is the DC coefficient alone, see rasterize_gaussians)
             opts = dict(dtype=torch.float32, device=device)
             # ibgs_backward overwrites every element of its outputs (zeros for invisible Gaussians): no memsets
             have_sr = scales is not None and scales.numel() != 0
@@ -555,7 +559,8 @@ class _CModule:
             want_cov = not skip_unused or not have_sr
             dL_dcolors = new(P, NUM_CHANNELS, **opts) if want_colors else _zeros_view((P, NUM_CHANNELS), device)
             dL_dcov3D = new(P, 6, **opts) if want_cov else _zeros_view((P, 6), device)
-            dL_dsh = None if factored else new(P, M, 3, **opts)
+            dL_dsh = None if factored else new(P, M_dc, 3, **opts)
+            dL_dsh_rest = None if (factored or sh_rest is None) else new(P, M - M_dc, 3, **opts)
             dL_dscales = _sink_or_new("scales", (P, 3), new, opts) if (have_sr and P != 0) else _zeros_view((P, 3), device)
             dL_drotations = _sink_or_new("rotations", (P, 4), new, opts) if (have_sr and P != 0) else _zeros_view((P, 4), device)
             if P != 0:
@@ -579,7 +584,7 @@ class _CModule:
                 a.stream = stream
                 a.P, a.D, a.M, a.W, a.H = P, int(degree), M, W, H
                 a.R = int(R)
-                a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c)
+                a.means3D = _ptr(means3D_c); a.shs = _ptr(sh_c); a.colors_precomp = _ptr(colors_c); a.shs_rest = _ptr(sh_rest_c)
                 a.scales = _ptr(scales_c); a.rotations = _ptr(rot_c); a.cov3D_precomp = _ptr(cov_c); a.all_map = _ptr(all_map_c)
                 a.scale_modifier = float(scale_modifier)
                 a.bg = _ptr(bg_c); a.viewmatrix = _ptr(vm_c); a.projmatrix = _ptr(pm_c); a.campos = _ptr(campos_c)
@@ -609,6 +614,7 @@ class _CModule:
                 a.dL_dopacity = dL_dopacity.data_ptr(); a.dL_dcolors = dL_dcolors.data_ptr() if want_colors else None
                 a.dL_dmean3D = dL_dmeans3D.data_ptr(); a.dL_dcov3D = dL_dcov3D.data_ptr() if want_cov else None
                 a.dL_dsh = dL_dsh.data_ptr() if (M and not factored) else None
+                a.dL_dsh_rest = dL_dsh_rest.data_ptr() if dL_dsh_rest is not None else None
                 a.dL_dscale = dL_dscales.data_ptr() if have_sr else None; a.dL_drot = dL_drotations.data_ptr() if have_sr else None
                 a.dL_dall_map = dL_dall_map.data_ptr() if (render_geo and all_maps.numel() != 0 and not fused) else None
                 if fused and render_geo:
@@ -646,7 +652,11 @@ class _CModule:
                     _sh_factor_sink.append({"dcolor": dL_dcolors, "campos": campos_c.reshape(3), "degree": int(degree), "M": M})
         res = (dL_dmeans2D, dL_dmeans2D_abs, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                dL_dscales, dL_drotations, dL_dall_map)
-        return res + (dL_dplane_normal, dL_dplane_offset) if plane is not None else res
+        if plane is not None or sh_rest is not None:          # the extensions' results follow the reference's ten: plane normal, plane offset, SH rest
+            res = res + (dL_dplane_normal, dL_dplane_offset)
+            if sh_rest is not None:
+                res = res + (dL_dsh_rest,)
+        return res
 
     @staticmethod
     def mark_visible(means3D, viewmatrix, projmatrix):
@@ -668,9 +678,9 @@ _C = _CModule()
 
 
 def rasterize_gaussians(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
-                        cov3Ds_precomp, all_map, raster_settings, plane_normal=None, plane_offset=None, plane_mode=0):
+                        cov3Ds_precomp, all_map, raster_settings, plane_normal=None, plane_offset=None, plane_mode=0, sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales,
-                                     rotations, cov3Ds_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode)
+                                     rotations, cov3Ds_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode, sh_rest)
 
 
 def rasterize_depth_batch(means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, viewmatrices, projmatrices,
@@ -752,9 +762,11 @@ _EMPTY = torch.Tensor([])          # never written, never returned: the stand-in
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,
-                cov3Ds_precomp, all_maps, raster_settings, plane_normal=None, plane_offset=None, plane_mode=0):
+                cov3Ds_precomp, all_maps, raster_settings, plane_normal=None, plane_offset=None, plane_mode=0, sh_rest=None):
         plane = (plane_normal, plane_offset, int(plane_mode)) if plane_mode else None
         kw = {"plane": plane} if plane is not None else {}
+        if sh_rest is not None:
+            kw["sh_rest"] = sh_rest
         # argument order of the reference's _C.rasterize_gaussians (reference __init__.py:66-98)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -791,7 +803,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(out_normal_map, out_median_intersected_depth, out_warped_image, colors_precomp,
                               all_maps, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               plane_normal if plane_normal is not None else none, plane_offset if plane_offset is not None else none,
+                              sh_rest if sh_rest is not None else none,
                               geomBuffer, binningBuffer, imgBuffer)
+        ctx.has_sh_rest = sh_rest is not None
         ctx.mark_non_differentiable(radii, out_use_first_src_frame)
         return (color, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
                 out_min_depth_diff, out_camera_ray, out_use_first_src_frame)
@@ -803,8 +817,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
         (normal_map_pixels, median_intersected_depth_pixels, warped_image_pixels, colors_precomp, all_maps, means3D,
-         scales, rotations, cov3Ds_precomp, radii, sh, plane_normal, plane_offset, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
+         scales, rotations, cov3Ds_precomp, radii, sh, plane_normal, plane_offset, sh_rest, geomBuffer, binningBuffer, imgBuffer) = ctx.saved_tensors
         kw = {}
+        if ctx.has_sh_rest:
+            kw["sh_rest"] = sh_rest
         if ctx.plane_mode:
             kw["plane"] = (plane_normal if plane_normal.numel() else None, plane_offset if plane_offset.numel() else None, ctx.plane_mode)
         if getattr(ctx, "packed_tex", None) is not None:
@@ -836,8 +852,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_means2D_abs, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
          grad_sh, grad_scales, grad_rotations, grad_all_map) = res[:10]
         grad_plane_normal, grad_plane_offset = (res[10], res[11]) if ctx.plane_mode else (None, None)
+        grad_sh_rest = res[12] if ctx.has_sh_rest else None
         return (grad_means3D, grad_means2D, grad_means2D_abs, grad_sh, grad_colors_precomp, grad_opacities,
-                grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_all_map, None, grad_plane_normal, grad_plane_offset, None)
+                grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_all_map, None, grad_plane_normal, grad_plane_offset, None, grad_sh_rest)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -877,9 +894,12 @@ class GaussianRasterizer(nn.Module):
         return visible
 
     def forward(self, means3D, means2D, means2D_abs, opacities, shs=None, colors_precomp=None, scales=None,
-                rotations=None, cov3D_precomp=None, all_map=None, plane_normal=None, plane_offset=None, plane_mode=0):
+                rotations=None, cov3D_precomp=None, all_map=None, plane_normal=None, plane_offset=None, plane_mode=0, shs_rest=None):
         """Reference signature plus the fused plane-map extension: instead of `all_map` pass the raw `_normal` /
-        `_offset` parameters with plane_mode=1 (learnt normals) or plane_mode=2 (normal = smallest-scale axis)."""
+        `_offset` parameters with plane_mode=1 (learnt normals) or plane_mode=2 (normal = smallest-scale axis) -- and `shs_rest`: the SH
+        coefficients as the model's two arrays, `shs` = `_features_dc` (P, 1, 3) and `shs_rest` = `_features_rest` (P, M - 1, 3), instead of their torch.cat."""
+        if shs_rest is not None and (shs is None or shs.dim() != 3 or int(shs.shape[1]) != 1 or shs_rest.dim() != 3):
+            raise Exception('shs_rest needs shs = the DC coefficients (P, 1, 3)')
         raster_settings = self.raster_settings
         if plane_mode and all_map is not None:
             raise Exception('Please provide either all_map or plane_mode, not both!')
@@ -906,4 +926,4 @@ class GaussianRasterizer(nn.Module):
             all_map = _EMPTY
 
         return rasterize_gaussians(means3D, means2D, means2D_abs, shs, colors_precomp, opacities, scales,
-                                   rotations, cov3D_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode)
+                                   rotations, cov3D_precomp, all_map, raster_settings, plane_normal, plane_offset, plane_mode, shs_rest)

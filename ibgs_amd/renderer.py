@@ -119,6 +119,12 @@ def _plane_map(pc, viewpoint_camera, learnt_normal, means3D):
     return all_map
 
 
+# SH coefficients handed to the rasterizer as the model's two arrays (`_features_dc`, `_features_rest`) instead of `pc.get_features` = their torch.cat
+# (scene/gaussian_model.py:140-143): no 192-byte-per-Gaussian copy per call, and none for the gradient on the way back.  Bit-identical results
+# (tests/test_gpu_sh_split.py).  False = the reference's expression.
+SPLIT_SH = True
+
+
 def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
@@ -135,10 +141,19 @@ def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
             dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
             colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
         else:
-            shs = pc.get_features
+            dc, rest = getattr(pc, "_features_dc", None), getattr(pc, "_features_rest", None)
+            if (SPLIT_SH and torch.is_tensor(dc) and torch.is_tensor(rest) and dc.is_cuda and dc.dim() == 3 and rest.dim() == 3 and dc.shape[1] == 1
+                    and rest.shape[1] >= 1 and dc.is_contiguous() and rest.is_contiguous() and dc.dtype == torch.float32 and rest.dtype == torch.float32):
+                shs = (dc, rest)          # (render / render_depth unpack it into shs= / shs_rest=)
+            else:
+                shs = pc.get_features
     else:
         colors_precomp = override_color
     return scales, rotations, cov3D_precomp, shs, colors_precomp
+
+
+def _sh_kw(shs):
+    return dict(shs=shs[0], shs_rest=shs[1]) if isinstance(shs, tuple) else dict(shs=shs)
 
 
 # The |dL/dmean2D| statistic (viewspace_points_abs.grad) has one reader, densification (train.py:400-410, until densify_until_iter).  A trainer
@@ -224,7 +239,7 @@ def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor
         campos=viewpoint_camera.camera_center, prefiltered=False, render_geo=False, render_depth_only=True,
         debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    outs = rasterizer(means3D=means3D, means2D=means2D, means2D_abs=means2D_abs, shs=shs,
+    outs = rasterizer(means3D=means3D, means2D=means2D, means2D_abs=means2D_abs, **_sh_kw(shs),
                       colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, **_plane_inputs(pc, viewpoint_camera, learnt_normal, means3D, scales, rotations))
     return outs[3]
@@ -396,7 +411,7 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
 
     (rendered_image, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
      out_min_depth_diff, out_camera_ray, use_first_src_frame_mask) = rasterizer(
-        means3D=means3D, means2D=screenspace_points, means2D_abs=screenspace_points_abs, shs=shs,
+        means3D=means3D, means2D=screenspace_points, means2D_abs=screenspace_points_abs, **_sh_kw(shs),
         colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
         cov3D_precomp=cov3D_precomp, **plane_kw)
 

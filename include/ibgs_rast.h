@@ -196,6 +196,11 @@ typedef struct ibgs_forward_args {
      * hint, and the repeated pass after a too small hint, still call binning_alloc.  The arena the lists ended up in is `binning` iff the return value
      * R <= rendered_hint and this field was large enough. */
     char* binning; size_t binning_bytes;
+    /* Optional: the SH coefficients in the reference MODEL's two arrays instead of their concatenation.  shs_rest != NULL: `shs` holds the DC coefficient only
+     * (P x 1 x 3, `_features_dc`) and `shs_rest` the other M - 1 (P x (M - 1) x 3, `_features_rest`); M stays the total count.  Saves the caller the
+     * torch.cat of scene/gaussian_model.py:140-143 (192 B read + written per Gaussian and call at M = 16, and its mirror image in the backward).  Both 16-byte aligned.
+     * Results are bit-identical to the concatenated form. */
+    const float* shs_rest;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {
@@ -270,6 +275,10 @@ typedef struct ibgs_backward_args {
     /* optional (may be NULL): ibgs_tile_order_slots(W, H) words that receive the order in which a colour backward launched its tiles, i.e.
      * what ibgs_forward_args.tile_order_hint of the same camera's next forward wants (the same words also land in the image arena) */
     uint32_t* tile_order_out;
+    /* SH coefficients in two arrays (see ibgs_forward_args.shs_rest): then dL_dsh receives the DC gradient (P x 1 x 3) and dL_dsh_rest the rest
+     * (P x (M - 1) x 3); both fully overwritten.  With IBGS_FLAG_SH_FACTORED neither is written. */
+    const float* shs_rest;
+    float* dL_dsh_rest;
 } ibgs_backward_args;
 
 size_t ibgs_required_deterministic(int64_t R, int32_t P);          /* any frame, any flags: four rows per list entry */

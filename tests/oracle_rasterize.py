@@ -42,7 +42,9 @@ class _OracleRasterize(torch.autograd.Function):
 
 
 def oracle_rasterize(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, raster_settings,
-                     plane_normal=None, plane_offset=None, plane_mode=0):
+                     plane_normal=None, plane_offset=None, plane_mode=0, sh_rest=None):
+    if sh_rest is not None:          # the model's two SH arrays (rasterizer: shs_rest): the oracle takes their concatenation, autograd splits the gradient again
+        sh = torch.cat((sh, sh_rest), dim=1)
     assert colors_precomp is None or colors_precomp.numel() == 0
     assert cov3Ds_precomp is None or cov3Ds_precomp.numel() == 0
     return _OracleRasterize.apply(means3D, means2D, means2D_abs, sh, opacities, scales, rotations, raster_settings)
