@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
 // operation and in its order (this file is compiled without contraction): colours and clamp flags stay bit-identical.  Writes quad 2 of
 // the render record and the clamp bits.
 constexpr int SHC_ROW = 52;          // LDS words per row: 48 coefficients + 4 words of padding
+template <bool SPLIT>          // SPLIT: DC and rest coefficients in two arrays (ibgs_forward_args.shs_rest) -- its own instantiation, so that the combined layout's code stays what it was
 __global__ void __launch_bounds__(256) sh_color_kernel(PreParams p, Cam cam)
 {
     __shared__ float s_sh_all[4][32 * SHC_ROW];
@@ -431,50 +432,43 @@ __global__ void __launch_bounds__(256) sh_color_kernel(PreParams p, Cam cam)
     const int nb = (D + 1) * (D + 1);
     const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
     float shv[48];
-    if (p.shs_rest && M == 16 && first + 64 <= p.P) {
+    if (SPLIT && M == 16 && first + 64 <= p.P) {
         // DC and the rest in two arrays (the reference model's `_features_dc` (P, 1, 3) and `_features_rest` (P, 15, 3) as they are: no torch.cat, no
         // second copy of 192 B per Gaussian).  Same scheme as below: the wave's 64 rows are one contiguous block per array -- 64 x 180 B = 720 float4 of
         // rest, 64 x 12 B = 48 float4 of DC, 768 = 12 x 64 pieces, all loads coalesced and in flight together -- parked in LDS in two rounds of 32 rows
-        // (360 + 24 = 384 = 6 x 64 pieces per round), in the SAME row layout [dc(3), rest(45)], so everything behind the transpose is unchanged.  A piece
-        // straddles rows (45 floats per row), so it is scattered word by word.  Pieces that hold nothing a live Gaussian needs at this degree are skipped.
+        // (360 + 24 = 384 = 6 x 64 pieces per round) AS THEY LIE in memory (16-byte LDS stores, conflict-free); lane r then reads its row word by word:
+        // the rows are 45 (and 3) words apart, odd strides, so the 64 lanes of every read hit distinct banks.  (Scattering the pieces into padded rows
+        // instead -- word stores 4 apart -- ran into 8-way bank conflicts: sh_color 51 -> 83 us.)  Pieces that hold nothing a live Gaussian needs are skipped.
         const float4* rest4 = reinterpret_cast<const float4*>(p.shs_rest + (size_t)first * 45);
         const float4* dc4 = reinterpret_cast<const float4*>(p.shs + (size_t)first * 3);
-        const int nrest = 3 * nb - 3;          // floats of a rest row the active degree reads
         float4 v[12];
 #pragma unroll
         for (int it = 0; it < 12; it++) {
             const int h = it / 6, qp = (it % 6) * 64 + lane;          // piece of round h
-            bool need = false;
             if (qp < 360) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = 4 * qp + k, r = e / 45, c = e - 45 * r; need = need || (((alive_m >> (32 * h + r)) & 1ull) && c < nrest); }
+                const int ra = (4 * qp) / 45, rb = (4 * qp + 3) / 45;          // the (at most two) rows the piece touches
+                const bool need = nb > 1 && (((alive_m >> (32 * h + ra)) & 1ull) || ((alive_m >> (32 * h + rb)) & 1ull));
                 v[it] = need ? rest4[360 * h + qp] : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = 4 * (qp - 360) + k; need = need || ((alive_m >> (32 * h + e / 3)) & 1ull); }
+                const int ra = (4 * (qp - 360)) / 3, rb = (4 * (qp - 360) + 3) / 3;
+                const bool need = (((alive_m >> (32 * h + ra)) & 3ull) != 0ull) || ((alive_m >> (32 * h + rb)) & 1ull);          // (a DC piece touches rows ra, ra + 1 [, rb])
                 v[it] = need ? dc4[24 * h + (qp - 360)] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        float4* s_raw = reinterpret_cast<float4*>(s_sh);          // 384 float4 of this round: rest rows 0..31 (1440 words), then their DC (96 words)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int qp = it * 64 + lane;
-                const float4 q = v[h * 6 + it];
-                const float f[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (qp < 360) { const int e = 4 * qp + k, r = e / 45, c = e - 45 * r; s_sh[r * SHC_ROW + 3 + c] = f[k]; }
-                    else { const int e = 4 * (qp - 360) + k, r = e / 3, c = e - 3 * r; s_sh[r * SHC_ROW + c] = f[k]; }
-                }
-            }
+            for (int it = 0; it < 6; it++) s_raw[it * 64 + lane] = v[h * 6 + it];
             if ((lane >> 5) == h) {
-                const float4* row4 = reinterpret_cast<const float4*>(s_sh + (lane & 31) * SHC_ROW);
+                const float* rr = s_sh + 45 * (lane & 31);
+                const float* rd = s_sh + 1440 + 3 * (lane & 31);
+                shv[0] = rd[0]; shv[1] = rd[1]; shv[2] = rd[2];
 #pragma unroll
-                for (int k = 0; k < 12; k++) { const float4 q = row4[k]; shv[4 * k] = q.x; shv[4 * k + 1] = q.y; shv[4 * k + 2] = q.z; shv[4 * k + 3] = q.w; }
+                for (int k = 0; k < 45; k++) shv[3 + k] = rr[k];
             }
         }
-    } else if (p.shs_rest) {          // other coefficient counts / the last, partial wave: plain per-lane loads from the two arrays
+    } else if (SPLIT) {          // other coefficient counts / the last, partial wave: plain per-lane loads from the two arrays
         const float* sr = p.shs_rest + (size_t)i * (M - 1) * 3;
         const float* sd = p.shs + (size_t)i * 3;
 #pragma unroll
@@ -598,7 +592,10 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         const bool no_sh = a.render_depth_only || a.colors_precomp || !a.shs;
         if (split) {
             if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
-            if (phase != 1) hipLaunchKernelGGL(sh_color_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+            if (phase != 1) {
+                if (p.shs_rest) hipLaunchKernelGGL(sh_color_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+                else hipLaunchKernelGGL(sh_color_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+            }
         } else if (phase != 2) {
             if (no_sh) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
             else hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, s, p, cam);

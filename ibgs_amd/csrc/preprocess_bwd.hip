@@ -63,7 +63,7 @@ __device__ __forceinline__ int sh_basis(int D, float x, float y, float z, float 
 // WRITE_SH = false is the view-parallel "factored" mode (IBGS_FLAG_SH_FACTORED): dL/dsh of one view is the
 // outer product basis(dir) x dL/dRGB, so only the clamp-masked dL/dRGB (3 floats instead of 3 M) leaves this
 // kernel, in dL_dcolors; ibgs_sh_grad_from_views (below) rebuilds the summed dL/dsh after the exchange.
-template <bool FAST16, bool WRITE_SH>
+template <bool FAST16, bool WRITE_SH, bool SPLIT = false>          // SPLIT: DC and rest coefficients in two arrays (ibgs_backward_args.shs_rest), its own instantiations
 __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBwdParams p, Cam cam)
 {
     __shared__ float4 s_t[FAST16 ? 64 * 13 : 1];     // row stride 13 quads: conflict-free b128 access
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         p.dL_dmean3D[3 * i] = 0.f; p.dL_dmean3D[3 * i + 1] = 0.f; p.dL_dmean3D[3 * i + 2] = 0.f;
         if (p.dL_dcov3D) for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
         if (!FAST16 && WRITE_SH && p.shs) {
-            if (p.shs_rest) {
+            if (SPLIT) {
                 float* gd = p.dL_dsh + (size_t)i * 3; float* gr = p.dL_dsh_rest + (size_t)i * (p.M - 1) * 3;
                 gd[0] = gd[1] = gd[2] = 0.f;
                 for (int k = 0; k < 3 * (p.M - 1); k++) gr[k] = 0.f;
@@ -113,51 +113,38 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
             p.dL_drot[4 * i] = 0.f; p.dL_drot[4 * i + 1] = 0.f; p.dL_drot[4 * i + 2] = 0.f; p.dL_drot[4 * i + 3] = 0.f;
         }
     }
-    if (FAST16 && p.shs_rest && p.shs) {
+    if (FAST16 && SPLIT && p.shs) {
         // DC and the rest in two arrays (ibgs_backward_args.shs_rest): the wave's 64 rows are one contiguous block per array (720 + 48 float4 = 12 x 64
-        // pieces), fetched with coalesced 16-B loads -- pieces that hold nothing of a Gaussian that needs its coefficients are skipped -- and scattered
-        // word by word into the rows [dc(3), rest(45)] of the transpose buffer, from which each lane then reads its own row (the combined layout's per-lane
-        // 16-B loads need 16-byte aligned rows; 180-byte rows are not).  Full blocks only: the last, partial block is not FAST16's (launcher).
+        // pieces), fetched with coalesced 16-B loads -- pieces that hold nothing of a Gaussian that needs its coefficients are skipped -- and parked in the
+        // transpose buffer AS THEY LIE (16-byte stores); each lane then reads its own row word by word: rows 45 (3) words apart, odd strides, no bank
+        // conflicts.  (The combined layout's per-lane 16-B loads need 16-byte aligned rows; 180-byte rows are not.)
         const int lane = threadIdx.x;
         const uint64_t vism = __builtin_amdgcn_ballot_w64(vis);
         const int i0 = blockIdx.x * 64;
+        const int nrows = min(64, p.P - i0);          // (the last block may be partial: its pieces end with the arrays; lanes beyond them are not `vis`)
         const float4* rest4 = reinterpret_cast<const float4*>(p.shs_rest + (size_t)i0 * 45);
         const float4* dc4 = reinterpret_cast<const float4*>(p.shs + (size_t)i0 * 3);
-        float* s_w = reinterpret_cast<float*>(s_t);
-        const int nrows = min(64, p.P - i0);          // (the last block may be partial: its pieces end with the arrays; lanes beyond them are not `vis`)
         float4 v[12];
 #pragma unroll
         for (int it = 0; it < 12; it++) {
             const int q = it * 64 + lane;
-            bool need = false;
             v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < 720) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) need = need || ((vism >> ((4 * q + k) / 45)) & 1ull);
-                if (need) {
+                const int ra = (4 * q) / 45, rb = (4 * q + 3) / 45;
+                if (((vism >> ra) & 1ull) || ((vism >> rb) & 1ull)) {
                     if (4 * q + 3 < nrows * 45) v[it] = rest4[q];
                     else { const float* sp = p.shs_rest + (size_t)i0 * 45; float* f = &v[it].x; for (int k = 0; k < 4; k++) if (4 * q + k < nrows * 45) f[k] = sp[4 * q + k]; }
                 }
             } else {
-                const int qd = q - 720;
-#pragma unroll
-                for (int k = 0; k < 4; k++) need = need || ((vism >> ((4 * qd + k) / 3)) & 1ull);
-                if (need) {
+                const int qd = q - 720, ra = (4 * qd) / 3, rb = (4 * qd + 3) / 3;
+                if ((((vism >> ra) & 3ull) != 0ull) || ((vism >> rb) & 1ull)) {
                     if (4 * qd + 3 < nrows * 3) v[it] = dc4[qd];
                     else { const float* sp = p.shs + (size_t)i0 * 3; float* f = &v[it].x; for (int k = 0; k < 4; k++) if (4 * qd + k < nrows * 3) f[k] = sp[4 * qd + k]; }
                 }
             }
         }
 #pragma unroll
-        for (int it = 0; it < 12; it++) {
-            const int q = it * 64 + lane;
-            const float f[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (q < 720) { const int e = 4 * q + k, r = e / 45, c = e - 45 * r; s_w[r * 52 + 3 + c] = f[k]; }
-                else { const int e = 4 * (q - 720) + k, r = e / 3, c = e - 3 * r; s_w[r * 52 + c] = f[k]; }
-            }
-        }
+        for (int it = 0; it < 12; it++) s_t[it * 64 + lane] = v[it];          // rest: words 0 .. 2879, DC: words 2880 .. 3071
         __syncthreads();
     }
     if (vis) {
@@ -309,14 +296,17 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         const float dorig[3] = {mean[0] - cam.campos[0], mean[1] - cam.campos[1], mean[2] - cam.campos[2]};
         const float len = sqrtf(dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2]);
         const float x = dorig[0] / len, y = dorig[1] / len, z = dorig[2] / len;
-        const float* shg = p.shs + (size_t)i * (p.shs_rest ? 1 : p.M) * 3;          // (split: the DC row; SHK reads the others from shs_rest)
+        const float* shg = p.shs + (size_t)i * (SPLIT ? 1 : p.M) * 3;          // (split: the DC row; SHK reads the others from shs_rest)
         float* gsh = p.dL_dsh + (size_t)i * p.M * 3;
         float shv[FAST16 ? 48 : 1];
         if (FAST16) {
-            if (p.shs_rest) {          // staged by the whole wave before this branch (below the kernel's head): the lane's row [dc(3), rest(45)] out of LDS
-                const float4* row4 = s_t + (size_t)threadIdx.x * 13;
+            if (SPLIT) {          // staged by the whole wave before this branch: the lane's DC (3 words) and rest (45 words) out of LDS, odd strides
+                const float* s_w = reinterpret_cast<const float*>(s_t);
+                const float* rr = s_w + 45 * threadIdx.x;
+                const float* rd = s_w + 2880 + 3 * threadIdx.x;
+                shv[0] = rd[0]; shv[1] = rd[1]; shv[2] = rd[2];
 #pragma unroll
-                for (int v = 0; v < 12; v++) { const float4 q = row4[v]; shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w; }
+                for (int k = 0; k < 45; k++) shv[3 + k] = rr[k];
             } else {
                 const float4* r4 = reinterpret_cast<const float4*>(shg);
 #pragma unroll
@@ -338,7 +328,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
             for (int k = 0; k < 16; k++) {
                 if (k < nb) { gv[3 * k] = B[k] * g[0]; gv[3 * k + 1] = B[k] * g[1]; gv[3 * k + 2] = B[k] * g[2]; }
             }
-        } else if (p.shs_rest) {
+        } else if (SPLIT) {
             float* gd = p.dL_dsh + (size_t)i * 3; float* gr = p.dL_dsh_rest + (size_t)i * (p.M - 1) * 3;
             gd[0] = B[0] * g[0]; gd[1] = B[0] * g[1]; gd[2] = B[0] * g[2];
             for (int k = 1; k < nb; k++) { gr[3 * (k - 1)] = B[k] * g[0]; gr[3 * (k - 1) + 1] = B[k] * g[1]; gr[3 * (k - 1) + 2] = B[k] * g[2]; }
@@ -352,7 +342,7 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         float gd[3] = {0, 0, 0};
         if (D > 0) {
             float dx3[3], dy3[3], dz3[3];
-#define SHK(k, ch) (FAST16 ? shv[3 * (k) + (ch)] : ((p.shs_rest && (k) > 0) ? p.shs_rest[((size_t)i * (p.M - 1) + ((k) - 1)) * 3 + (ch)] : shg[3 * (k) + (ch)]))
+#define SHK(k, ch) (FAST16 ? shv[3 * (k) + (ch)] : ((SPLIT && (k) > 0) ? p.shs_rest[((size_t)i * (p.M - 1) + ((k) - 1)) * 3 + (ch)] : shg[3 * (k) + (ch)]))
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 dx3[ch] = -bC1 * SHK(3, ch); dy3[ch] = -bC1 * SHK(1, ch); dz3[ch] = bC1 * SHK(2, ch);
@@ -417,34 +407,31 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     }
     }   // vis
 
-    if (FAST16 && WRITE_SH && p.shs && p.shs_rest) {
-        // ... and out again the same way: rows [dc(3), rest(45)] into the transpose buffer, the block's two contiguous pieces of dL/dsh (48 + 720 float4)
-        // gathered word by word and stored with coalesced 16-B writes
+    if (FAST16 && WRITE_SH && SPLIT && p.shs) {
+        // ... and out again the same way: every lane stores its 3 + 45 gradient words where the two arrays want them (odd strides: no conflicts), then
+        // the block's two contiguous pieces of dL/dsh (720 + 48 float4) leave with coalesced 16-B writes
         const int lane = threadIdx.x;
         __syncthreads();          // (every lane has read its coefficient row)
+        float* s_w = reinterpret_cast<float*>(s_t);
+        s_w[2880 + 3 * lane] = gv[0]; s_w[2880 + 3 * lane + 1] = gv[1]; s_w[2880 + 3 * lane + 2] = gv[2];
 #pragma unroll
-        for (int v = 0; v < 12; v++) s_t[lane * 13 + v] = make_float4(gv[4 * v], gv[4 * v + 1], gv[4 * v + 2], gv[4 * v + 3]);
+        for (int k = 0; k < 45; k++) s_w[45 * lane + k] = gv[3 + k];
         __syncthreads();
         const int i0 = blockIdx.x * 64;
-        const float* s_w = reinterpret_cast<const float*>(s_t);
+        const int nrows = min(64, p.P - i0);
         float4* dr = reinterpret_cast<float4*>(p.dL_dsh_rest + (size_t)i0 * 45);
         float4* dd = reinterpret_cast<float4*>(p.dL_dsh + (size_t)i0 * 3);
 #pragma unroll
         for (int it = 0; it < 12; it++) {
             const int q = it * 64 + lane;
-            float f[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (q < 720) { const int e = 4 * q + k, r = e / 45, c = e - 45 * r; f[k] = s_w[r * 52 + 3 + c]; }
-                else { const int e = 4 * (q - 720) + k, r = e / 3, c = e - 3 * r; f[k] = s_w[r * 52 + c]; }
-            }
-            const int nrows = min(64, p.P - i0);
+            const float4 f4 = s_t[q];
+            const float f[4] = {f4.x, f4.y, f4.z, f4.w};
             if (q < 720) {
-                if (4 * q + 3 < nrows * 45) dr[q] = make_float4(f[0], f[1], f[2], f[3]);
+                if (4 * q + 3 < nrows * 45) dr[q] = f4;
                 else { float* op = p.dL_dsh_rest + (size_t)i0 * 45; for (int k = 0; k < 4; k++) if (4 * q + k < nrows * 45) op[4 * q + k] = f[k]; }
             } else {
                 const int qd = q - 720;
-                if (4 * qd + 3 < nrows * 3) dd[qd] = make_float4(f[0], f[1], f[2], f[3]);
+                if (4 * qd + 3 < nrows * 3) dd[qd] = f4;
                 else { float* op = p.dL_dsh + (size_t)i0 * 3; for (int k = 0; k < 4; k++) if (4 * qd + k < nrows * 3) op[4 * qd + k] = f[k]; }
             }
         }
@@ -480,11 +467,16 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
     p.dL_dplane_normal = a.dL_dplane_normal; p.dL_dplane_offset = a.dL_dplane_offset;
     const Cam cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     const bool factored = a.shs && (a.flags & IBGS_FLAG_SH_FACTORED);
+    const bool split = a.shs && a.shs_rest;
     if (a.shs && a.M == 16) {
-        if (factored) hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
+        if (factored && split) hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, true>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
+        else if (factored) hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
+        else if (split) hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
         else hipLaunchKernelGGL((preprocess_bwd_kernel<true, true>), dim3((a.P + 63) / 64), dim3(64), 0, s, p, cam);
     } else {
-        if (factored) hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        if (factored && split) hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, true>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        else if (factored) hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
+        else if (split) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, true>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
         else hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
     }
     IBGS_HIP(hipGetLastError());
