@@ -556,14 +556,14 @@ def small_frame(dev, steps):
 class TrainIteration:
     """ONE iteration as the reference's trainer runs it in steady state (train.py:287-430), at C3 size on the `trained_geo` scene: `renderer.render(
     render_geo=True, return_depth_normal=True)` through the fused plane glue with 4 cached source depths, L1 against the view's image, backward, the depth
-    cache write (:298-299), the densification statistics (:400-405; written without the reference's boolean-index host syncs), `optimizer.step()` +
+    cache write (:298-299), the densification statistics (:400-405; `densify.add_densification_stats`: one launch, no host syncs), `optimizer.step()` +
     `zero_grad` (:421-424), cameras round-robin."""
     ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation",
             "normal": "_normal", "offset": "_offset"}
     LRS = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20.0, "opacity": 2.5e-2, "scaling": 5e-3, "rotation": 1e-3, "normal": 1e-3, "offset": 1.6e-5}   # arguments/__init__.py:90-98
 
     def __init__(self, dev, c, opt_cls):
-        from ibgs_amd import renderer, simple_scene
+        from ibgs_amd import densify, renderer, simple_scene
         self.renderer = renderer
         P, W, H = c["P"], c["W"], c["H"]
         self.P, self.dev = P, dev
@@ -578,8 +578,8 @@ class TrainIteration:
         self.opt = opt_cls([{"params": [getattr(self.pc, self.ATTR[k])], "lr": lr, "name": k} for k, lr in self.LRS.items()], lr=0.0, eps=1e-15)   # gaussian_model.py:227-241
         with torch.no_grad():
             self.scene.rendered_depth_list = renderer.render_depth_batch(self.cams, self.pc, self.scene, self.pipe, self.args, self.bg, True, 4, 4)
-        self.st = {"accum": torch.zeros(P, 1, device=dev), "accum_abs": torch.zeros(P, 1, device=dev), "denom": torch.zeros(P, 1, device=dev),
-                   "max_radii2D": torch.zeros(P, device=dev)}
+        self.st = {k: torch.zeros((P, 1) if i < 4 else (P,), device=dev) for i, k in enumerate(densify.STAT_NAMES)}          # gaussian_model.py:218-221, 203-204
+        self.densify = densify
         self.it = 0
 
     def __call__(self):
@@ -591,12 +591,9 @@ class TrainIteration:
         loss.backward()
         with torch.no_grad():
             scene.rendered_depth_list[k] = out["median_intersected_depth"].detach()
-            vis = out["visibility_filter"]
-            st["max_radii2D"] = torch.where(vis, torch.max(st["max_radii2D"], out["radii"].float()), st["max_radii2D"])
-            v = vis.unsqueeze(1)
-            st["accum"] += torch.where(v, torch.norm(out["viewspace_points"].grad[:, :2], dim=-1, keepdim=True), 0.0)
-            st["accum_abs"] += torch.where(v, torch.norm(out["viewspace_points_abs"].grad[:, :2], dim=-1, keepdim=True), 0.0)
-            st["denom"] += v
+            # max_radii2D + add_densification_stats (train.py:400-405) in one launch (`densify.add_densification_stats`; the reference's five boolean-indexed
+            # updates each stop the host for an index count)
+            self.densify.add_densification_stats(st, out["viewspace_points"], out["viewspace_points_abs"], out["radii"])
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
 
@@ -606,10 +603,10 @@ class TrainIteration:
         st = self.st
         n_app = self.P - int(keep.sum().item())
         ext = {gr["name"]: gr["params"][0].detach()[:n_app].clone() for gr in self.opt.param_groups}
-        new, extra = densify.prune_and_extend_optimizer(self.opt, keep, ext, extra=[st["accum"], st["accum_abs"], st["denom"], st["max_radii2D"]])
+        new, extra = densify.prune_and_extend_optimizer(self.opt, keep, ext, extra=[st[k] for k in densify.STAT_NAMES])
         for kname, a_ in self.ATTR.items():
             setattr(self.pc, a_, new[kname])
-        st["accum"], st["accum_abs"], st["denom"], st["max_radii2D"] = extra
+        self.st = dict(zip(densify.STAT_NAMES, extra))
 
 
 def train_iter(dev, c, steps):

@@ -115,7 +115,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
-           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats",
+           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_densify_stats", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats",
            "ibgs_required_l1", "ibgs_l1_loss", "ibgs_l1_grad", "ibgs_l1_rescale",
            "ibgs_depth_normal_forward", "ibgs_depth_normal_backward",
            "ibgs_last_error", "ibgs_version"]
@@ -183,6 +183,8 @@ def load():
     lib.ibgs_l1_loss.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_size_t]
     lib.ibgs_l1_grad.restype = ctypes.c_int32
     lib.ibgs_l1_grad.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4
+    lib.ibgs_densify_stats.restype = ctypes.c_int32
+    lib.ibgs_densify_stats.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 8
     lib.ibgs_depth_normal_forward.restype = ctypes.c_int32
     lib.ibgs_depth_normal_forward.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_float] * 4 + [ctypes.c_void_p] * 2
     lib.ibgs_depth_normal_backward.restype = ctypes.c_int32

@@ -42,6 +42,26 @@ __global__ void __launch_bounds__(COMPACT_THREADS) compact_apply_kernel(CompactT
         tail[e] = d.append ? d.append[e] : 0.0f;
 }
 
+
+// The densification statistics of one training view (train.py:400-405, scene/gaussian_model.py:600-604) in ONE kernel: for the Gaussians the view saw
+// (radii > 0): max_radii2D = max(max_radii2D, radius), accum += |dL/dmean2D.xy|, accum_abs += |dL/dmean2D_abs.xy|, both denominators += 1.  The reference
+// writes them as five boolean-indexed updates (`t[mask] = ...`, `t[mask] += ...`): each one a nonzero + gather + scatter and a HOST SYNC for the index count.
+__global__ void __launch_bounds__(256) densify_stats_kernel(int P, const int32_t* __restrict__ radii, const float* __restrict__ g2, const float* __restrict__ g2a,
+                                                            float* __restrict__ accum, float* __restrict__ accum_abs, float* __restrict__ denom,
+                                                            float* __restrict__ denom_abs, float* __restrict__ max_radii)
+{
+#pragma clang fp contract(off)          // the norms as torch.norm forms them: sqrt(x * x + y * y), no fused multiply-add
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    if (max_radii) max_radii[i] = fmaxf(max_radii[i], (float)r);
+    if (accum && g2) { const float x = g2[3 * i], y = g2[3 * i + 1]; accum[i] += sqrtf(x * x + y * y); }
+    if (accum_abs && g2a) { const float x = g2a[3 * i], y = g2a[3 * i + 1]; accum_abs[i] += sqrtf(x * x + y * y); }
+    if (denom) denom[i] += 1.0f;
+    if (denom_abs) denom_abs[i] += 1.0f;
+}
+
 }  // namespace ibgs
 
 using namespace ibgs;
@@ -95,6 +115,17 @@ int32_t ibgs_compact_apply(void* stream, int32_t n_tensors, const ibgs_compact_t
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(compact_apply_kernel, dim3((unsigned)blocks, (unsigned)n_tensors), dim3(COMPACT_THREADS), 0, s, tab, off, n_old, n_app);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int32_t ibgs_densify_stats(void* stream, int32_t P, const int32_t* radii, const float* dL_dmean2D, const float* dL_dmean2D_abs,
+                           float* accum, float* accum_abs, float* denom, float* denom_abs, float* max_radii2D)
+{
+    if (P <= 0) return 0;
+    if (!radii) { set_error("densify_stats: radii required"); return -IBGS_ERR_INVALID; }
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P, radii, dL_dmean2D, dL_dmean2D_abs,
+                       accum, accum_abs, denom, denom_abs, max_radii2D);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

@@ -251,3 +251,33 @@ def densify_and_prune(optimizer, stats, max_grad, abs_max_grad, min_opacity, ext
         mask = select_prune(p, stats["max_radii2D"], min_opacity, extent, max_screen_size)
         p, extra = surgery(optimizer, ~mask, None, extra=[stats[k] for k in STAT_NAMES])
         return p, dict(zip(STAT_NAMES, extra))
+
+
+def add_densification_stats(stats, viewspace_points, viewspace_points_abs, radii):
+    """`gaussians.max_radii2D[vis] = max(...)` + `GaussianModel.add_densification_stats(viewspace_point_tensor, viewspace_point_tensor_abs, visibility_filter)`
+    (train.py:400-405, scene/gaussian_model.py:600-604) for one view, in ONE launch and without the reference's five boolean-indexed updates (each a
+    nonzero + gather + scatter and a host sync).  stats: dict with STAT_NAMES tensors (updated IN PLACE); viewspace_points*: the sinks `render()` returned
+    (their `.grad` is read; `viewspace_points_abs` may be None or carry no gradient: its statistics are then left alone); radii: `render()`'s int32 radii
+    (visibility = radii > 0)."""
+    lib = _lib.load()
+    g = viewspace_points.grad if torch.is_tensor(viewspace_points) else None
+    ga = viewspace_points_abs.grad if (torch.is_tensor(viewspace_points_abs) and viewspace_points_abs.grad is not None) else None
+    if g is None:
+        raise RuntimeError("add_densification_stats: viewspace_points has no .grad (call it after loss.backward())")
+    if not radii.is_cuda:
+        raise RuntimeError("add_densification_stats runs on the MI355X only (no CPU path)")
+    P = int(radii.shape[0])
+    r = radii if radii.dtype == torch.int32 else radii.to(torch.int32)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    for k in STAT_NAMES[:5]:
+        t = stats.get(k)
+        if t is not None and not (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == P):
+            raise ValueError("add_densification_stats: stats[%r] must be a contiguous float32 tensor with one value per Gaussian" % k)
+    with torch.cuda.device(radii.device):
+        rc = lib.ibgs_densify_stats(torch.cuda.current_stream(radii.device).cuda_stream, P, r.contiguous().data_ptr(), g.contiguous().data_ptr(),
+                                    None if ga is None else ga.contiguous().data_ptr(), ptr(stats.get("xyz_gradient_accum")),
+                                    ptr(stats.get("xyz_gradient_accum_abs")) if ga is not None else None, ptr(stats.get("denom")),
+                                    ptr(stats.get("denom_abs")) if ga is not None else None, ptr(stats.get("max_radii2D")))
+    if rc < 0:
+        raise RuntimeError("ibgs_densify_stats failed (%d): %s" % (rc, _lib.last_error()))
+    return stats

@@ -370,6 +370,12 @@ size_t ibgs_required_compact(int32_t n_old);
 int64_t ibgs_compact_plan(void* stream, int32_t n_old, const uint8_t* keep_mask /* n_old or NULL */, char* scratch, size_t scratch_bytes);
 int32_t ibgs_compact_apply(void* stream, int32_t n_tensors, const ibgs_compact_tensor* tensors, int32_t n_old, int32_t n_app,
                            const char* scratch);
+/* The densification statistics of one training view (train.py:400-405; GaussianModel.add_densification_stats, scene/gaussian_model.py:600-604) in one
+ * launch and without the reference's boolean-index host syncs: for every Gaussian with radii[i] > 0: max_radii2D[i] = max(max_radii2D[i], radii[i]),
+ * accum[i] += |dL_dmean2D[i].xy|, accum_abs[i] += |dL_dmean2D_abs[i].xy|, denom[i] += 1, denom_abs[i] += 1.  dL_dmean2D*: P x 3 (the `.grad` of the
+ * viewspace sinks); accum* / denom*: P (or P x 1) floats; any output (and its input) may be NULL. */
+int32_t ibgs_densify_stats(void* stream, int32_t P, const int32_t* radii, const float* dL_dmean2D, const float* dL_dmean2D_abs,
+                           float* accum, float* accum_abs, float* denom, float* denom_abs, float* max_radii2D);
 
 /* Introspection for tests: byte offsets of the named sub-arrays inside the arenas.
  * Returns -1 for an unknown name. Names: see DESIGN.md section 2. */

@@ -204,3 +204,30 @@ def test_densify_and_prune_on_the_gpu_is_the_reference_s(tag):
     for g in opt.param_groups:          # and the optimiser still steps (FusedAdam on the new Parameters)
         g["params"][0].grad = torch.ones_like(g["params"][0])
     opt.step()
+
+
+def test_densification_statistics_in_one_launch():
+    """`densify.add_densification_stats` against the reference's five boolean-indexed updates (train.py:400-405, scene/gaussian_model.py:600-604),
+    restated with torch on the same tensors: bit for bit (the norms are formed without contraction, as torch.norm over two values does)."""
+    P = 20011
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    radii = torch.randint(-2, 40, (P,), device="cuda", dtype=torch.int32, generator=gen).clamp_min(0)
+    vp = torch.zeros(P, 3, device="cuda", requires_grad=True); vpa = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    vp.grad = torch.randn(P, 3, device="cuda", generator=gen); vpa.grad = torch.randn(P, 3, device="cuda", generator=gen).abs()
+    a = {k: torch.rand((P, 1) if i < 4 else (P,), device="cuda", generator=gen) * (30.0 if k == "max_radii2D" else 1.0) for i, k in enumerate(densify.STAT_NAMES)}
+    b = {k: v.clone() for k, v in a.items()}
+    for _ in range(2):
+        densify.add_densification_stats(a, vp, vpa, radii)
+        mask = radii > 0          # visibility_filter
+        b["max_radii2D"][mask] = torch.max(b["max_radii2D"][mask], radii[mask].float())
+        b["xyz_gradient_accum"][mask] += torch.norm(vp.grad[mask, :2], dim=-1, keepdim=True)
+        b["xyz_gradient_accum_abs"][mask] += torch.norm(vpa.grad[mask, :2], dim=-1, keepdim=True)
+        b["denom"][mask] += 1
+        b["denom_abs"][mask] += 1
+    assert int((radii > 0).sum()) not in (0, P)
+    for k in densify.STAT_NAMES:
+        assert torch.equal(a[k], b[k]), k
+    # without the |.| statistic (renderer.TRACK_ABS_GRAD = False: the abs sink carries no gradient): its two tensors are left alone
+    c = {k: v.clone() for k, v in a.items()}
+    densify.add_densification_stats(c, vp, None, radii)
+    assert torch.equal(c["xyz_gradient_accum_abs"], a["xyz_gradient_accum_abs"]) and torch.equal(c["denom_abs"], a["denom_abs"]) and not torch.equal(c["denom"], a["denom"])
