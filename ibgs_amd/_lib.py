@@ -60,6 +60,7 @@ class ForwardArgs(ctypes.Structure):
         ("tile_order_hint", ctypes.c_void_p),
         ("binning", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
         ("shs_rest", c_float_p),
+        ("depth_bound_hint", c_float_p), ("depth_bound_out", c_float_p),
     ]
 
 

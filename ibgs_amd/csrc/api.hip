@@ -71,6 +71,7 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.offsets = c.take<uint32_t>(P + 5);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
+    g.tile_partial2 = c.take<uint32_t>((P + 63) / 64 + 1);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return g;
 }
@@ -92,6 +93,7 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.slot_c = c.take<uint32_t>(HW * IBGS_MAX_BUFFER_LENGTH);
     im.tile_walked = c.take<uint32_t>(tiles * 4);
     im.tile_order = c.take<uint32_t>((tiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES);
+    im.tile_done = c.take<uint32_t>(tiles * 4);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;
 }
@@ -158,8 +160,10 @@ static int stage_check(hipStream_t s, bool debug, const char* what)
 // the total, then a ticket, straight into pinned host memory; the host polls the ticket (ibgs_forward).  The four runtime calls it replaces -- event
 // record, stream wait, copy, event record -- cost the forward ~12 us of host time, and the copy engine's own latency on top.  The ticket counts in
 // DEVICE memory (a kernel argument could not change from call to call were this sequence ever replayed from a graph); the host knows which one it waits for.
-__global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __restrict__ partial, uint32_t nwords, uint32_t* __restrict__ seq_dev, volatile uint32_t* host_words)
+__global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __restrict__ partial, uint32_t nwords, uint32_t* __restrict__ seq_dev, volatile uint32_t* host_words,
+                                                             uint32_t* __restrict__ zero2 /* two words to clear (the depth-bound check's verdict, img meta[12..13]) or nullptr */)
 {
+    if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
     __shared__ unsigned long long s_w[16];
     unsigned long long sum = 0;
     for (uint32_t i = threadIdx.x; i < nwords; i += 1024) sum += partial[i];
@@ -242,7 +246,7 @@ size_t ibgs_tile_order_slots(int32_t W, int32_t H)
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
 {
     size_t t; ImgState im = ImgState::carve(nullptr, W, H, &t);
-    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order);
+    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order); OFF(im, tile_done);
     return -1;
 }
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
@@ -374,17 +378,23 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     const int gx = (a.W + TILE - 1) / TILE, gy = nv * ((a.H + TILE - 1) / TILE);
 
     const bool deferred = a.rendered_hint > 0 && !debug;
+    // depth-bound hint (ibgs_rast.h): the split preprocess path of a hinted colour / geo pass, and only where the sort's kernels can run guarded
+    const bool bound_ok = deferred && nv == 1 && !a.render_depth_only && a.shs && !a.colors_precomp && radix_uses_onesweep((size_t)Pn, 32) && preprocess_is_split(a);
+    const bool use_bound = bound_ok && a.depth_bound_hint != nullptr;
+    const bool track_done = bound_ok && (a.depth_bound_hint || a.depth_bound_out);
     const size_t nwaves = (size_t)nv * (((size_t)a.P + 63) / 64);          // words of per-wave tile sums the preprocess kernel wrote; the depth sort's error flag follows them
     RSlot* rs = rslot();
     if (!rs) return -IBGS_ERR_HIP;
     { StageTimer t(s, IBGS_STAGE_PREPROCESS);
-      if ((rc = launch_preprocess(s, a, g, deferred ? 1 : 0))) return rc;
+      if ((rc = launch_preprocess(s, a, g, deferred ? 1 : 0, use_bound ? a.depth_bound_hint : nullptr))) return rc;
       if (deferred) {
           // R = the sum of the tiles touched, final as soon as the geometry kernel is: a one-workgroup kernel adds the per-wave sums up HERE and stores the
           // total + a ticket into pinned host memory, while the stream goes on with the SH colours and the depth sort.  (Until round 4 the sums left
           // behind the sort, by a copy on a second stream, together with the sort's error flag: on small frames the host then sat out five sort launches'
           // worth of GPU latency -- ~45 us of a 0.34 ms call pair, profiles/r05_host_split.txt -- before it could queue the loss and the backward.)
-          hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, g.tile_partial, (uint32_t)nwaves, rs->seq_dev, rs->host);
+          // (under a depth-bound hint: R of the UNBOUNDED lists, which the repair pass must be able to store -- the preprocess kernel sums both)
+          hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, use_bound ? g.tile_partial2 : g.tile_partial, (uint32_t)nwaves, rs->seq_dev, rs->host,
+                             track_done ? im.meta + 12 : nullptr);
           IBGS_HIP(hipGetLastError());
           rs->seq_host++;          // the ticket that kernel will write
           if ((rc = launch_preprocess(s, a, g, 2))) return rc;
@@ -421,6 +431,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if (deferred) cap = a.rendered_hint < (int64_t)0xFFFF0000ll ? a.rendered_hint : (int64_t)0xFFFF0000ll;
     else { if ((rc = exact_R(&R))) return rc; cap = R; }
 
+    BinState b_first{};
     auto tail = [&](int64_t n, bool read_back) -> int {
         int rc;
         // the hinted pass may use an arena the caller sized for the hint beforehand (ibgs_forward_args.binning: no call back into the caller, which
@@ -429,6 +440,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         char* bin_mem = (read_back && a.binning && a.binning_bytes >= need) ? a.binning : a.binning_alloc(need, a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
+        b_first = b;
         // hinted pass: the binning's last kernel leaves R as it counted it, the coarse slots in use and the depth sort's error word in pinned host memory
         // (diagnostics nobody waits for: ibgs_last_forward_stats; the error word: check_sort_flag)
         { StageTimer t(s, IBGS_STAGE_EMIT);
@@ -447,6 +459,26 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     };
     const bool prev_pending = rs->flag_pending;          // a hinted forward before this one whose sort nobody has vouched for yet
     if ((rc = tail(cap, deferred))) return rc;
+    const int ntiles_img = gx * gy;
+    if (use_bound) {
+        // Was the bound sound?  bound_verify_kernel sets meta[12] if a tile's pixels did not all terminate in front of its bound; the REPAIR PASS queued right
+        // behind it -- the whole forward once more, without a bound, into the same arenas -- reads that word in every kernel and leaves at once when it is zero
+        // (~20 empty launches).  The host never waits for the verdict.
+        const uint32_t* guard = im.meta + 12;
+        { StageTimer t(s, IBGS_STAGE_PREPROCESS);
+          if ((rc = launch_bound_verify(s, ntiles_img, g, b_first, im, a.depth_bound_hint))) return rc;
+          if ((rc = launch_preprocess(s, a, g, 0, nullptr, guard))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
+          if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.tile_partial + nwaves, g.offsets + Pn + 3, true, g.offsets + Pn + 4, guard))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_EMIT);
+          if ((rc = launch_binning(s, Pn, cap, gx, gy, g, b_first, im.ranges, a.tile_order_hint, im.meta, nv, g.tile_partial + nwaves, rs->stats, guard))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, cap, gx, gy, b_first, guard))) return rc; }
+        { StageTimer t(s, IBGS_STAGE_RENDER_FWD);
+          const float4* rgba = a.render_geo ? reinterpret_cast<const float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127)) : nullptr;
+          if ((rc = launch_render_forward(s, a, g, b_first, im, rgba, guard))) return rc; }
+    }
+    // the bound for this camera's next forward (when the hint turns out too small below, the lists are rebuilt first and this kernel runs again)
+    if (track_done && a.depth_bound_out && (rc = launch_bound_update(s, ntiles_img, g, b_first, im, use_bound ? a.depth_bound_hint : nullptr, a.depth_bound_out))) return rc;
     g_last_stats[1] = -1; g_last_stats[2] = 0;
     g_stats_slot = rs; rs->stats_pending = false;
     if (deferred) {
@@ -485,7 +517,15 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
             if ((rc = check_sort_flag(rs))) return rc;          // (the stream is drained: this forward's own word is final too)
+            if (use_bound) {          // the geometry state may be the bounded one: preprocess + depth sort once more without a bound
+                if ((rc = launch_preprocess(s, a, g, 0))) return rc;
+                if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.tile_partial + nwaves, g.offsets + Pn + 3, true, g.offsets + Pn + 4))) return rc;
+            }
             if ((rc = tail(R, false))) return rc;
+            if (track_done && a.depth_bound_out) {
+                IBGS_HIP(hipMemsetAsync(im.meta + 12, 0, 2 * sizeof(uint32_t), s));
+                if ((rc = launch_bound_update(s, ntiles_img, g, b_first, im, nullptr, a.depth_bound_out))) return rc;
+            }
         } else rs->stats_pending = true;
     }
     g_last_stats[0] = R;
@@ -550,7 +590,7 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
         }
         // (launch_render_backward brackets its kernels itself: IBGS_STAGE_GEO_WINDOW, IBGS_STAGE_TILE_ORDER, IBGS_STAGE_RENDER_BWD = the blend kernel alone)
         if ((rc = launch_render_backward(s, a, g, b, im, rgba, det ? ds.slab : nullptr, geo_tab))) return rc;
-        if (det) { StageTimer t(s, IBGS_STAGE_TILE_ORDER); if ((rc = launch_det_reduce(s, ds, b.point_list, (size_t)a.R, ipt, a.P, a.grad_acc))) return rc; }
+        if (det) { StageTimer t(s, IBGS_STAGE_TILE_ORDER); if ((rc = launch_det_reduce(s, ds, b.point_list, (size_t)a.R, ipt, a.P, a.grad_acc, g.offsets + a.P))) return rc; }
         if ((rc = stage_check(s, debug, "render backward"))) return rc;
     }
     { StageTimer t(s, IBGS_STAGE_PREPROCESS_BWD); if ((rc = launch_preprocess_backward(s, a, g))) return rc; }

@@ -57,6 +57,7 @@ struct GeomState {
                            //      together; [P+3] = Gaussians with tiles (what the depth sort keeps); [P+4] = 1 when the depth order lies in sort_val[1]
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
+    uint32_t* tile_partial2; // ceil(P / 64)   depth-bound hint in use: the tiles every wave's Gaussians would touch WITHOUT the bound (R of the unbounded lists: sizes the repair pass)
     static GeomState carve(char* base, size_t P, size_t* total);
 };
 
@@ -72,6 +73,8 @@ struct ImgState {
     uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
     uint32_t* tile_walked; // tiles x 4   how far the forward walked every tile's list (largest n_contrib), per wave of the tile ([tile * waves + wave]) = the backward's work there
     uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)
+    uint32_t* tile_done;   // tiles x 4   per wave of the tile (layout of tile_walked): the 1-based list position at which its last pixel terminated, 0xFFFFFFFF if one was still
+                           //             open at the end of the list; meta[12] = 1: the depth bound was violated somewhere and the guarded repair pass ran, [13] = dirty tiles
     static ImgState carve(char* base, int W, int H, size_t* total);
 };
 
@@ -394,7 +397,9 @@ constexpr int HYBRID_MIN_TILES = 768;
 inline int hybrid_max_tiles() { static const int v = getenv("IBGS_HYBRID_MAX_TILES") ? atoi(getenv("IBGS_HYBRID_MAX_TILES")) : 4096; return v; }
 inline int hybrid_theta() { static const int v = getenv("IBGS_HYBRID_THETA") ? atoi(getenv("IBGS_HYBRID_THETA")) : HYBRID_THETA; return v > 0 ? v : HYBRID_THETA; }      // (the env: experiments)
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0);
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0, const float* bound = nullptr /* depth-bound hint (split colour pass only) */,
+                      const uint32_t* run_if = nullptr /* guard of the repair pass */);
+bool preprocess_is_split(const ibgs_forward_args& a);          // geometry and SH colours in two kernels (the only path that takes a depth-bound hint)
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
 
 // device-wide primitives (scan_sort.hip)
@@ -402,7 +407,8 @@ size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by r
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
                      uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false,
-                     uint32_t* result_alt = nullptr);
+                     uint32_t* result_alt = nullptr, const uint32_t* run_if = nullptr /* guard of a repair pass: every kernel leaves at once when *run_if == 0 */);
+bool radix_uses_onesweep(size_t n, int nbits);      // the single-launch passes -- the only ones that can run guarded -- would be taken
 // result_alt: device word (zeroed by the caller).  When given (32-bit keys, single-launch passes), a LAST pass in which every key carries the same digit --
 //          the top byte of depths within [2, 8), say -- moves nothing and sets *result_alt = 1: the result is then in keys[1] / vals[1] (else, as always, in [0])
 size_t radix_zero_elems(size_t n, int nbits);      // leading words of `hist` the sort needs zeroed (see scratch_is_zero)
@@ -423,16 +429,19 @@ void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatt
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
                    const uint32_t* order_hint = nullptr, uint32_t* meta = nullptr /* meta[11] = 1 when the hint is a valid tile order */,
                    int n_views = 1 /* batched depth views: P = n_views x instances, gy = n_views x rows */,
-                   const uint32_t* sort_flag = nullptr, uint32_t* host_note = nullptr /* pinned host words the last kernel leaves R, C and the sort's error word in */);
+                   const uint32_t* sort_flag = nullptr, uint32_t* host_note = nullptr /* pinned host words the last kernel leaves R, C and the sort's error word in */,
+                   const uint32_t* run_if = nullptr /* guard of the repair pass */);
 constexpr int ORDER_CLASSES = 1024;          // SIMDs of the chip = classes of the balanced launch order (render_bwd.hip)
-int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
+int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, const uint32_t* run_if = nullptr);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
 // geo backward: per-pixel table of the median / warp terms of every buffered contributor (render_bwd.hip), 6 words per slot
 constexpr int GEO_TAB_FIELDS = 6;
 inline size_t geo_table_floats(int W, int H) { return (size_t)W * H * IBGS_MAX_BUFFER_LENGTH * GEO_TAB_FIELDS; }
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
-                          const ImgState& im, const float4* src_rgba);
+                          const ImgState& im, const float4* src_rgba, const uint32_t* run_if = nullptr /* guard of the repair pass */);
+int launch_bound_verify(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound);      // depth-bound hint: meta[12] = 1 when it was violated
+int launch_bound_update(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound_in, float* bound_out);      // ... the bound for the camera's next forward
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
                            const ImgState& im, const float4* src_rgba, float* slab = nullptr, float* geo_tab = nullptr);
 int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g);
@@ -448,7 +457,7 @@ struct DetState {
 };
 int render_backward_waves_per_tile(const ibgs_backward_args& a);
 int launch_det_prepare(hipStream_t s, const DetState& d, size_t rows);                    // zero the slab
-int launch_det_reduce(hipStream_t s, const DetState& d, const uint32_t* point_list, size_t R, int ipt, int P, float* gacc);
+int launch_det_reduce(hipStream_t s, const DetState& d, const uint32_t* point_list, size_t R, int ipt, int P, float* gacc, const uint32_t* listed /* device word: entries the lists hold (<= R) */);
 int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, const float* means3D, const float* camposes,
                               const float* dcolor, size_t view_stride, float* dL_dsh);
 

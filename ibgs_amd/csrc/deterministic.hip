@@ -35,11 +35,13 @@ DetState DetState::carve(char* base, size_t R, size_t P, size_t* total)
     return d;
 }
 
+// (`listed`: the entries the forward's lists really hold, a device word -- fewer than R when a depth-bound hint shortened them (ibgs_rast.h: the forward
+// returns R of the unbounded lists); the slots behind them get the id P, sort behind every Gaussian and belong to no segment)
 __global__ void __launch_bounds__(256) det_pairs_kernel(const uint32_t* __restrict__ point_list, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals, size_t rows, int ipt)
+                                                        uint32_t* __restrict__ vals, size_t rows, int ipt, const uint32_t* __restrict__ listed, uint32_t P)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < rows) { keys[i] = point_list[i / (size_t)ipt]; vals[i] = (uint32_t)i; }
+    if (i < rows) { const size_t e = i / (size_t)ipt; keys[i] = e < (size_t)*listed ? point_list[e] : P; vals[i] = (uint32_t)i; }
 }
 
 // first sorted slot whose id is >= g, for g = 0..P (seg[P] = R)
@@ -72,14 +74,14 @@ int launch_det_prepare(hipStream_t s, const DetState& d, size_t rows)
     return 0;
 }
 
-int launch_det_reduce(hipStream_t s, const DetState& d, const uint32_t* point_list, size_t R, int ipt, int P, float* gacc)
+int launch_det_reduce(hipStream_t s, const DetState& d, const uint32_t* point_list, size_t R, int ipt, int P, float* gacc, const uint32_t* listed)
 {
     const size_t rows = R * (size_t)ipt;
-    hipLaunchKernelGGL(det_pairs_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, point_list, d.keys[0], d.vals[0], rows, ipt);
+    hipLaunchKernelGGL(det_pairs_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, point_list, d.keys[0], d.vals[0], rows, ipt, listed, (uint32_t)P);
     IBGS_HIP(hipGetLastError());
     uint32_t* keys[2] = {d.keys[0], d.keys[1]};
     uint32_t* vals[2] = {d.vals[0], d.vals[1]};
-    int rc = radix_sort_pairs(s, keys, vals, rows, id_bits((size_t)P), d.hist, d.hist_elems);
+    int rc = radix_sort_pairs(s, keys, vals, rows, id_bits((size_t)P + 1), d.hist, d.hist_elems);
     if (rc) return rc;
     hipLaunchKernelGGL(det_segments_kernel, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, s, d.keys[0], d.seg, rows, P);
     IBGS_HIP(hipGetLastError());

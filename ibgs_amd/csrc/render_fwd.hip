@@ -41,6 +41,8 @@ struct FwdParams {
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
     int hybrid_grid1;    // ... its first hybrid_grid1 workgroups are the tiles' first waves (hybrid_item, common.h)
     int hybrid;          // 1: render_fwd_color_hybrid_kernel
+    const uint32_t* run_if;   // guard of the repair pass (api.hip): the kernel leaves at once when *run_if == 0; nullptr on every ordinary pass
+    uint32_t* done;           // per (tile, wave of the tile), layout of `walked`: the list position (end of the staging round) by which the wave's last pixel had terminated, 0xFFFFFFFF if one was still open at the end of the list (depth-bound verification)
     int split_epilogue;  // geo: the blend kernel only parks its median buffer (slot_c, and the weights in the first L planes of out_cam_feat); geo_epilogue_kernel does the rest
     const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by an extra workgroup of cell_place_kernel: meta[11]; nullptr: the tile map
     // outputs
@@ -209,7 +211,8 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
     };
     float4 ahead = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (GEO) ahead = fetch_quad(0);
-    for (int base = 0; base < n; base += CHUNK) {
+    int base = 0;          // (lives past the loop: where the wave left the list)
+    for (; base < n; base += CHUNK) {
         uint64_t riskm = 0ull;          // staged records whose conic is near-singular: the reference's power expression decides for them (common.h)
         if constexpr (GEO) {
             float4 v = ahead;
@@ -391,13 +394,21 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
         for (int q = 0; q < PPL; q++) m = max(m, inside[q] ? lastc[q] : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
+        // ... and whether every pixel of this wave had finished by then (no pixel left that a Gaussian further back could still reach): what the check of a
+        // depth-bound hint needs (bound_verify_kernel)
+        uint64_t left = 0ull;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) left |= live[q];
+        // the end of the round in which the last pixel terminated (at an entry that is NOT blended: it lies behind the last contributor, within that
+        // round), or "a pixel was still open": the loop is only ever left early through its all-finished exit, with `base` still on that round
+        const uint32_t fin = left == 0ull ? (uint32_t)min(n, base + CHUNK) : 0xFFFFFFFFu;
         if (p.hybrid) {
             // hybrid colour kernel: four words per tile whichever shape walked it (a tile wave leaves the other three at zero)
-            if (IPT == 1) { if (lane < 4) p.walked[(size_t)tile * 4 + lane] = lane == 0 ? m : 0u; }
-            else if (lane == 0) p.walked[(size_t)tile * 4 + sub] = m;
+            if (IPT == 1) { if (lane < 4) { p.walked[(size_t)tile * 4 + lane] = lane == 0 ? m : 0u; p.done[(size_t)tile * 4 + lane] = lane == 0 ? fin : 0u; } }
+            else if (lane == 0) { p.walked[(size_t)tile * 4 + sub] = m; p.done[(size_t)tile * 4 + sub] = fin; }
             if (lane == 0 && tile == 0 && sub == 0) p.meta[10] = 4u;
         }
-        else if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
+        else if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; p.done[(size_t)tile * IPT + sub] = fin; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
     }
     // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
     // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --
@@ -557,6 +568,7 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
 template <int MODE, int PPL, int MAXL>
 __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 : 1) render_fwd_kernel(FwdParams p)
 {
+    if (p.run_if && *p.run_if == 0u) return;
     __shared__ float4 s_rec[(MODE == MODE_GEO) ? 4 : 3][(MODE == MODE_GEO) ? 16 : WAVE];
     constexpr int IPT = 4 / PPL;
     int tile, sub;
@@ -582,6 +594,7 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
 // operations, TILE_Q above): the hint that may steer the choice stays a pure performance matter.
 __global__ void __launch_bounds__(64, 8) render_fwd_color_hybrid_kernel(FwdParams p)
 {
+    if (p.run_if && *p.run_if == 0u) return;
     __shared__ float4 s_rec[3][WAVE];
     int tile, sub; bool split;
     if (p.order && p.meta[11] == 1u) {
@@ -626,6 +639,7 @@ template <int MAXL>
 __global__ void __launch_bounds__(256) geo_epilogue_kernel(FwdParams p)
 {
 #pragma clang fp contract(off)
+    if (p.run_if && *p.run_if == 0u) return;
     int tile, sub;
     if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub)) return;
     const int W = p.cam.W, H = p.cam.H;
@@ -743,10 +757,76 @@ __global__ void __launch_bounds__(256) geo_epilogue_kernel(FwdParams p)
     p.out_depth[pix] = med;
 }
 
+// ---- depth-bound hint: check and renewal (round 5) -----------------------------------------------------------------------------------------------
+// bound[t] = the depth behind which nothing of tile t was reached by this camera's previous forward, or +inf (preprocess.hip applies it).  After the
+// blend, tile t is FINE if no Gaussian the bound removed could have been reached there: bound[t] = +inf (then nothing that touches t was removed: a
+// Gaussian goes only if it lies behind the bound of every tile of its rectangle), or every pixel of the tile terminated (T < 1e-4, tile_done) at an
+// entry no deeper than bound[t]: whatever was removed from the list lies strictly behind that entry in the depth order, so the list the pixels saw up
+// to their termination is the unbounded one, entry for entry.  One tile that is not fine sets meta[12] = 1: the guarded
+// repair pass queued behind this kernel then redoes the frame without a bound; otherwise its kernels leave at once.
+__global__ void __launch_bounds__(256) bound_verify_kernel(int ntiles, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float* __restrict__ depths,
+                                                           const uint32_t* __restrict__ done, const float* __restrict__ bound, uint32_t* __restrict__ meta)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (t < ntiles) {
+        const float bt = bound[t];
+        if (!(bt == INFINITY)) {          // (anything else counts as a bound, NaN included: preprocess.hip's fmaxf skips a NaN, so the tile's neighbours' bounds applied)
+            const uint32_t ipt = meta[10];
+            uint32_t w = 0;          // by which list position the tile's last pixel had terminated, 0xFFFFFFFF: one never did
+            for (uint32_t k = 0; k < ipt; k++) w = max(w, done[(size_t)t * ipt + k]);
+            const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+            if (w == 0u || w > r1 - r0) bad = true;          // (0: an empty list under a bound)
+            else if (!(depths[point_list[r0 + w - 1u]] <= bt)) bad = true;
+        }
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
+    if (m != 0ull && (threadIdx.x & 63) == 0) { atomicOr(meta + 12, 1u); atomicAdd(meta + 13, (uint32_t)__builtin_popcountll(m)); }
+}
+
+// The bound for this camera's NEXT forward, from what this one walked (after the repair pass, if it ran): a tile whose pixels all finished gets the
+// depth of the entry BOUND_SLACK positions behind its last contributor, widened by BOUND_MARGIN -- room for the scene to move a little between two
+// visits of the camera; a tile with a pixel still open (or a list that ends within the slack) gets +inf.
+constexpr uint32_t BOUND_SLACK = 64;
+constexpr float BOUND_MARGIN = 1.02f;
+__global__ void __launch_bounds__(256) bound_update_kernel(int ntiles, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float* __restrict__ depths,
+                                                           const uint32_t* __restrict__ done, const uint32_t* __restrict__ meta, const float* __restrict__ bound_in, float* __restrict__ bound_out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t ipt = meta[10];
+    uint32_t w = 0;
+    for (uint32_t k = 0; k < ipt; k++) w = max(w, done[(size_t)t * ipt + k]);
+    const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
+    float b = INFINITY;
+    if (w != 0xFFFFFFFFu && w > 0u) {
+        if (w + BOUND_SLACK < r1 - r0) b = depths[point_list[r0 + w + BOUND_SLACK - 1u]] * BOUND_MARGIN;
+        // a list that the bound in force cut short behind the terminator: that bound served, keep it (else the tile would go back and forth between
+        // a bounded and an unbounded frame)
+        else if (bound_in && meta[12] == 0u) b = bound_in[t];
+    }
+    bound_out[t] = b;
+}
+
+int launch_bound_verify(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound)
+{
+    hipLaunchKernelGGL(bound_verify_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, ntiles, im.ranges, b.point_list, g.depths, im.tile_done, bound, im.meta);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_bound_update(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound_in, float* bound_out)
+{
+    hipLaunchKernelGGL(bound_update_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, ntiles, im.ranges, b.point_list, g.depths, im.tile_done, im.meta, bound_in, bound_out);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
-                          const ImgState& im, const float4* src_rgba)
+                          const ImgState& im, const float4* src_rgba, const uint32_t* run_if)
 {
     FwdParams p;
+    p.run_if = run_if; p.done = im.tile_done;
     p.ranges = im.ranges; p.point_list = b.point_list; p.rec = reinterpret_cast<const float4*>(g.rec);
     p.cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     p.ntiles = p.cam.gx * p.cam.gy;

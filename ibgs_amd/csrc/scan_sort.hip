@@ -295,8 +295,10 @@ constexpr int OS_THREADS = 512, OS_WAVES = OS_THREADS / 64, OS_ITEMS = RS_CHUNK 
 
 __global__ void __launch_bounds__(OS_HIST_THREADS) onesweep_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npass, int dbits,
                                                                    uint32_t* __restrict__ ghist /* npass x 256 */,
-                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept)
+                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept,
+                                                                   const uint32_t* __restrict__ run_if /* guard of a repair pass (api.hip), or nullptr */)
 {
+    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t h[OS_MAX_PASS][RS_MAX_BINS];
     __shared__ uint32_t s_kept;
     for (int k = threadIdx.x; k < OS_MAX_PASS * RS_MAX_BINS; k += OS_HIST_THREADS) (&h[0][0])[k] = 0;
@@ -328,8 +330,10 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
                                                                    uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                                    int drop_here /* first pass of a sort that drops the 0xFFFFFFFF keys */,
                                                                    const uint32_t* __restrict__ n_kept /* items that take part (device) */,
-                                                                   uint32_t* __restrict__ stays /* last pass only, or nullptr: a pass that would move nothing may leave its input where it is and say so */)
+                                                                   uint32_t* __restrict__ stays /* last pass only, or nullptr: a pass that would move nothing may leave its input where it is and say so */,
+                                                                   const uint32_t* __restrict__ run_if /* guard of a repair pass, or nullptr */)
 {
+    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t wcnt[OS_WAVES][RS_MAX_BINS];
     __shared__ unsigned long long ptab[OS_WAVES][RS_MAX_BINS];      // match-any slots (wave_rank)
     __shared__ uint32_t dstart[RS_MAX_BINS];
@@ -475,7 +479,8 @@ static size_t onesweep_elems(size_t n)
 }
 
 static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
-                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt)
+                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt,
+                                     const uint32_t* run_if)
 {
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int nbins = 1 << dbits;
@@ -487,18 +492,19 @@ static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t*
     if (!scratch_is_zero) IBGS_HIP(hipMemsetAsync(scratch, 0, need * sizeof(uint32_t), s));
     const unsigned hb = (unsigned)((n + 8u * OS_HIST_THREADS - 1) / (8u * OS_HIST_THREADS));          // ~8 keys per thread (4 and 16 measured: 12.1 / 17.2 us against 12.2)
     const unsigned hblocks = hb < 256u ? (hb ? hb : 1u) : 256u;
-    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33);
+    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33, run_if);
     IBGS_HIP(hipGetLastError());
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
         hipLaunchKernelGGL(onesweep_pass_kernel, dim3(nblocks), dim3(OS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
                            n, pass * dbits, dbits, nbins, ghist + pass * RS_MAX_BINS, status + (size_t)pass * nblocks * RS_MAX_BINS,
                            tickets + pass, err_dev ? err_dev : tickets + 32, (kept_dev && pass == 0) ? 1 : 0, kept_dev ? kept_dev : tickets + 33,
-                           (result_alt && npass == 4 && pass == 3) ? result_alt : (uint32_t*)nullptr);
+                           (result_alt && npass == 4 && pass == 3) ? result_alt : (uint32_t*)nullptr, run_if);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
     if (cur != 0) {
+        if (run_if) { set_error("guarded radix sort: an odd number of passes would need an unguarded copy"); return -IBGS_ERR_INVALID; }
         IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
@@ -543,8 +549,17 @@ size_t radix_zero_elems(size_t n, int nbits_total)
     return (size_t)OS_MAX_PASS * RS_MAX_BINS + 64 + (size_t)npass * nblocks * RS_MAX_BINS;
 }
 
+bool radix_uses_onesweep(size_t n, int nbits_total)          // the single-launch passes (the only ones that can run guarded) would be taken for this sort
+{
+    if (n == 0 || nbits_total <= 0) return false;
+    const size_t nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    const int npass = (nbits_total + 7) / 8;
+    const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
+    return want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK;
+}
+
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt)
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt, const uint32_t* run_if)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -553,7 +568,8 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
     if (want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
-        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero, result_alt);
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero, result_alt, run_if);
+    if (run_if) { set_error("guarded radix sort: only the single-launch passes can run guarded"); return -IBGS_ERR_INVALID; }
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;

@@ -125,6 +125,17 @@ ORDER_HINT_GEO = os.environ.get("IBGS_ORDER_HINT_GEO", "0") == "1"          # (t
 ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p); the least recently used one goes first
 _order_hints = collections.OrderedDict()
 
+# Depth-bound hints (include/ibgs_rast.h: ibgs_forward_args.depth_bound_hint / depth_bound_out): per camera, the depth per tile behind which its last forward
+# reached nothing.  The next forward of that camera drops the Gaussians behind it before the depth sort, the SH pass and the binning -- most of a trained
+# scene's visible Gaussians -- and a device-side check plus a guarded repair pass keep the result exact when the scene has moved past the bound (so a stale
+# or foreign buffer -- a recycled view-matrix address -- costs time, never correctness).  One buffer per camera, updated in place by every forward.
+# OFF by default: on MI355X the repair pass's ~20 empty launches (2-3 us of GPU time each, queued behind the blend whether or not they have work) cost
+# more than the shorter sort / SH pass / binning bring -- C3 1080p steps: init 1.745 -> 1.795 ms, trained opacities 0.805 -> 0.868 ms, trained geo
+# 1.796 -> 1.807 ms with 36 % / 26 % / 70 % of the depth sort's input gone (tools/depth_bound_ab.py, docs/EXPERIMENTS.md section 11).
+DEPTH_BOUND = os.environ.get("IBGS_DEPTH_BOUND", "0") == "1"          # (the environment switch is for A/B runs)
+DEPTH_BOUND_MAX = 512          # cameras remembered (32 KB each at 1080p)
+_bound_hints = collections.OrderedDict()
+
 
 def _camera_key(viewmatrix, device, W, H, geo, stream):
     """(a colour pass and a geo pass of one camera keep separate orders: their kernels hold different numbers of waves per SIMD; and one buffer
@@ -483,6 +494,18 @@ class _CModule:
                     if oh is not None:
                         _order_hints.move_to_end(ckey)
                         a.tile_order_hint = oh.data_ptr()
+                if DEPTH_BOUND and RENDERED_HINT and sh_c is not None and not render_depth_only and not debug:
+                    bkey = _camera_key(viewmatrix, device, W, H, render_geo, stream)
+                    if bkey is not None:
+                        bh = _bound_hints.get(bkey)
+                        if bh is None:          # +inf everywhere = no bound: what the buffer says until a forward of this camera has left its own
+                            while len(_bound_hints) >= DEPTH_BOUND_MAX:
+                                _bound_hints.popitem(last=False)          # (a buffer an enqueued kernel still uses stays alive in the stream's allocator until it ran)
+                            bh = _bound_hints[bkey] = torch.full((((W + 15) // 16) * ((H + 15) // 16),), float("inf"), dtype=torch.float32, device=device)
+                        else:
+                            _bound_hints.move_to_end(bkey)
+                            a.depth_bound_hint = bh.data_ptr()
+                        a.depth_bound_out = bh.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
                 hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
                 prev = (max(hist) if isinstance(hist, list) else int(hist)) if hist else 0

@@ -201,6 +201,17 @@ typedef struct ibgs_forward_args {
      * torch.cat of scene/gaussian_model.py:140-143 (192 B read + written per Gaussian and call at M = 16, and its mirror image in the backward).  Both 16-byte aligned.
      * Results are bit-identical to the concatenated form. */
     const float* shs_rest;
+    /* Optional depth-bound hint (device pointers, ceil(W/16) x ceil(H/16) floats each; either may be NULL).  depth_bound_out receives, per tile, a depth a little
+     * behind the entry at which the tile's last pixel terminated in THIS forward (+inf where a pixel was still open).  Handed to a later forward of the SAME
+     * camera as depth_bound_hint, it lets the preprocess stage drop every Gaussian that lies behind the bound of all the tiles its rectangle covers before
+     * the depth sort, the SH evaluation and the binning see it: in a trained scene most visible Gaussians sit behind saturated pixels and are never reached.
+     * EXACT whatever the buffer holds: after the blend a kernel checks, per tile, that every pixel terminated in front of the tile's bound (then the lists
+     * the pixels saw are the unbounded ones entry for entry); if one did not -- the scene or the camera moved, garbage -- the frame is redone without a
+     * bound by a second pass queued behind the check, whose kernels all leave at once when the check was clean.  Outputs, arenas and gradients are those
+     * of a forward without the hint (the lists of an unrepaired frame lack entries no pixel reaches); the return value is R of the unbounded lists.
+     * Colour and render_geo passes with a rendered_hint; ignored with IBGS_FLAG_DEBUG, render_depth_only, n_views > 1, precomputed colours. */
+    const float* depth_bound_hint;
+    float* depth_bound_out;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {
