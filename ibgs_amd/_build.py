@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libibgs_rast.so")
-SOURCES = ["api", "preprocess", "scan_sort", "binning", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "adam", "compact", "deterministic", "loss", "depth_normal"]
+SOURCES = ["api", "preprocess", "scan_sort", "binning", "render_fwd", "render_bwd", "preprocess_bwd", "knn", "adam", "compact", "deterministic", "loss", "depth_normal", "activate"]
 EXTRA = {
     "preprocess": ["-ffp-contract=off"],           # bit-identical to the oracle (see preprocess.hip)
     # no SLP packing: v_pk_*_f32 is not faster than two scalar VALU ops on gfx950 and costs v_mov / s_nop glue
@@ -64,7 +64,7 @@ def csrc_sha():
 KERNEL_TU = (("render_fwd", "render_fwd"), ("pack_rgba", "render_fwd"), ("render_bwd", "render_bwd"), ("geo_window", "render_bwd"), ("tile_order", "render_bwd"),
              ("preprocess_bwd", "preprocess_bwd"), ("sh_grad", "preprocess_bwd"), ("preprocess_kernel", "preprocess"), ("sh_color", "preprocess"), ("mark_visible", "preprocess"),
              ("onesweep", "scan_sort"), ("radix", "scan_sort"), ("scan_", "scan_sort"), ("cell_", "binning"), ("expand_", "binning"), ("tile_ranges", "binning"),
-             ("l1_", "loss"), ("depth_normal", "depth_normal"), ("adam", "adam"), ("compact", "compact"), ("det_", "deterministic"), ("knn", "knn"))
+             ("l1_", "loss"), ("depth_normal", "depth_normal"), ("activate_", "activate"), ("adam", "adam"), ("compact", "compact"), ("det_", "deterministic"), ("knn", "knn"))
 
 
 def tu_of(kernel_name):

@@ -118,7 +118,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
            "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_densify_stats", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats",
            "ibgs_required_l1", "ibgs_l1_loss", "ibgs_l1_grad", "ibgs_l1_rescale",
-           "ibgs_depth_normal_forward", "ibgs_depth_normal_backward",
+           "ibgs_depth_normal_forward", "ibgs_depth_normal_backward", "ibgs_activate_forward", "ibgs_activate_backward",
            "ibgs_last_error", "ibgs_version"]
 
 _lib = None
@@ -190,6 +190,10 @@ def load():
     lib.ibgs_depth_normal_forward.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_float] * 4 + [ctypes.c_void_p] * 2
     lib.ibgs_depth_normal_backward.restype = ctypes.c_int32
     lib.ibgs_depth_normal_backward.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_float] * 4 + [ctypes.c_void_p] * 3
+    lib.ibgs_activate_forward.restype = ctypes.c_int32
+    lib.ibgs_activate_forward.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 6
+    lib.ibgs_activate_backward.restype = ctypes.c_int32
+    lib.ibgs_activate_backward.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 9
     lib.ibgs_l1_rescale.restype = ctypes.c_int32
     lib.ibgs_l1_rescale.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     lib.ibgs_required_geo_table.restype = ctypes.c_size_t

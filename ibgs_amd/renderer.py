@@ -24,6 +24,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from .activations import fused_activations, standard_model
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 _C0 = 0.28209479177387814
@@ -125,13 +126,27 @@ def _plane_map(pc, viewpoint_camera, learnt_normal, means3D):
 SPLIT_SH = True
 
 
+# The three activations of the model -- get_scaling = exp, get_rotation = F.normalize, get_opacity = sigmoid (scene/gaussian_model.py:44-52, 128-147), evaluated
+# by every render() call -- in ONE kernel each way (ibgs_amd/activations.py) instead of ~17 torch launches (exp, sigmoid, norm, clamp, expand, div and their
+# backward: ~0.09 ms of a 2.0 ms trainer iteration at 1 M Gaussians).  Only for a model that keeps the reference's raw parameters and activation functions
+# (`activations.standard_model`); anything else, and FUSED_ACTIVATIONS = False, goes through the model's own properties.
+FUSED_ACTIVATIONS = True
+
+
+def _activated(pc):
+    """(scales, rotations, opacities) of the model."""
+    if FUSED_ACTIVATIONS and standard_model(pc):
+        return fused_activations(pc._scaling, pc._rotation, pc._opacity)
+    return pc.get_scaling, pc.get_rotation, pc.get_opacity
+
+
 def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
+        opacities = pc.get_opacity
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
+        scales, rotations, opacities = _activated(pc)
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
@@ -149,7 +164,7 @@ def _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color):
                 shs = pc.get_features
     else:
         colors_precomp = override_color
-    return scales, rotations, cov3D_precomp, shs, colors_precomp
+    return scales, rotations, cov3D_precomp, shs, colors_precomp, opacities
 
 
 def _sh_kw(shs):
@@ -224,7 +239,7 @@ def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor
     dev = pc.get_xyz.device
     means2D, means2D_abs = _sinks(pc)
     means3D = pc.get_xyz
-    scales, rotations, cov3D_precomp, shs, colors_precomp = _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color)
+    scales, rotations, cov3D_precomp, shs, colors_precomp, opacities = _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color)
     if depth_error_threshold is None:
         depth_error_threshold = getattr(args, "depth_error_threshold", 0.01)
     n, ref_to_src_list, src_images, src_rendered_depths, src_cam_pos = _no_sources(viewpoint_camera, dev)
@@ -240,7 +255,7 @@ def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor
         debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     outs = rasterizer(means3D=means3D, means2D=means2D, means2D_abs=means2D_abs, **_sh_kw(shs),
-                      colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
+                      colors_precomp=colors_precomp, opacities=opacities, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, **_plane_inputs(pc, viewpoint_camera, learnt_normal, means3D, scales, rotations))
     return outs[3]
 
@@ -258,8 +273,9 @@ def render_depth_batch(viewpoint_cameras, pc, scene, pipe, args, bg_color, learn
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
+        opacities = pc.get_opacity
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        scales, rotations, opacities = _activated(pc)
     plane = _plane_inputs(pc, cams[0], learnt_normal, pc.get_xyz, scales, rotations) if FUSED_PLANE_MAP else {}
     if not same or "plane_mode" not in plane or len(cams) > _rl.MAX_VIEWS:
         return torch.stack([render_depth(c, pc, scene, pipe, args, bg_color, learnt_normal, nb_src_frames, buffer_length,
@@ -268,7 +284,7 @@ def render_depth_batch(viewpoint_cameras, pc, scene, pipe, args, bg_color, learn
     vms = torch.stack([c.world_view_transform.to(dev) for c in cams])
     pms = torch.stack([c.full_proj_transform.to(dev) for c in cams])
     cps = torch.stack([c.camera_center.to(dev) for c in cams])
-    depths, _ = rasterize_depth_batch(pc.get_xyz, pc.get_opacity, scales, rotations, cov3D_precomp, scaling_modifier, vms, pms, cps,
+    depths, _ = rasterize_depth_batch(pc.get_xyz, opacities, scales, rotations, cov3D_precomp, scaling_modifier, vms, pms, cps,
                                       [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], H, W,
                                       buffer_length, plane.get("plane_normal"), plane.get("plane_offset"), plane["plane_mode"],
                                       debug=pipe.debug)
@@ -359,7 +375,7 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
         depth_error_threshold = getattr(args, "depth_error_threshold", 0.01)
     depth_error_threshold = float(depth_error_threshold)
     means3D = pc.get_xyz
-    scales, rotations, cov3D_precomp, shs, colors_precomp = _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color)
+    scales, rotations, cov3D_precomp, shs, colors_precomp, opacities = _appearance(pc, pipe, viewpoint_camera, scaling_modifier, override_color)
 
     if render_geo:
         nearest = find_closest_frames(viewpoint_camera, scene, args) if do_find_closest_frame else viewpoint_camera.nearest_id
@@ -412,7 +428,7 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
     (rendered_image, radii, out_normal_map, out_median_intersected_depth, out_cam_feat, out_warped_image,
      out_min_depth_diff, out_camera_ray, use_first_src_frame_mask) = rasterizer(
         means3D=means3D, means2D=screenspace_points, means2D_abs=screenspace_points_abs, **_sh_kw(shs),
-        colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales, rotations=rotations,
+        colors_precomp=colors_precomp, opacities=opacities, scales=scales, rotations=rotations,
         cov3D_precomp=cov3D_precomp, **plane_kw)
 
     rendered_normal = out_normal_map[0:3] if render_geo else None

@@ -35,6 +35,7 @@ class SimpleCamera:
 
 class SimpleGaussians(torch.nn.Module):
     """Raw (pre-activation) parameters as nn.Parameters; getters apply the reference's activations."""
+    standard_activations = True          # exp / F.normalize / sigmoid on `_scaling` / `_rotation` / `_opacity`: the renderer may fuse them (ibgs_amd/activations.py)
 
     def __init__(self, g, sh_degree=3, device="cpu"):
         super().__init__()

@@ -354,6 +354,14 @@ int32_t ibgs_depth_normal_forward(void* stream, int32_t W, int32_t H, float fx, 
 int32_t ibgs_depth_normal_backward(void* stream, int32_t W, int32_t H, float fx, float fy, float cx, float cy, const float* depth,
                                    const float* dL_dnormal, float* dL_ddepth);
 
+/* Row G of SURVEY 8(a), model side: the activations render() applies to the raw parameters on every call (scene/gaussian_model.py:44-52, 128-147) -- scale =
+ * exp(raw_scale) (P x 3), rot = F.normalize(raw_rot) = raw_rot / max(|raw_rot|, 1e-12) (P x 4), opacity = sigmoid(raw_opacity) (P x 1) -- one kernel each way
+ * instead of ~17 torch launches.  Any of the three may be left out (NULL input; backward: NULL output).  Backward: d_* = dL/d raw_* from g_* = dL/d activated,
+ * every element written.  Arithmetic as torch's kernels, operation by operation (expf, 1 / (1 + expf(-x)), sqrtf of the sum of squares). */
+int32_t ibgs_activate_forward(void* stream, int32_t P, const float* raw_scale, const float* raw_rot, const float* raw_opacity, float* scale, float* rot, float* opacity);
+int32_t ibgs_activate_backward(void* stream, int32_t P, const float* raw_scale, const float* raw_rot, const float* raw_opacity,
+                               const float* g_scale, const float* g_rot, const float* g_opacity, float* d_scale, float* d_rot, float* d_opacity);
+
 /* Section 8(f) "next" row 3 -- replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26,
  * simple_knn.cu:185-220): out[i] = mean of the three smallest squared distances from point i to the other
  * points (exact).  `scratch` >= ibgs_required_knn(P) bytes, caller-owned, transient. */
