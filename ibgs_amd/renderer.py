@@ -262,7 +262,7 @@ def render_depth(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor
 
 def render_depth_batch(viewpoint_cameras, pc, scene, pipe, args, bg_color, learnt_normal: bool, nb_src_frames: int,
                        buffer_length: int, depth_error_threshold: Optional[float] = None, scaling_modifier=1.0,
-                       override_color=None):
+                       override_color=None, _activated_by_caller=None):
     """Depth maps of several cameras in ONE rasterizer pass: same results as
     `[render_depth(c, ...) for c in viewpoint_cameras]` stacked to (n, 1, H, W).  Falls back to that loop when the
     cameras differ in size or the fused plane-map inputs are unavailable."""
@@ -274,8 +274,8 @@ def render_depth_batch(viewpoint_cameras, pc, scene, pipe, args, bg_color, learn
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
         opacities = pc.get_opacity
-    else:
-        scales, rotations, opacities = _activated(pc)
+    else:          # (render() hands over what it has just computed for its own pass: the same model, the same call)
+        scales, rotations, opacities = _activated_by_caller if _activated_by_caller is not None else _activated(pc)
     plane = _plane_inputs(pc, cams[0], learnt_normal, pc.get_xyz, scales, rotations) if FUSED_PLANE_MAP else {}
     if not same or "plane_mode" not in plane or len(cams) > _rl.MAX_VIEWS:
         return torch.stack([render_depth(c, pc, scene, pipe, args, bg_color, learnt_normal, nb_src_frames, buffer_length,
@@ -393,7 +393,8 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
                 # the reference loops render_depth over the sources (:245-253); here they share ONE rasterizer pass
                 src_rendered_depths = render_depth_batch([scene.getTrainCameras()[i] for i in chosen], pc, scene, pipe, args, bg_color,
                                                          learnt_normal, nb_src_frames, buffer_length, depth_error_threshold,
-                                                         scaling_modifier, override_color)
+                                                         scaling_modifier, override_color,
+                                                         _activated_by_caller=(scales, rotations, opacities) if scales is not None else None)
             else:
                 src_rendered_depths = _rows(scene.rendered_depth_list, chosen)
             if cached is not None:
