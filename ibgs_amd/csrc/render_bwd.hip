@@ -372,6 +372,9 @@ __global__ void __launch_bounds__(256, 6) geo_window_kernel(BwdParams p)
             const float tz = r[8] * X + r[9] * Y + r[10] * Z + r[11];
             const float u = (tx * fx / tz) + cx, vv_ = (ty * fy / tz) + cy;
             if (u >= 0 && u <= W - 1 && vv_ >= 0 && vv_ <= H - 1) {
+                // past the decision: values only (gradient terms, compared with the oracle to a tolerance) -- multiply-adds may fuse here, which takes a
+                // third of the block's ~140 instructions away (tex_rgba_b keeps its own setting: the forward's fetch, bit for bit)
+#pragma clang fp contract(fast)
                 const float4* img = p.src_rgba + (size_t)si * HW;
                 const float4 c4 = tex_rgba_b(img, W, H, u + 0.5f, vv_ + 0.5f, p.tex_quant);
                 const float cc3[3] = {c4.x, c4.y, c4.z};

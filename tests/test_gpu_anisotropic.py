@@ -32,6 +32,24 @@ F64_K = 2.0
 # max(the usual bar, 3 x the oracle's own fma / no-fma difference), and the north-star bars (image L1 1e-4) still hold absolutely.
 
 
+class fixed_summation_order:
+    """On needle scenes the per-Gaussian gradients are sums of tile contributions a thousand times larger than their total: with float atomics the ORDER of
+    the additions moves dL/dmeans3D by 3e-3 of its norm from run to run (25 runs: 3.7e-3 .. 6.5e-3 from the float64 build, the fp32 oracle 3.6e-3) -- the
+    reference's own atomicAdd backward has the same freedom.  A bar that is to mean something cannot sit inside that scatter: those cases run the
+    deterministic backward (IBGS_FLAG_DETERMINISTIC: one fixed order), the default mode keeps its coverage on every other scene."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old = rasterizer.DETERMINISTIC
+        rasterizer.DETERMINISTIC = self.on or self.old
+
+    def __exit__(self, *exc):
+        rasterizer.DETERMINISTIC = self.old
+        return False
+
+
 def fma_twin(inp, grads):
     with oracle.variant("fma"):
         r = oracle.forward(inp, tex_quant=rasterizer.TEX_QUANT, cull=True)
@@ -91,7 +109,8 @@ def report(tag, o, ist, ref):
 def test_colour_path_on_anisotropic_gaussians(anisotropy, opacity):
     inp = scene(P=4000, W=208, H=144, deg=3, seed=31, opacity=opacity, anisotropy=anisotropy)
     g = {"color": rnd((3, 144, 208), 1)}
-    ref, o, ist, leaves, gb = run(inp, g)
+    with fixed_summation_order(anisotropy != "plane"):
+        ref, o, ist, leaves, gb = run(inp, g)
     twin, _ = fma_twin(inp, g)
     r64, g64 = f64_truth(inp, g)
     report("%s/%s" % (anisotropy, opacity), o, ist, ref)
@@ -133,7 +152,8 @@ def test_tile_culling_changes_no_result_on_anisotropic_gaussians(anisotropy):
     assert culled["num_rendered"] < 0.7 * full["num_rendered"]
     for k in ("color", "radii", "final_T"):
         assert np.array_equal(culled[k], full[k]), k                    # oracle vs oracle: bit-identical
-    ref, o, ist, leaves, _ = run(inp, g, cull=True)
+    with fixed_summation_order(anisotropy != "plane"):
+        ref, o, ist, leaves, _ = run(inp, g, cull=True)
     _, g64 = f64_truth(inp, g)
     assert ist["R"] == culled["num_rendered"]
     assert l1(o["color"], full["color"]) < (1e-6 if anisotropy == "plane" else 1e-5) and np.array_equal(o["radii"], full["radii"])
