@@ -207,3 +207,35 @@ def test_split_sh_arrays_under_a_bound():
         for x, y, what in zip(a[:4], b[:4], ("color", "dL/dsh dc", "dL/dsh rest", "dL/dopacity")):
             assert torch.equal(x, y), (i, what)
     assert got[3][4][12] == 0 and got[4][4][12] == 1
+
+
+@pytest.mark.parametrize("shape", ["tile", "quadrant"])
+@pytest.mark.parametrize("geo", [False, True], ids=["colour", "geo"])
+def test_forced_wave_shapes_under_a_bound(shape, geo):
+    """The `done` words every blend kernel variant leaves (one wave per tile, one per quadrant, two per tile) feed the same check."""
+    old = rasterizer.WAVE_SHAPE
+    rasterizer.WAVE_SHAPE = shape
+    try:
+        inp = dense(geo, 208, 144, P=30000)
+        ref = frames(inp, 2, False)
+        got = frames(inp, 4, True)
+    finally:
+        rasterizer.WAVE_SHAPE = old
+    for i, f in enumerate(got):
+        same_frame(f, ref[min(i, 1)], "%s frame %d" % (shape, i))
+    assert got[3]["meta"][12] == 0 and got[3]["st"]["R"] < got[3]["R"]
+
+
+def test_nothing_visible_and_tiny_frames_under_a_bound():
+    """R = 0 (every Gaussian behind the camera) and a frame of a single tile row: the bound buffers exist, nothing is dropped, nothing breaks."""
+    inp = scene(P=500, W=96, H=16, deg=1, seed=3, opacity="trained", scale_mul=3.0)
+    ref = frames(inp, 2, False)
+    got = frames(inp, 4, True)
+    for i, f in enumerate(got):
+        same_frame(f, ref[min(i, 1)], "one tile row, frame %d" % i)
+    far = dict(inp); far["means3D"] = (inp["means3D"] - np.array([0, 0, 500.0], np.float32)).astype(np.float32)
+    ref = frames(far, 2, False)
+    got = frames(far, 4, True)
+    for i, f in enumerate(got):
+        assert f["R"] == 0 or f["R"] == ref[min(i, 1)]["R"]
+        assert torch.equal(f["outs"]["color"], ref[min(i, 1)]["outs"]["color"])
