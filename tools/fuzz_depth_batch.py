@@ -36,8 +36,9 @@ for case in range(n_cases):
         a = batch[v].cpu().numpy()
         d = np.abs(a - ref)
         tame = np.abs(ref) < 10.0 * max(float(np.median(np.abs(ref[ref != 0]))) if (ref != 0).any() else 1.0, 1e-6)
-        worst_frac = max(worst_frac, float((d > 1e-3 * (1 + np.abs(ref))).mean()))
-        worst_mean = max(worst_mean, float(d[tame].mean() / (np.abs(ref[tame]).mean() + 1e-9)))
+        off = d > 1e-3 * (1 + np.abs(ref))          # pixels where a decision on a rounded float (T > 0.5, depth > 0) fell the other way: counted, not averaged --
+        worst_frac = max(worst_frac, float(off.mean()))          # ONE of them on a grazing plane is 10^2 scene units and would be the whole mean
+        worst_mean = max(worst_mean, float(d[tame & ~off].mean() / (np.abs(ref[tame]).mean() + 1e-9)))
     ok = same and worst_frac < 2e-3 and worst_mean < 1e-4
     bad += not ok
     print("%s case %2d: %dx%d views %d learnt %d L %d | batch == singles %s, pixels off by > 1e-3: %.2e, mean rel (tame pixels) %.2e"

@@ -4,6 +4,7 @@ python tools/fuzz_fused.py [n_cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
 from tests.metrics import l1, rel_l2
 from tests.test_gpu_fused_planes import _oracle_chain, _run, _scene
 
@@ -19,7 +20,16 @@ for case in range(n_cases):
     names = ["_xyz", "_rotation", "_scaling", "_opacity", "_features_dc"] + (["_normal", "_offset"] if learnt else [])
     errs = {n: (rel_l2(g_fus[n], g_orc[n]) if g_orc[n] is not None and np.abs(g_orc[n]).sum() > 0 else float("nan")) for n in names}
     worst = max(v for v in errs.values() if v == v) if any(v == v for v in errs.values()) else 0.0
+    note = ""
+    if worst >= 5e-3:
+        # the arbiter (tests/test_gpu_anisotropic.py): one decision on a rounded float -- in the fp32 oracle as easily as in the kernels -- moves a gradient of
+        # a 6 000-Gaussian scene by per cents; the float64 build of the oracle says who is off
+        with oracle.variant("f64"):
+            _, g_64 = _oracle_chain(learnt, g, dev, cams, scene, bg)
+        e64 = {n: (rel_l2(g_fus[n], g_64[n]), rel_l2(g_orc[n], g_64[n])) for n in names if errs[n] == errs[n]}
+        worst = max((a if a > max(5e-3, 2.0 * b) else 0.0) for a, b in e64.values())
+        note = " | vs float64 (HIP, oracle fp32): %s" % {k: "%.1e, %.1e" % v for k, v in e64.items()}
     ok = dc < 1e-6 and dn < 1e-5 and worst < 5e-3
     bad += not ok
-    print("%s case %2d: P %d %dx%d seed %d learnt %d | colour %.1e normal %.1e grads %s" % ("ok  " if ok else "FAIL", case, P, W, H, seed, learnt, dc, dn, {k: "%.1e" % v for k, v in errs.items()}), flush=True)
+    print("%s case %2d: P %d %dx%d seed %d learnt %d | colour %.1e normal %.1e grads %s%s" % ("ok  " if ok else "FAIL", case, P, W, H, seed, learnt, dc, dn, {k: "%.1e" % v for k, v in errs.items()}, note), flush=True)
 print("failures:", bad)
