@@ -129,6 +129,14 @@ __device__ __forceinline__ void stage_for_exp2(float4& pos_opacity_quad, float4&
 constexpr float POWER_RISK = 0.99999f;
 constexpr float LOG2_E = 1.4426950408889634f;
 __device__ __forceinline__ bool conic_is_risky(float a, float b, float c) { return b * b > POWER_RISK * (a * c); }
+// The blend kernels take E from the reference's per-pixel expression for a WIDER class than the one the `power > 0` test can fire for (round 5): the shifted
+// quadratic form's rounding error is a few ulp of S = a dx^2 + c dy^2, which stands to E as 1 : (1 - b^2 / (a c)) -- at 10^-3 from singular every ulp of S is
+// 10^3 ulp of E.  For conics within 10^-3 of singular both passes therefore follow the reference's rounding (the same wave-uniform branch; such conics are
+// rare outside needle scenes: no measurable cost on the bench workloads).  Measured on tests/test_gpu_anisotropic.py's scenes: colour mean L1 against the
+// oracle 5.3e-07 .. 3.3e-06 -> 1.8e-08 (giant needles), 1.1e-06 -> 2.2e-07 (needles), n_contrib equal on 99.997 % -> 100 % of the pixels.  The tile cull's
+// exemption keeps POWER_RISK: its 0.1 % margin covers this class (4 ulp of S <= 2.4e-4 E here).
+constexpr float BLEND_REF_POWER_RISK = 0.999f;
+__device__ __forceinline__ bool conic_takes_ref_power(float a, float b, float c) { return b * b > BLEND_REF_POWER_RISK * (a * c); }
 __device__ __forceinline__ float ref_power_E(float dx, float dy, float a, float b, float c, float neg_log2_opacity)
 {
 #pragma clang fp contract(off)

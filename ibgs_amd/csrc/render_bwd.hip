@@ -169,7 +169,7 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
             float4 ra = r[0];
             ra.w = __uint_as_float(id);            // the record's spare slot carries the Gaussian index to the atomic
             float4 c1 = r[1];
-            risky = conic_is_risky(c1.x, c1.y, c1.z);
+            risky = conic_takes_ref_power(c1.x, c1.y, c1.z);
             stage_for_exp2(ra, c1);                            // as the forward stages them (common.h): same numbers, same decisions
             s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = r[2];
         }
@@ -508,7 +508,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p, const in
             float4 ra = r[0];
             ra.w = __uint_as_float(id);
             float4 c1 = r[1];
-            risky = conic_is_risky(c1.x, c1.y, c1.z);
+            risky = conic_takes_ref_power(c1.x, c1.y, c1.z);
             stage_for_exp2(ra, c1);
             s_rec[0][lane] = ra; s_rec[1][lane] = c1; s_rec[2][lane] = r[2]; s_rec[3][lane] = r[3];
         }

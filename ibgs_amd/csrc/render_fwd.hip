@@ -217,7 +217,7 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
         if constexpr (GEO) {
             float4 v = ahead;
             const int qd = lane & 3;
-            const bool risky = qd == 1 && base + (lane >> 2) < n && conic_is_risky(v.x, v.y, v.z);
+            const bool risky = qd == 1 && base + (lane >> 2) < n && conic_takes_ref_power(v.x, v.y, v.z);
             // stage_for_exp2 (common.h), one quad per lane: quad 0 carries the opacity, quad 1 the conic
             if (qd == 0) v.z = -__builtin_amdgcn_logf(v.z);
             if (qd == 1) { v.x *= EXP2_SCALE; v.y *= EXP2_SCALE; v.z *= EXP2_SCALE; }
@@ -231,7 +231,7 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
                 const uint32_t id = p.point_list[r0 + e];
                 const float4* r = p.rec + (size_t)id * 4;
                 float4 c0 = r[0], c1 = r[1];
-                risky = conic_is_risky(c1.x, c1.y, c1.z);
+                risky = conic_takes_ref_power(c1.x, c1.y, c1.z);
                 stage_for_exp2(c0, c1);                        // conic in units of the exp2 exponent, opacity as -log2 (common.h)
                 s_rec[0][lane] = c0;
                 s_rec[1][lane] = c1;
