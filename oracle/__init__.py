@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libibgs_oracle.so")
 _SO_FMA = os.path.join(_HERE, "_build", "libibgs_oracle_fma.so")
 _SO_F64 = os.path.join(_HERE, "_build", "libibgs_oracle_f64.so")
+_SO_ACC32 = os.path.join(_HERE, "_build", "libibgs_oracle_acc32.so")
 _RT = np.float32          # element type of the float arrays at the C interface: float32, float64 inside `variant("f64")`
 _SRC = os.path.join(_HERE, "ibgs_oracle.c")
 _lib = None
@@ -35,9 +36,11 @@ def build(force=False):
     (-fmad=true is its default) in a pattern that cannot be known here, so the difference between the two builds is the size of what
     the reference's own arithmetic leaves undetermined -- tests use it as the noise floor of ill-conditioned quantities.
     A third build, `variant("f64")`, turns every float of the source into a double (-DORC_F64): the arbiter for ill-conditioned quantities --
-    a float build is as good as its distance from this one."""
+    a float build is as good as its distance from this one.  A fourth, `variant("acc32")` (-DORC_ACC_FLOAT), is the oracle proper with its per-Gaussian gradient
+    sums kept in float like the reference's atomicAdd (single-threaded, pixel order): a diagnostic for what float accumulation alone costs."""
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
-    for so, flags in ((_SO, ["-ffp-contract=off"]), (_SO_FMA, ["-ffp-contract=fast", "-mfma"]), (_SO_F64, ["-ffp-contract=off", "-DORC_F64"])):
+    for so, flags in ((_SO, ["-ffp-contract=off"]), (_SO_FMA, ["-ffp-contract=fast", "-mfma"]), (_SO_F64, ["-ffp-contract=off", "-DORC_F64"]),
+                      (_SO_ACC32, ["-ffp-contract=off", "-DORC_ACC_FLOAT"])):
         if (not force) and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(_SRC):
             continue
         subprocess.check_call(["gcc", "-O2"] + flags + ["-fno-fast-math", "-fopenmp", "-shared", "-fPIC", "-o", so, _SRC, "-lm"])
@@ -66,8 +69,8 @@ class variant:
     build in which every float is a double (inputs are converted, results come back as float64 arrays) -- see build()."""
 
     def __init__(self, name):
-        assert name in ("fma", "plain", "f64")
-        self.path = {"fma": _SO_FMA, "plain": _SO, "f64": _SO_F64}[name]
+        assert name in ("fma", "plain", "f64", "acc32")
+        self.path = {"fma": _SO_FMA, "plain": _SO, "f64": _SO_F64, "acc32": _SO_ACC32}[name]
         self.rt = np.float64 if name == "f64" else np.float32
 
     def __enter__(self):

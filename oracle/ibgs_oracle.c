@@ -24,6 +24,15 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+/* Per-Gaussian gradient sums over pixels.  Default: double accumulators (see "Arithmetic" above).  -DORC_ACC_FLOAT (oracle.variant("acc32")): every addition is
+ * rounded to float, i.e. what the reference's float atomicAdd (backward.cu:673, 770, 793-804) and any fp32 implementation keep -- in ONE thread and pixel order
+ * here, so the result is reproducible.  A diagnostic: how far float accumulation alone moves an ill-conditioned gradient (tools/fuzz_parity.py). */
+#ifdef ORC_ACC_FLOAT
+#define ACC_ADD(dst, v) do { (dst) = (double)(float)((float)(dst) + (float)(v)); } while (0)
+#else
+#define ACC_ADD(dst, v) do { _Pragma("omp atomic") (dst) += (double)(v); } while (0)
+#endif
 #include <string.h>
 
 /* Third build of this one source (oracle.variant("f64"), gcc -DORC_F64): every `float` of the restatement -- arrays at the interface
@@ -730,7 +739,9 @@ void orc_render_backward(
     /* rows in parallel; the double accumulators are updated atomically (sum order is then
      * nondeterministic at the 1e-16 level, far below the fp32 results being checked) */
     long long nskip = 0;
+#ifndef ORC_ACC_FLOAT
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : nskip)
+#endif
     for (int py = 0; py < H; py++) for (int px = 0; px < W; px++) {
         const size_t pix = (size_t)py * W + px;
         const int tile = (py / TILE) * gx + (px / TILE);
@@ -777,8 +788,7 @@ void orc_render_backward(
                 accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
                 last_color[ch] = c;
                 dL_dalpha += (c - accum_rec[ch]) * g_pix[ch];
-#pragma omp atomic
-                acc_color[3 * id + ch] += (double)(w * g_pix[ch]);
+                ACC_ADD(acc_color[3 * id + ch], (w * g_pix[ch]));
             }
             if (render_geo) {
                 const float* am = all_map + 5 * id;
@@ -839,8 +849,7 @@ void orc_render_backward(
                     }
                 }
                 for (int ch = 0; ch < 5; ch++) {
-#pragma omp atomic
-                    acc_all_map[5 * id + ch] += (double)gm[ch];
+                    ACC_ADD(acc_all_map[5 * id + ch], gm[ch]);
                 }
             }
             dL_dalpha *= T;
@@ -852,22 +861,14 @@ void orc_render_backward(
             const float dG_ddelx = -gdx * co[0] - gdy * co[1];
             const float dG_ddely = -gdy * co[2] - gdx * co[1];
             const float mx = dL_dG * dG_ddelx * ddelx_dx, my = dL_dG * dG_ddely * ddely_dy;
-#pragma omp atomic
-            acc_mean2D[2 * id] += (double)mx;
-#pragma omp atomic
-            acc_mean2D[2 * id + 1] += (double)my;
-#pragma omp atomic
-            acc_mean2D_abs[2 * id] += (double)fabsf(mx);
-#pragma omp atomic
-            acc_mean2D_abs[2 * id + 1] += (double)fabsf(my);
-#pragma omp atomic
-            acc_conic[3 * id + 0] += (double)(-0.5f * gdx * dx * dL_dG);
-#pragma omp atomic
-            acc_conic[3 * id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
-#pragma omp atomic
-            acc_conic[3 * id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
-#pragma omp atomic
-            acc_opacity[id] += (double)(G * dL_dalpha);
+            ACC_ADD(acc_mean2D[2 * id], mx);
+            ACC_ADD(acc_mean2D[2 * id + 1], my);
+            ACC_ADD(acc_mean2D_abs[2 * id], fabsf(mx));
+            ACC_ADD(acc_mean2D_abs[2 * id + 1], fabsf(my));
+            ACC_ADD(acc_conic[3 * id + 0], (-0.5f * gdx * dx * dL_dG));
+            ACC_ADD(acc_conic[3 * id + 1], (-0.5f * gdx * dy * dL_dG));
+            ACC_ADD(acc_conic[3 * id + 2], (-0.5f * gdy * dy * dL_dG));
+            ACC_ADD(acc_opacity[id], (G * dL_dalpha));
         }
     }
     g_power_skips[1] = nskip;
