@@ -700,6 +700,8 @@ def main():
     ap.add_argument("--geo", action="store_true", help="make render_geo=True, n_src=4, L=4 the timed workload (second line of SURVEY 8(d))")
     ap.add_argument("--wave-shape", default=None, choices=["tile", "quadrant"], help="force the blend kernels' work decomposition (experiments)")
     ap.add_argument("--no-geo-line", action="store_true", help="skip the extra (untimed for `value`) geo measurement in the default line")
+    ap.add_argument("--force-exchange", action="store_true", help="--gpus 1 only: initialise a process group of ONE rank (nccl = RCCL) and run the view-parallel exchange through it -- every "
+                    "collective of the N-GPU step is issued at world size 1; the line gains the `rccl` object (exchange_ms = the fixed cost of the path)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (view hopping, test-time frame, torch-L1 step, C1 CPU baseline protocol)")
     a = ap.parse_args()
 
@@ -712,13 +714,14 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
-    rank, world, local_rank = vdist.init_from_env(backend=os.environ.get("IBGS_DIST_BACKEND"))   # default: nccl (= RCCL)
+    forced = bool(a.force_exchange) and a.gpus == 1
+    rank, world, local_rank = vdist.init_from_env(backend=os.environ.get("IBGS_DIST_BACKEND"), force=forced)   # default: nccl (= RCCL)
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
-    backend = dist.get_backend() if world > 1 else None
+    backend = dist.get_backend() if (world > 1 or forced) else None
     if world > ndev and not (os.environ.get("IBGS_BENCH_SHARE_GPU") == "1" and backend == "gloo"):
         raise SystemExit("bench.py: %d ranks but %d GPU(s)" % (world, ndev))
     local_rank %= max(ndev, 1)
@@ -732,10 +735,10 @@ def main():
         _rz.WAVE_SHAPE = a.wave_shape
     wl = Workload(a.config, rank % 8, dev, a.opacity, a.geo, a.forward_only, 1234 + rank)
     reducer = None
-    if world > 1:
+    if world > 1 or forced:
         # the leaves go into the rasterizer as they are: its backward writes their gradients straight into the all-reduce bucket
         reducer = vdist.ViewParallelReducer(wl.params, sh=wl.leaves["shs"], means3D=wl.leaves["means3D"], factored=(a.exchange == "factored"),
-                                            agree_every=a.agree_every,
+                                            agree_every=a.agree_every, force=forced,
                                             direct={k: wl.leaves[k] for k in ("means3D", "opacities", "scales", "rotations")})
 
     def step():
@@ -750,7 +753,7 @@ def main():
 
     m = measure(wl, step, a.steps, a.warmup, world)
     rccl = None
-    if world > 1 and not a.forward_only:
+    if (world > 1 or forced) and not a.forward_only:
         # serial cost of the exchange alone (hipEvents around reduce() on the compute stream, which waits for the collectives),
         # and the step without any exchange; neither enters `value`
         n_x = 5
@@ -905,6 +908,8 @@ def main():
         }
         if rccl is not None:
             out["rccl"] = rccl
+            if forced:
+                out["forced_exchange"] = True          # the timed step ran the N-GPU exchange at world size 1 (its fixed cost is inside `value`)
         if geo_line is not None:
             out["geo"] = geo_line
         if trained_geo is not None:
@@ -916,7 +921,7 @@ def main():
                 out["cpu_baseline"]["c1_protocol"] = cpu_baseline_c1(dev)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,6 +24,7 @@ FLAG_TEX_PACKED = 256
 FLAG_NO_REF_POWER_SKIP = 512
 FLAG_NO_ABS_GRAD = 1024
 FLAG_SPLIT_GEO_EPILOGUE = 2048
+FLAG_REF_ARITH = 4096
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 MAX_VIEWS = 8
 

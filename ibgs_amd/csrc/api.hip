@@ -94,6 +94,7 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.tile_walked = c.take<uint32_t>(tiles * 4);
     im.tile_order = c.take<uint32_t>((tiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES);
     im.tile_done = c.take<uint32_t>(tiles * 4);
+    im.tile_risky = c.take<uint32_t>(tiles * 4);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;
 }
@@ -246,7 +247,7 @@ size_t ibgs_tile_order_slots(int32_t W, int32_t H)
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
 {
     size_t t; ImgState im = ImgState::carve(nullptr, W, H, &t);
-    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order); OFF(im, tile_done);
+    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order); OFF(im, tile_done); OFF(im, tile_risky);
     return -1;
 }
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
@@ -574,7 +575,8 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     float* geo_tab = nullptr;
     if (a.render_geo) {
         float4* t = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127));
-        if (!(a.flags & IBGS_FLAG_TEX_PACKED) && (rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
+        const bool window = a.dL_ddepth || a.dL_dwarped;          // only the window pass (median depth / warp gradients) reads the textures and fills the table
+        if (window && !(a.flags & IBGS_FLAG_TEX_PACKED) && (rc = launch_pack_rgba(s, a.src_images, t, a.W, a.H, a.n_src))) return rc;
         rgba = t;
         geo_tab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(a.geo_table) + 127) & ~uintptr_t(127));
     }

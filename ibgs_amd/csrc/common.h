@@ -75,6 +75,8 @@ struct ImgState {
     uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)
     uint32_t* tile_done;   // tiles x 4   per wave of the tile (layout of tile_walked): the 1-based list position at which its last pixel terminated, 0xFFFFFFFF if one was still
                            //             open at the end of the list; meta[12] = 1: the depth bound was violated somewhere and the guarded repair pass ran, [13] = dirty tiles
+    uint32_t* tile_risky;  // tiles x 4   per wave of the tile: non-zero when the forward staged a record whose conic is near-singular (conic_takes_ref_power) -- the backward walks such
+                           //             tiles with its reference-arithmetic kernels (render_bwd.hip)
     static ImgState carve(char* base, int W, int H, size_t* total);
 };
 
@@ -464,6 +466,7 @@ struct DetState {
     static DetState carve(char* base, size_t rows, size_t P, size_t* total);          // rows = R x waves per tile
 };
 int render_backward_waves_per_tile(const ibgs_backward_args& a);
+int render_backward_ref_arith(uint32_t flags);          // how the blend backward sums the pairs of near-singular conics (render_bwd.hip: RA_*); bit 4 (RA_ASSOC): their rows hold the reference's sums
 int launch_det_prepare(hipStream_t s, const DetState& d, size_t rows);                    // zero the slab
 int launch_det_reduce(hipStream_t s, const DetState& d, const uint32_t* point_list, size_t R, int ipt, int P, float* gacc, const uint32_t* listed /* device word: entries the lists hold (<= R) */);
 int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, const float* means3D, const float* camposes,

@@ -25,6 +25,7 @@ struct PreBwdParams {
     const float* cov3D;        // precomputed input or the forward's computed one
     float* gacc;               // P x 16 moment rows written by render_bwd.hip (re-zeroed here when clear_gacc)
     int clear_gacc;
+    int risky_rows;            // format of a near-singular conic's row (render_bwd.hip): 0 = moments like every other row (no reference branch), 1 = RA_LFORM sums, 2 = RA_ASSOC (the reference's sums)
     const float* rec;          // P x 16 forward records (conic, opacity)
     float* dL_dmean2D; float* dL_dmean2D_abs; float* dL_dconic; float* dL_dopacity; float* dL_dcolors;
     float* dL_dall_map; float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dsh_rest; float* dL_dscale; float* dL_drot;
@@ -155,16 +156,22 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
     // (backward.cu:786-804): dG/ddelx = -G (a dx + b dy), conic grads -0.5 G d d^T, dL/do = G dL/dalpha.
     const float ddelx_dx = (float)(0.5 * cam.W), ddely_dy = (float)(0.5 * cam.H);
     const float ca2 = r1.x, cb2 = r1.y, cc2 = r1.z, opa = r0.z;
-    const float g2x = -ddelx_dx * (ca2 * g0.x + cb2 * g0.y);   // dL/dmean2D
-    const float g2y = -ddely_dy * (cc2 * g0.y + cb2 * g0.x);
-    const float gcx = -0.5f * g1.x, gcy = -0.5f * g1.y, gcz = -0.5f * g1.z; // dL/dconic (a, b, c)
+    // A near-singular conic's row (render_bwd.hip, "near-singular conics"): RA_LFORM -- sums of q l, |q l|, q l l^T with l = (conic in exp2 units) d: the conic is
+    // already applied, and the three second moments ARE dL/dcov2D up to 0.5, 1, 0.5 (and the scale): taken below instead of the chain of backward.cu:405-420;
+    // RA_ASSOC -- the reference's own per-pair quantities (dL/dG dG/ddel, its magnitude, gd d dL/dG, G dL/dalpha): only 0.5 W, 0.5 H and -0.5 remain to be applied
+    const int risky_row = conic_takes_ref_power(ca2, cb2, cc2) ? p.risky_rows : 0;
+    const bool ref_row = risky_row == 2, l_row = risky_row == 1;
+    const float g2x = ref_row ? ddelx_dx * g0.x : (l_row ? -ddelx_dx * (g0.x * EXP2_UNSCALE) : -ddelx_dx * (ca2 * g0.x + cb2 * g0.y));   // dL/dmean2D
+    const float g2y = ref_row ? ddely_dy * g0.y : (l_row ? -ddely_dy * (g0.y * EXP2_UNSCALE) : -ddely_dy * (cc2 * g0.y + cb2 * g0.x));
+    const float gcx = -0.5f * g1.x, gcy = -0.5f * g1.y, gcz = -0.5f * g1.z; // dL/dconic (a, b, c)   (l_row: not the conic gradient -- see dL_dconic below)
     const float gcol[3] = {g2.x, g2.y, g2.z};
 
     p.dL_dmean2D[3 * i] = g2x; p.dL_dmean2D[3 * i + 1] = g2y; p.dL_dmean2D[3 * i + 2] = 0.f;
     // (the blend kernels form sum |q (conic d)| with the conic in exp2 units, common.h: undone here, once per Gaussian)
-    if (p.dL_dmean2D_abs) { p.dL_dmean2D_abs[3 * i] = ddelx_dx * (g0.z * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * (g0.w * EXP2_UNSCALE); p.dL_dmean2D_abs[3 * i + 2] = 0.f; }
-    if (p.dL_dconic) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }
-    p.dL_dopacity[i] = opa > 0.f ? g1.w / opa : 0.f;
+    const float abs_unscale = ref_row ? 1.0f : EXP2_UNSCALE;
+    if (p.dL_dmean2D_abs) { p.dL_dmean2D_abs[3 * i] = ddelx_dx * (g0.z * abs_unscale); p.dL_dmean2D_abs[3 * i + 1] = ddely_dy * (g0.w * abs_unscale); p.dL_dmean2D_abs[3 * i + 2] = 0.f; }
+    if (p.dL_dconic && !l_row) { p.dL_dconic[4 * i] = gcx; p.dL_dconic[4 * i + 1] = gcy; p.dL_dconic[4 * i + 2] = 0.f; p.dL_dconic[4 * i + 3] = gcz; }          // (l_row: below, once cov2D is known)
+    p.dL_dopacity[i] = ref_row ? g1.w : (opa > 0.f ? g1.w / opa : 0.f);          // (l_row: sum q, like every other row)
     if ((WRITE_SH || !p.shs) && p.dL_dcolors) { p.dL_dcolors[3 * i] = gcol[0]; p.dL_dcolors[3 * i + 1] = gcol[1]; p.dL_dcolors[3 * i + 2] = gcol[2]; }
     if (p.dL_dall_map) {
         p.dL_dall_map[5 * i] = g2.w; p.dL_dall_map[5 * i + 1] = g3.x; p.dL_dall_map[5 * i + 2] = g3.y;
@@ -253,6 +260,19 @@ __global__ void __launch_bounds__(FAST16 ? 64 : 256) preprocess_bwd_kernel(PreBw
         da = d2inv * (-c_ * c_ * gcx + 2 * b_ * c_ * gcy + (denom - a_ * c_) * gcz);
         dc = d2inv * (-a_ * a_ * gcz + 2 * a_ * b_ * gcy + (denom - a_ * c_) * gcx);
         db = d2inv * 2 * (b_ * c_ * gcx - (denom + 2 * b_ * b_) * gcy + a_ * b_ * gcz);
+        if (l_row) {
+            // the three expressions above are -(c dx - b dy)^2, -(a dy - b dx)^2 and their product summed over the pairs, i.e. det^2 x the sums of q l_x^2, q l_y^2,
+            // q l_x l_y with l = conic d -- which is what the blend accumulated for this Gaussian, pair by pair, with nothing cancelling (render_bwd.hip: RA_LFORM)
+            const float kk = d2inv * (denom * denom);          // = det^2 / (det^2 + 1e-7): the reference's regulariser, kept
+            const float m00 = g1.x * (EXP2_UNSCALE * EXP2_UNSCALE), m01 = g1.y * (EXP2_UNSCALE * EXP2_UNSCALE), m11 = g1.z * (EXP2_UNSCALE * EXP2_UNSCALE);          // sum q l l^T with the unscaled conic
+            da = kk * 0.5f * m00; db = kk * m01; dc = kk * 0.5f * m11;
+            if (p.dL_dconic) {          // the optional dL/dconic output of such a Gaussian, back from its sums: d = cov2D l, so sum q d d^T = cov2D (sum q l l^T) cov2D
+                p.dL_dconic[4 * i] = -0.5f * (a_ * a_ * m00 + 2 * a_ * b_ * m01 + b_ * b_ * m11);
+                p.dL_dconic[4 * i + 1] = -0.5f * (a_ * b_ * m00 + (a_ * c_ + b_ * b_) * m01 + b_ * c_ * m11);
+                p.dL_dconic[4 * i + 2] = 0.f;
+                p.dL_dconic[4 * i + 3] = -0.5f * (b_ * b_ * m00 + 2 * b_ * c_ * m01 + c_ * c_ * m11);
+            }
+        }
         gS[0] = (A[0][0] * A[0][0] * da + A[0][0] * A[1][0] * db + A[1][0] * A[1][0] * dc);
         gS[3] = (A[0][1] * A[0][1] * da + A[0][1] * A[1][1] * db + A[1][1] * A[1][1] * dc);
         gS[5] = (A[0][2] * A[0][2] * da + A[0][2] * A[1][2] * db + A[1][2] * A[1][2] * dc);
@@ -460,6 +480,7 @@ int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const
     p.scales = a.scales; p.rotations = a.rotations; p.scale_modifier = a.scale_modifier;
     p.cov3D = a.cov3D_precomp ? a.cov3D_precomp : g.cov3D;
     p.gacc = a.grad_acc; p.rec = g.rec; p.clear_gacc = (a.flags & IBGS_FLAG_CLEAR_GRAD_ACC) ? 1 : 0;
+    { const int ra = render_backward_ref_arith(a.flags); p.risky_rows = (ra & 4) ? 2 : ((ra & 2) ? 1 : 0); }          // RA_ASSOC / RA_LFORM (render_bwd.hip)
     p.dL_dmean2D = a.dL_dmean2D; p.dL_dmean2D_abs = a.dL_dmean2D_abs; p.dL_dconic = a.dL_dconic;
     p.dL_dopacity = a.dL_dopacity; p.dL_dcolors = a.dL_dcolors; p.dL_dall_map = a.dL_dall_map;
     p.dL_dmean3D = a.dL_dmean3D; p.dL_dcov3D = a.dL_dcov3D; p.dL_dsh = a.dL_dsh; p.dL_dsh_rest = a.dL_dsh_rest; p.dL_dscale = a.dL_dscale; p.dL_drot = a.dL_drot;

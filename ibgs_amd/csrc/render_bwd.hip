@@ -43,7 +43,9 @@ struct BwdParams {
     int ntiles;
     TileMap tmap;
     int n_src; int tex_quant;
-    int power_skip;       // as the forward (render_fwd.hip, common.h)
+    int power_skip;       // RA_* bits (below): 0 = no reference branch at all (IBGS_FLAG_NO_REF_POWER_SKIP), else how the pairs of near-singular conics are evaluated
+    const uint32_t* tile_risky;      // 4 words per tile, written by the forward (ImgState::tile_risky): non-zero = the tile's list holds a near-singular conic.  Those tiles belong to
+                                     // the *_risk_kernel launched beside every blend kernel; the fast kernels skip them (nullptr: nobody skips anything)
     const float* ref_to_src; const float4* src_rgba;
     const float* final_T; const uint32_t* n_contrib; const float* sum_w; const uint32_t* low_high;
     const int32_t* valid_idx; const float* valid_w;
@@ -93,6 +95,72 @@ __device__ __forceinline__ float fast_rcp(float x)
     return r * (2.0f - x * r);
 }
 
+
+// ---- near-singular conics (round 6) --------------------------------------------------------------------------------------------------------
+// A conic within 10^-3 of singular (common.h: conic_takes_ref_power) is where fp32 shows in the gradients: the chain of backward.cu:405-420 forms
+// dL/dcov2D = (-c^2 Sxx + 2bc Sxy - b^2 Syy) / det^2 from the pixel sums S = sum q d d^T, a difference of near-equal numbers that turns every ulp
+// of S into 10^3-10^4 ulp of the result.  Measured on the needle scenes of tests/test_gpu_fuzz_pins.py (profiles/r06_ref_arith_ab.txt): ANY
+// fp32 evaluation of that chain -- the oracle's two builds, its float-sum build, the kernels with libm exp / IEEE division / the reference's association
+// in any combination, with one summation order or another -- lands 1e-3 .. 3e-2 from the float64 evaluation, and which one is closest changes with the
+// order of the additions alone (ratio to the fp32 oracle builds: 0.8 .. 3.9 on one scene).  No per-pair value carries that; the chain does.  So for those
+// Gaussians the blend sums what the chain really needs,
+//        dL/dcov2D = 0.5 sum_pairs q l l^T,   l = conic d   (algebraically the same: -c^2 dx^2 + 2bc dx dy - b^2 dy^2 = -(c dx - b dy)^2 = -(det l_x)^2),
+// per pixel, where nothing cancels (RA_LFORM, the default: l_moments below, a wave-uniform branch of the fast kernels; preprocess_bwd.hip takes the three
+// sums as dL/dcov2D): 3-10 x closer to float64 than the reference's own fp32 arithmetic and the same from run to run, whatever the order.
+// IBGS_FLAG_REF_ARITH selects the reference's arithmetic to the letter instead (RA_ASSOC; SURVEY Q1 as a switch): G = exp(power) at libm accuracy
+// (backward.cu:648), T / (1 - alpha) as an IEEE division (:654), the eight per-pair quantities of :779-804 in its association, uncontracted; the row then
+// holds the reference's sums and the ill-conditioned chain runs as the reference runs it.  That block (libm exp, divisions, eight more sums) does not fit
+// beside the fast path -- inlined it cost the hot loops 19-40 spilled VGPRs, as a called function 60 % of the kernel's time -- so under the flag the tiles
+// whose list holds such a conic (flagged by the forward: ImgState::tile_risky) are walked by kernels of their own (*_risk_kernel: the RISK = true
+// instantiation of the bodies below, launched behind the blend kernel, which skips those tiles).
+// The DECISIONS (which pairs blend) are the forward's either way: both passes visit the same pairs.
+constexpr int RA_DECIDE = 1, RA_LFORM = 2, RA_ASSOC = 4;
+__device__ __forceinline__ float ref_power(float dx, float dy, float a, float b, float c)
+{
+#pragma clang fp contract(off)
+    return -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy;          // forward.cu:419, backward.cu:644
+}
+// RA_ASSOC: rs[0..1] dL/dG dG/ddel{x,y} (x 0.5 W / 0.5 H in preprocess_bwd), rs[2..3] their magnitudes, rs[4..6] gd{x,x,y} d{x,y,y} dL/dG (x -0.5 there), rs[7] G dL/dalpha
+__device__ __forceinline__ void ref_pair_sums(float (&rs)[8], float G, float dL_dalpha, float dx, float dy, float o, float a, float b, float c)
+{
+#pragma clang fp contract(off)
+    const float dL_dG = o * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    const float dG_ddelx = -gdx * a - gdy * b;
+    const float dG_ddely = -gdy * c - gdx * b;
+    const float mx = dL_dG * dG_ddelx, my = dL_dG * dG_ddely;
+    rs[0] += mx; rs[1] += my; rs[2] += fabsf(mx); rs[3] += fabsf(my);
+    rs[4] += gdx * dx * dL_dG; rs[5] += gdx * dy * dL_dG; rs[6] += gdy * dy * dL_dG;
+    rs[7] += G * dL_dalpha;
+}
+// The six geometric sums of a near-singular conic on the fast path, in l-space: v[0..1] = sum q l, v[4..6] = sum q l l^T, v[7] = sum q over the lane's pixels, with
+// l = (scaled conic) d formed per pixel -- the quadrant-0 value shifted like E (d_q = d_0 - (8,0), (0,8), (8,8)).  What cancels catastrophically downstream of the
+// d-moments (K S K with K = conic) never enters: l is small where the Gaussian is.  ~30 instructions instead of 17, for these Gaussians only (a wave-uniform branch).
+// preprocess_bwd.hip undoes the exp2 scale of the conic (EXP2_UNSCALE, squared for the second moments) and takes the second moments as dL/dcov2D.
+template <int PPL, int NV>
+__device__ __forceinline__ void l_moments(float (&v)[NV], const float (&Q)[PPL], float dx0, float dy0, float ca, float cb, float cc)
+{
+    const float lx0 = ca * dx0 + cb * dy0, ly0 = cb * dx0 + cc * dy0;
+    float sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, s0 = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+        // pixel offsets of the lane's quadrants: PPL == 4: (0,0), (8,0), (0,8), (8,8); PPL == 2: (0,0), (8,0)
+        const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+        const float lx = fmaf(-ox, ca, fmaf(-oy, cb, lx0)), ly = fmaf(-ox, cb, fmaf(-oy, cc, ly0));
+        const float qx = Q[q] * lx, qy = Q[q] * ly;
+        sx += qx; sy += qy; s0 += Q[q];
+        sxx = fmaf(qx, lx, sxx); sxy = fmaf(qx, ly, sxy); syy = fmaf(qy, ly, syy);
+    }
+    v[0] = sx; v[1] = sy; v[4] = sxx; v[5] = sxy; v[6] = syy; v[7] = s0;
+}
+// is `tile` one of the flagged tiles?  (four words per tile: one per wave of the forward variant that walked it, unused ones zero)
+__device__ __forceinline__ bool tile_is_risky(const uint32_t* __restrict__ tile_risky, int tile)
+{
+    if (!tile_risky) return false;
+    const uint4 w = *reinterpret_cast<const uint4*>(tile_risky + (size_t)tile * 4);
+    return (w.x | w.y | w.z | w.w) != 0u;
+}
+
 // ---- colour variant -------------------------------------------------------------------------------------------------
 // Same traversal and the same (pixel, Gaussian) decisions as render_bwd_body below, restructured so that a pair costs
 // ~24 VALU instructions instead of ~41 (the kernel is VALU-issue bound):
@@ -113,7 +181,7 @@ __device__ __forceinline__ float fast_rcp(float x)
 __device__ unsigned long long g_lanes_bwd[4];
 #endif
 constexpr int BWD_CHUNK = 16;          // 16 records per round: 0.75 KB + 4 KB of per-pixel constants <= 5 KB per wave = 8 waves per SIMD, every tile of a 1080p frame resident at once
-template <int PPL, bool ABS = true>          // ABS = false (IBGS_FLAG_NO_ABS_GRAD): the |.| moments of dL/dmean2D are not accumulated
+template <int PPL, bool ABS = true, bool RISK = false>          // ABS = false (IBGS_FLAG_NO_ABS_GRAD): the |.| moments of dL/dmean2D are not accumulated; RISK: the tile's list holds near-singular conics (see above)
 __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const int tile, const int sub, float4 (&s_rec)[3][BWD_CHUNK],
                                                       float4 (*s_gpix)[WAVE] /* PPL rows: dL/dC (rgb), -T_final * (bg . dL/dC) */)
 {
@@ -210,13 +278,57 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                         lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
                     }
                 }
-                if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h)
-                    const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
-                    const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
+                if constexpr (!RISK) {
+                    if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h); the sums: l_moments below
+                        const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+                        const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
 #pragma unroll
-                    for (int q = 0; q < PPL; q++) {
-                        const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
-                        p2q[q] = ref_power_E(g0.x - (pxf0 + ox), g0.y - (pyf0 + oy), g1.x, g1.y, g1.z, nlo);
+                        for (int q = 0; q < PPL; q++) {
+                            const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+                            p2q[q] = ref_power_E(g0.x - (pxf0 + ox), g0.y - (pyf0 + oy), g1.x, g1.y, g1.z, nlo);
+                        }
+                    }
+                }
+                if constexpr (RISK) {
+                    if ((riskm >> j) & 1ull) {          // wave-uniform: a near-singular conic in the reference's arithmetic (IBGS_FLAG_REF_ARITH).  E (the decision) from the reference's
+                                                        // expression, `power > 0` pairs dropped (common.h); G, alpha, T and the sums as described above
+                        const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+                        const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];          // the record as preprocess wrote it (unscaled conic, opacity)
+                        float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rR = 0.f, rG = 0.f, rB = 0.f;
+                        bool rany = false;
+#pragma unroll
+                        for (int q = 0; q < PPL; q++) {
+                            const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+                            const float dx = g0.x - (pxf0 + ox), dy = g0.y - (pyf0 + oy);
+                            const float power = ref_power(dx, dy, g1.x, g1.y, g1.z);
+                            const float E = ref_power_E(dx, dy, g1.x, g1.y, g1.z, nlo);          // what both passes decide on (+inf: `power > 0`)
+                            const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(E <= ALPHA_SKIP_E);
+                            if (okm == 0ull) continue;
+                            rany = true;
+                            const float Gr = __builtin_amdgcn_inverse_ballot_w64(okm) ? expf(power) : 0.f;          // backward.cu:648; 0 where the test fails: alpha = 0 leaves T and S unchanged
+                            const float oG = g0.z * Gr;
+                            const float alpha = fminf(0.99f, oG);
+                            const float om = 1.f - alpha;
+                            T[q] = T[q] / om;          // backward.cu:654
+                            const float w = alpha * T[q];
+                            const float4 gp = s_gpix[q][lane];
+                            const float cg = q2.x * gp.x + q2.y * gp.y + q2.z * gp.z;
+                            float dL_dalpha = cg - S[q];
+                            S[q] = fmaf(alpha, dL_dalpha, S[q]);
+                            rR = fmaf(w, gp.x, rR); rG = fmaf(w, gp.y, rG); rB = fmaf(w, gp.z, rB);
+                            dL_dalpha = dL_dalpha * T[q];
+                            if constexpr (!BG0) dL_dalpha += gp.w / om;          // ... - T_final (bg . g) / (1 - alpha)
+                            ref_pair_sums(rs, Gr, dL_dalpha, dx, dy, g0.z, g1.x, g1.y, g1.z);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(rany) != 0ull) {
+                            float v[12] = {rs[0], rs[1], rs[2], rs[3], rs[4], rs[5], rs[6], rs[7], rR, rG, rB, 0.f};
+                            const float tot = wave_transpose_reduce12(v, lane);
+                            if (col >= 0) {
+                                if (p.slab) p.slab[((size_t)(r0 + k) * (p.slab_ipt ? p.slab_ipt : IPT) + (size_t)sub) * GACC_FLOATS + col] = tot;
+                                else atomicAdd(p.gacc + (size_t)gid * GACC_FLOATS + col, tot);
+                            }
+                        }
+                        continue;
                     }
                 }
                 float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f;
@@ -259,6 +371,8 @@ __device__ __forceinline__ void render_bwd_color_body(const BwdParams& p, const 
                     IBGS_LANES_ADD(1, 1);
                     // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb (= grad_acc columns)
                     float v[12];
+                    if (!RISK && ((riskm >> j) & 1ull)) l_moments<PPL>(v, Q, dx0, dy0, ca, cb, cc);          // wave-uniform: a near-singular conic (see above)
+                    else
                     if constexpr (PPL == 4) {
                         const float A = Q[1] + Q[3], B = Q[2] + Q[3], S0 = (Q[0] + Q[2]) + A;
                         const float t = dx0 * S0, u = dy0 * S0;
@@ -450,7 +564,7 @@ __global__ void __launch_bounds__(256, 6) geo_window_kernel(BwdParams p)
 // render_bwd_color_body plus (i) the three normal channels, blended like colour channels (they share S), (ii) the window pairs:
 // a pixel's next buffered contributor number sits in a register; when the traversal reaches it (one integer compare per quadrant
 // and Gaussian) the lane loads that entry of the window table, adds E to dL/dalpha and w K to the plane sums, and moves on.
-template <int PPL, bool ABS = true>          // ABS = false: IBGS_FLAG_NO_ABS_GRAD, as in the colour body
+template <int PPL, bool ABS = true, bool RISK = false>          // ABS = false: IBGS_FLAG_NO_ABS_GRAD; RISK: a flagged tile -- both as in the colour body
 __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p, const int tile, const int sub, float4 (&s_rec)[4][BWD_CHUNK],
                                                     float4 (*s_gpix)[WAVE] /* PPL rows: dL/dC (rgb), -T_final * (bg . dL/dC) */, float4 (*s_gnrm)[WAVE] /* PPL rows: dL/dN (xyz) */)
 {
@@ -492,7 +606,7 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p, const in
         gn.w = 0.f;
         s_gpix[q][lane] = g; s_gnrm[q][lane] = gn;
         slot[q] = 0;
-        next_c[q] = inside ? __float_as_uint(p.tab[pix]) : 0u;          // table entry 0, field 0 (0 = no window pair at all)
+        next_c[q] = (inside && p.tab) ? __float_as_uint(p.tab[pix]) : 0u;          // table entry 0, field 0 (0 = no window pair at all; no table: no depth / warp gradient came in)
     }
     nmax = wave_max_u32(nmax);
     const uint32_t r0 = p.ranges[2 * tile], r1 = p.ranges[2 * tile + 1];
@@ -545,13 +659,68 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p, const in
                         lxq[3] = fmaf(-8.0f, cb, lxq[1]); lyq[3] = fmaf(-8.0f, cc, lyq[1]);
                     }
                 }
-                if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h)
-                    const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
-                    const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
+                if constexpr (!RISK) {
+                    if ((riskm >> j) & 1ull) {          // wave-uniform and rare: E from the reference's expression, `power > 0` pairs dropped (common.h); the sums: l_moments below
+                        const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+                        const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
 #pragma unroll
-                    for (int q = 0; q < PPL; q++) {
-                        const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
-                        p2q[q] = ref_power_E(g0.x - (pxf0 + ox), g0.y - (pyf0 + oy), g1.x, g1.y, g1.z, nlo);
+                        for (int q = 0; q < PPL; q++) {
+                            const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+                            p2q[q] = ref_power_E(g0.x - (pxf0 + ox), g0.y - (pyf0 + oy), g1.x, g1.y, g1.z, nlo);
+                        }
+                    }
+                }
+                if constexpr (RISK) {
+                    if ((riskm >> j) & 1ull) {          // wave-uniform: a near-singular conic in the reference's arithmetic, as in the colour body (+ the normal channels and the window pairs)
+                        const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+                        const float4 g0 = p.rec[(size_t)gid * 4], g1 = p.rec[(size_t)gid * 4 + 1];
+                        float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rR = 0.f, rG = 0.f, rB = 0.f, rNx = 0.f, rNy = 0.f, rNz = 0.f, rD = 0.f;
+                        bool rany = false;
+#pragma unroll
+                        for (int q = 0; q < PPL; q++) {
+                            const float ox = (PPL == 4) ? (float)((q & 1) * 8) : (float)(q * 8), oy = (PPL == 4) ? (float)((q >> 1) * 8) : 0.f;
+                            const float dx = g0.x - (pxf0 + ox), dy = g0.y - (pyf0 + oy);
+                            const float power = ref_power(dx, dy, g1.x, g1.y, g1.z);
+                            const float E = ref_power_E(dx, dy, g1.x, g1.y, g1.z, nlo);
+                            const uint64_t okm = __builtin_amdgcn_ballot_w64(k < ncontrib[q]) & __builtin_amdgcn_ballot_w64(E <= ALPHA_SKIP_E);
+                            if (okm == 0ull) continue;
+                            rany = true;
+                            const float Gr = __builtin_amdgcn_inverse_ballot_w64(okm) ? expf(power) : 0.f;
+                            const float oG = g0.z * Gr;
+                            const float alpha = fminf(0.99f, oG);
+                            const float om = 1.f - alpha;
+                            T[q] = T[q] / om;
+                            const float w = alpha * T[q];
+                            const float4 gp = s_gpix[q][lane], gn = s_gnrm[q][lane];
+                            const float cg = q2.x * gp.x + q2.y * gp.y + q2.z * gp.z + q3.x * gn.x + q3.y * gn.y + q3.z * gn.z;
+                            float dL_dalpha = cg - S[q];
+                            S[q] = fmaf(alpha, dL_dalpha, S[q]);
+                            rR = fmaf(w, gp.x, rR); rG = fmaf(w, gp.y, rG); rB = fmaf(w, gp.z, rB);
+                            rNx = fmaf(w, gn.x, rNx); rNy = fmaf(w, gn.y, rNy); rNz = fmaf(w, gn.z, rNz);
+                            const uint64_t hit = okm & __builtin_amdgcn_ballot_w64(k + 1u == next_c[q]);          // window pair (as on the fast path below)
+                            if (hit != 0ull) {
+                                if (__builtin_amdgcn_inverse_ballot_w64(hit)) {
+                                    const float* e = p.tab + (size_t)(slot[q] * GEO_TAB_FIELDS) * HW + pixo[q];
+                                    dL_dalpha += e[HW];
+                                    rNx = fmaf(w, e[2 * HW], rNx); rNy = fmaf(w, e[3 * HW], rNy); rNz = fmaf(w, e[4 * HW], rNz);
+                                    rD = fmaf(w, e[5 * HW], rD);
+                                    slot[q]++;
+                                    next_c[q] = (slot[q] < (uint32_t)p.tab_slots) ? __float_as_uint(e[(size_t)GEO_TAB_FIELDS * HW]) : 0u;
+                                }
+                            }
+                            dL_dalpha = dL_dalpha * T[q];
+                            if constexpr (!BG0) dL_dalpha += gp.w / om;
+                            ref_pair_sums(rs, Gr, dL_dalpha, dx, dy, g0.z, g1.x, g1.y, g1.z);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(rany) != 0ull) {
+                            float v[16] = {rs[0], rs[1], rs[2], rs[3], rs[4], rs[5], rs[6], rs[7], rR, rG, rB, rNx, rNy, rNz, rD, 0.f};
+                            const float tot = wave_transpose_reduce16(v, lane);
+                            if (col >= 0) {
+                                if (p.slab) p.slab[((size_t)(r0 + k) * (p.slab_ipt ? p.slab_ipt : IPT) + (size_t)sub) * GACC_FLOATS + col] = tot;
+                                else atomicAdd(p.gacc + (size_t)gid * GACC_FLOATS + col, tot);
+                            }
+                        }
+                        continue;
                     }
                 }
                 float Q[PPL], aX = 0.f, aY = 0.f, vR = 0.f, vG = 0.f, vB = 0.f, vNx = 0.f, vNy = 0.f, vNz = 0.f, vD = 0.f;
@@ -597,6 +766,8 @@ __device__ __forceinline__ void render_bwd_geo_body(const BwdParams& p, const in
                 if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                     // v[]: 0 Sx, 1 Sy, 2 Ax, 3 Ay, 4 Sxx, 5 Sxy, 6 Syy, 7 S0, 8-10 rgb, 11-13 normal, 14 dist (= grad_acc columns)
                     float v[16];
+                    if (!RISK && ((riskm >> j) & 1ull)) l_moments<PPL>(v, Q, dx0, dy0, ca, cb, cc);          // wave-uniform: a near-singular conic (see above)
+                    else
                     if constexpr (PPL == 4) {
                         const float A = Q[1] + Q[3], B = Q[2] + Q[3], S0 = (Q[0] + Q[2]) + A;
                         const float t = dx0 * S0, u = dy0 * S0;
@@ -648,7 +819,7 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_kernel(BwdParams p)
     else have = tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub);
     __shared__ float4 s_rec[3][BWD_CHUNK];
     __shared__ float4 s_gpix[4][WAVE];
-    if (have) render_bwd_color_body<4>(p, tile, sub, s_rec, s_gpix);
+    if (have && !tile_is_risky(p.tile_risky, tile)) render_bwd_color_body<4>(p, tile, sub, s_rec, s_gpix);
     IBGS_TRACE_END(g_trace_bwd);
 }
 __global__ void __launch_bounds__(64, 8) render_bwd_color_noabs_kernel(BwdParams p)          // IBGS_FLAG_NO_ABS_GRAD
@@ -659,7 +830,19 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_noabs_kernel(BwdParams
     else have = tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub);
     __shared__ float4 s_rec[3][BWD_CHUNK];
     __shared__ float4 s_gpix[4][WAVE];
-    if (have) render_bwd_color_body<4, false>(p, tile, sub, s_rec, s_gpix);
+    if (have && !tile_is_risky(p.tile_risky, tile)) render_bwd_color_body<4, false>(p, tile, sub, s_rec, s_gpix);
+}
+// The flagged tiles (their list holds a near-singular conic), one wave per tile whatever the frame's size, in the order of the kernel it is launched beside
+// (p.order) or in tile order; every other workgroup leaves at once.  128 VGPRs: the reference-arithmetic block spills nothing.
+template <bool ABS>
+__global__ void __launch_bounds__(64, 4) render_bwd_color_risk_kernel(BwdParams p)
+{
+    __shared__ float4 s_rec[3][BWD_CHUNK];
+    __shared__ float4 s_gpix[4][WAVE];
+    int tile = (int)blockIdx.x;
+    if (p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)(t & ~ORDER_SPLIT_BIT); }
+    if (tile >= p.ntiles || !tile_is_risky(p.tile_risky, tile)) return;
+    render_bwd_color_body<4, ABS, true>(p, tile, 0, s_rec, s_gpix);
 }
 
 // ---- balanced launch order for the colour kernel ----------------------------------------------------------------------------------
@@ -752,7 +935,7 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_small_kernel(BwdParams
     int tile, sub;
     __shared__ float4 s_rec[3][BWD_CHUNK];
     __shared__ float4 s_gpix[1][WAVE];
-    if (tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4, tile, sub)) render_bwd_color_body<1>(p, tile, sub, s_rec, s_gpix);
+    if (tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4, tile, sub) && !tile_is_risky(p.tile_risky, tile)) render_bwd_color_body<1>(p, tile, sub, s_rec, s_gpix);
 }
 // Hybrid (frames of fewer tiles than wave slots; render_fwd.hip has the forward's twin and the reasoning): four workgroups per tile; where the forward
 // walked the tile's list further than `hybrid` per cent of a SIMD's fair share of all walks, each takes a quadrant, elsewhere the first takes the tile.
@@ -763,7 +946,7 @@ __global__ void __launch_bounds__(64, 8) render_bwd_color_hybrid_kernel(BwdParam
     __shared__ float4 s_rec[3][BWD_CHUNK];
     __shared__ float4 s_gpix[4][WAVE];
     int tile, sub; bool split;
-    if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split)) return;
+    if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split) || tile_is_risky(p.tile_risky, tile)) return;
     if (split) render_bwd_color_body<1, ABS>(p, tile, sub, s_rec, s_gpix);
     else if (sub == 0) render_bwd_color_body<4, ABS>(p, tile, 0, s_rec, s_gpix);
 }
@@ -776,7 +959,19 @@ __device__ __forceinline__ void render_bwd_geo_entry(const BwdParams& p)
     int tile, sub;
     if (PPL == 4 && p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)(t & ~ORDER_SPLIT_BIT); sub = 0; }
     else if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 4 / PPL, tile, sub)) return;
+    if (tile_is_risky(p.tile_risky, tile)) return;
     render_bwd_geo_body<PPL, ABS>(p, tile, sub, s_rec, s_gpix, s_gnrm);
+}
+template <bool ABS>          // the geo pass's flagged tiles: as render_bwd_color_risk_kernel
+__global__ void __launch_bounds__(64, 3) render_bwd_geo_risk_kernel(BwdParams p)
+{
+    __shared__ float4 s_rec[4][BWD_CHUNK];
+    __shared__ float4 s_gpix[4][WAVE];
+    __shared__ float4 s_gnrm[4][WAVE];
+    int tile = (int)blockIdx.x;
+    if (p.order) { const uint32_t t = p.order[blockIdx.x]; if (t == 0xFFFFFFFFu) return; tile = (int)(t & ~ORDER_SPLIT_BIT); }
+    if (tile >= p.ntiles || !tile_is_risky(p.tile_risky, tile)) return;
+    render_bwd_geo_body<4, ABS, true>(p, tile, 0, s_rec, s_gpix, s_gnrm);
 }
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_kernel(BwdParams p) { render_bwd_geo_entry<4, true>(p); }
 __global__ void __launch_bounds__(64, 4) render_bwd_geo4_noabs_kernel(BwdParams p) { render_bwd_geo_entry<4, false>(p); }          // IBGS_FLAG_NO_ABS_GRAD
@@ -789,9 +984,17 @@ __global__ void __launch_bounds__(64, 4) render_bwd_geo_hybrid_kernel(BwdParams 
     __shared__ float4 s_gpix[4][WAVE];
     __shared__ float4 s_gnrm[4][WAVE];
     int tile, sub; bool split;
-    if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split)) return;
+    if (!hybrid_item(blockIdx.x, p.hybrid_grid1, p.order, tile, sub, split) || tile_is_risky(p.tile_risky, tile)) return;
     if (split) render_bwd_geo_body<1, ABS>(p, tile, sub, s_rec, s_gpix, s_gnrm);
     else if (sub == 0) render_bwd_geo_body<4, ABS>(p, tile, 0, s_rec, s_gpix, s_gnrm);
+}
+
+// BwdParams::power_skip for a call's flags: 0 = no reference branch at all; else how a near-singular conic's pairs are summed (RA_LFORM: default, RA_ASSOC: the
+// reference's association -- bit RA_ASSOC also tells preprocess_bwd which row format to expect of those Gaussians)
+int render_backward_ref_arith(uint32_t flags)
+{
+    if (flags & IBGS_FLAG_NO_REF_POWER_SKIP) return 0;
+    return RA_DECIDE | ((flags & IBGS_FLAG_REF_ARITH) ? RA_ASSOC : RA_LFORM);
 }
 
 // how many waves share one tile in the variant launch_render_backward picks (1, 2 or 4): rows per list entry of the deterministic slab
@@ -810,7 +1013,8 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     p.ntiles = p.cam.gx * p.cam.gy;
     p.n_src = a.n_src; p.tex_quant = (a.flags & IBGS_FLAG_TEX_QUANT) ? 1 : 0;
-    p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
+    p.power_skip = render_backward_ref_arith(a.flags);
+    p.tile_risky = (p.power_skip & RA_ASSOC) ? im.tile_risky : nullptr;          // IBGS_FLAG_REF_ARITH: the flagged tiles go to the *_risk_kernel, the fast kernels skip them
     p.ref_to_src = a.ref_to_src; p.src_rgba = src_rgba;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w;
@@ -825,82 +1029,90 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     static const TileMap map_geo = tile_map_from_env("IBGS_TILE_MAP_BWD_GEO", TileMap{TMAP_BLOCK, 1, 8, 4});
     p.tmap = a.render_geo ? map_geo : map_color;
     auto grid = [&](int ipt) { return dim3((unsigned)tile_map_grid(p.tmap, p.cam.gx, p.cam.gy, ipt)); };
+    // the flagged tiles' kernel, launched behind whichever blend kernel ran: over the slots of its launch order, or over the tiles (no flag set: every wave leaves at once)
+    auto launch_risk = [&](int nslots_or_0) {
+        if (!p.tile_risky) return;          // (IBGS_FLAG_REF_ARITH only)
+        BwdParams r = p;
+        r.slab_ipt = render_backward_waves_per_tile(a);          // rows per list entry of the deterministic slab = the waves per tile of the kernel beside it; this one is wave 0
+        r.hybrid_grid1 = 0;
+        if (nslots_or_0 == 0) r.order = nullptr;
+        const dim3 g((unsigned)(nslots_or_0 ? nslots_or_0 : nt));
+        StageTimer t(s, IBGS_STAGE_RENDER_BWD);
+        const bool noabs = (a.flags & IBGS_FLAG_NO_ABS_GRAD) != 0;
+        if (a.render_geo) { if (noabs) hipLaunchKernelGGL(render_bwd_geo_risk_kernel<false>, g, dim3(64), 0, s, r); else hipLaunchKernelGGL(render_bwd_geo_risk_kernel<true>, g, dim3(64), 0, s, r); }
+        else { if (noabs) hipLaunchKernelGGL(render_bwd_color_risk_kernel<false>, g, dim3(64), 0, s, r); else hipLaunchKernelGGL(render_bwd_color_risk_kernel<true>, g, dim3(64), 0, s, r); }
+    };
+    const bool noabs = (a.flags & IBGS_FLAG_NO_ABS_GRAD) != 0;
+    const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
+    // launch order of the kernel that follows (tile_order_kernel): slot_rounds = the waves per SIMD that kernel holds; theta > 0 marks the tiles four quadrant waves should walk
+    auto launch_order = [&](int slot_rounds, int theta) {
+        StageTimer t(s, IBGS_STAGE_TILE_ORDER);
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, slot_rounds, im.tile_walked, im.meta, im.tile_order, a.tile_order_out, theta);
+        p.order = im.tile_order;
+    };
+    int risk_slots = 0;          // the flagged tiles' kernel runs over the slots of the launch order when there is one, else over the tiles
     if (a.render_geo) {
         // geo: one wave per tile on large frames (measured at C3-geo: 1.61 ms against 1.83 ms with one wave per half tile), one per
         // 8x8 quadrant on small ones
         const bool big = (a.flags & IBGS_FLAG_QUADRANT_WAVES) ? false : ((a.flags & IBGS_FLAG_TILE_WAVES) ? true : nt >= 4096);
-        if (!geo_tab) { set_error("geo backward needs the window table scratch"); return -IBGS_ERR_INVALID; }
-        { StageTimer t(s, IBGS_STAGE_GEO_WINDOW);
-          hipLaunchKernelGGL(geo_window_kernel, dim3((unsigned)(((size_t)a.W * a.H + 255) / 256)), dim3(256), 0, s, p); }
+        // The window pass (B2) only carries dL/dmedian_depth and dL/dwarped_image: when neither came in (a loss on `render` / `rendered_normal` alone, e.g. the
+        // 2 x len(cameras) iterations in which train.py renders geo without its geo losses, train.py:289-316) every table entry would be zero -- no table is
+        // built (0.19 of a 1.90 ms iteration at C3) and the blend loop looks nothing up: bit-identical to zero-filled gradients (tests/test_gpu_geo_no_window.py)
+        const bool window = a.dL_ddepth || a.dL_dwarped;
+        if (window && !geo_tab) { set_error("geo backward needs the window table scratch"); return -IBGS_ERR_INVALID; }
+        if (window) {
+            StageTimer t(s, IBGS_STAGE_GEO_WINDOW);
+            hipLaunchKernelGGL(geo_window_kernel, dim3((unsigned)(((size_t)a.W * a.H + 255) / 256)), dim3(256), 0, s, p);
+        } else p.tab = nullptr;
         IBGS_HIP(hipGetLastError());
         // the geo kernel holds four waves per SIMD: 4 096 slots for a 1080p frame's 8 160 tiles, so the second half of the launch starts as slots
         // free up -- a queue, which wants the heaviest tiles first (plain descending order; slot_rounds = 4 makes the order kernel choose it).  That
         // gives up the 8 x 4 block map's L2 locality and still wins everywhere: C3-geo 1.497 -> 1.452 ms, trained 0.600 -> 0.570, half of the
-        // Gaussians in one blob 1.764 -> 1.464 ms (-17 %).  IBGS_BWD_GEO_BALANCED=0: the tile map's order
-        static const int geo_balanced = getenv("IBGS_BWD_GEO_BALANCED") ? atoi(getenv("IBGS_BWD_GEO_BALANCED")) : 1;
-        if (big && geo_balanced) {
-            const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
-              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
-            p.order = im.tile_order;
+        // Gaussians in one blob 1.764 -> 1.464 ms (-17 %)
+        if (big) {
+            launch_order(4, 0);
+            risk_slots = nslots;
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo4_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+            if (noabs) hipLaunchKernelGGL(render_bwd_geo4_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
             else hipLaunchKernelGGL(render_bwd_geo4_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
-        } else if (!big && !(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
+        } else if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
             // small frames: per tile one wave or four (render_bwd_geo_hybrid_kernel), the tiles' first waves heaviest first (slot_rounds = 4: plain descending order)
-            const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
-              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, 4, im.tile_walked, im.meta, im.tile_order, a.tile_order_out, hybrid_theta()); }
+            launch_order(4, hybrid_theta());
             IBGS_HIP(hipGetLastError());
-            p.order = im.tile_order; p.slab_ipt = 4; p.hybrid_grid1 = nslots;
+            p.slab_ipt = 4; p.hybrid_grid1 = nslots;
+            risk_slots = nslots;
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_geo_hybrid_kernel<false>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
+            if (noabs) hipLaunchKernelGGL(render_bwd_geo_hybrid_kernel<false>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
             else hipLaunchKernelGGL(render_bwd_geo_hybrid_kernel<true>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
         } else {
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            if (big) hipLaunchKernelGGL(render_bwd_geo4_kernel, grid(1), dim3(64), 0, s, p);
-            else hipLaunchKernelGGL(render_bwd_geo_kernel, grid(4), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(render_bwd_geo_kernel, grid(4), dim3(64), 0, s, p);
         }
-    } else {
-        if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles())) {
-            if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
-                // per tile one wave or four (render_bwd_color_hybrid_kernel), the tiles' first waves in the balanced order of the tile-wave kernel below
-                const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-                { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
-                  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, ORDER_SNAKE_ROUNDS, im.tile_walked, im.meta, im.tile_order, a.tile_order_out, hybrid_theta()); }
-                IBGS_HIP(hipGetLastError());
-                p.order = im.tile_order;
-                p.slab_ipt = 4; p.hybrid_grid1 = nslots;
-                StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-                if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_color_hybrid_kernel<false>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
-                else hipLaunchKernelGGL(render_bwd_color_hybrid_kernel<true>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
-                IBGS_HIP(hipGetLastError());
-                return 0;
-            }
+    } else if ((a.flags & IBGS_FLAG_QUADRANT_WAVES) ? true : ((a.flags & IBGS_FLAG_TILE_WAVES) ? false : nt < hybrid_max_tiles())) {
+        if (!(a.flags & IBGS_FLAG_QUADRANT_WAVES) && nt >= HYBRID_MIN_TILES) {
+            // per tile one wave or four (render_bwd_color_hybrid_kernel), the tiles' first waves in the balanced order of the tile-wave kernel below
+            launch_order(ORDER_SNAKE_ROUNDS, hybrid_theta());
+            IBGS_HIP(hipGetLastError());
+            p.slab_ipt = 4; p.hybrid_grid1 = nslots;
+            risk_slots = nslots;
+            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
+            if (noabs) hipLaunchKernelGGL(render_bwd_color_hybrid_kernel<false>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
+            else hipLaunchKernelGGL(render_bwd_color_hybrid_kernel<true>, dim3(4u * (unsigned)nslots), dim3(64), 0, s, p);
+        } else {
             StageTimer t(s, IBGS_STAGE_RENDER_BWD);
             hipLaunchKernelGGL(render_bwd_color_small_kernel, grid(4), dim3(64), 0, s, p);
-            IBGS_HIP(hipGetLastError());
-            return 0;
         }
-        static const int balanced = getenv("IBGS_BWD_BALANCED") ? atoi(getenv("IBGS_BWD_BALANCED")) : 1;
-        if (balanced) {
-            const int nslots = (nt + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES;
-            { StageTimer t(s, IBGS_STAGE_TILE_ORDER);
-              static const int slot_rounds = getenv("IBGS_BWD_SLOT_ROUNDS") ? atoi(getenv("IBGS_BWD_SLOT_ROUNDS")) : ORDER_SNAKE_ROUNDS;      // experiments (with IBGS_BWD_PAD_LDS)
-              hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, nt, nslots, slot_rounds, im.tile_walked, im.meta, im.tile_order, a.tile_order_out); }
-            IBGS_HIP(hipGetLastError());
-            p.order = im.tile_order;
-            StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-            static const int pad_bal = getenv("IBGS_BWD_PAD_LDS") ? atoi(getenv("IBGS_BWD_PAD_LDS")) : 0;      // experiments: dynamic LDS that nobody uses = fewer waves per SIMD
-            if (a.flags & IBGS_FLAG_NO_ABS_GRAD) hipLaunchKernelGGL(render_bwd_color_noabs_kernel, dim3((unsigned)nslots), dim3(64), pad_bal, s, p);
-            else hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), pad_bal, s, p);
-            IBGS_HIP(hipGetLastError());
-            return 0;
-        }
-        static const int pad_lds = getenv("IBGS_BWD_PAD_LDS") ? atoi(getenv("IBGS_BWD_PAD_LDS")) : 0;      // experiments: dynamic LDS that nobody uses = fewer waves per SIMD
+    } else {
+        // one wave per tile in the balanced (snake) order; docs/EXPERIMENTS.md keeps the numbers of the tile map's order and of fewer waves per SIMD (round 3)
+        launch_order(ORDER_SNAKE_ROUNDS, 0);
+        IBGS_HIP(hipGetLastError());
+        risk_slots = nslots;
         StageTimer t(s, IBGS_STAGE_RENDER_BWD);
-        hipLaunchKernelGGL(render_bwd_color_kernel, grid(1), dim3(64), pad_lds, s, p);
+        if (noabs) hipLaunchKernelGGL(render_bwd_color_noabs_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL(render_bwd_color_kernel, dim3((unsigned)nslots), dim3(64), 0, s, p);
     }
+    IBGS_HIP(hipGetLastError());
+    launch_risk(risk_slots);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

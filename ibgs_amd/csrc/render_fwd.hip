@@ -39,6 +39,7 @@ struct FwdParams {
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
+    uint32_t* risky;          // ImgState::tile_risky (4 words per tile): this wave staged a record whose conic is near-singular
     int hybrid_grid1;    // ... its first hybrid_grid1 workgroups are the tiles' first waves (hybrid_item, common.h)
     int hybrid;          // 1: render_fwd_color_hybrid_kernel
     const uint32_t* run_if;   // guard of the repair pass (api.hip): the kernel leaves at once when *run_if == 0; nullptr on every ordinary pass
@@ -212,6 +213,7 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
     float4 ahead = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (GEO) ahead = fetch_quad(0);
     int base = 0;          // (lives past the loop: where the wave left the list)
+    uint64_t riskany = 0ull;          // a staged record had a near-singular conic: the backward walks this tile with its reference-arithmetic kernel (render_bwd.hip)
     for (; base < n; base += CHUNK) {
         uint64_t riskm = 0ull;          // staged records whose conic is near-singular: the reference's power expression decides for them (common.h)
         if constexpr (GEO) {
@@ -239,6 +241,7 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
             }
             if (p.power_skip) riskm = __builtin_amdgcn_ballot_w64(risky);
         }
+        riskany |= riskm;
         __syncthreads();
         const int count = min(CHUNK, n - base);
         for (int j = 0; j < count; j++) {
@@ -409,6 +412,9 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
             if (lane == 0 && tile == 0 && sub == 0) p.meta[10] = 4u;
         }
         else if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; p.done[(size_t)tile * IPT + sub] = fin; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
+        // four flag words per tile whatever the variant (wave `sub` of IPT writes words sub, sub + IPT, ...): non-zero = this wave staged a near-singular conic, i.e. the
+        // backward may meet one here (it walks no further than the forward did)
+        if (!DEPTH && p.risky && lane < PPL) p.risky[(size_t)tile * 4 + sub + lane * IPT] = riskany != 0ull ? 1u : 0u;
     }
     // The geo epilogue proper runs quadrant after quadrant in a ROLLED loop on values recomputed from (q, lane): by now the blend loop's
     // per-quadrant registers (T, colour, normal sums, ...) are dead, and what stays live is one quadrant's worth of epilogue state --
@@ -835,7 +841,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
     p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
-    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta; p.walked = im.tile_walked; p.order = nullptr;
+    p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta; p.walked = im.tile_walked; p.risky = im.tile_risky; p.order = nullptr;
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;

@@ -15,13 +15,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
-    Returns (rank, world_size, local_rank).  A single process needs no initialisation."""
+    Returns (rank, world_size, local_rank).  A single process needs no initialisation; `force` initialises a group of one anyway (the exchange classes
+    below then issue their collectives at world size 1 when built with force=True: the RCCL path on a one-GPU box, tests/test_gpu_rccl_world1.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -89,6 +90,13 @@ def allreduce_gradients(params, bucket=None, group=None, average=False):
     return bucket
 
 
+def _exchanging(group, force):
+    """True when collectives are to be issued: a process group of more than one rank, or any initialised group under `force`."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(force)
+
+
 def _resolve(x):
     """tensor | list of tensors | zero-argument callable returning either -> list of tensors (or [])."""
     if callable(x) and not isinstance(x, torch.Tensor):
@@ -139,8 +147,11 @@ class ViewParallelReducer:
     SH gradients that did not come through the factored path (a backward outside capture(), colours converted in
     Python, another loss term on the SH leaves) are detected in step 1 and all-reduced densely on every rank."""
 
-    def __init__(self, params, sh=None, means3D=None, group=None, expand=None, factored=True, agree_every=1, direct=None):
+    def __init__(self, params, sh=None, means3D=None, group=None, expand=None, factored=True, agree_every=1, direct=None, force=False):
+        """force: issue every collective (agreement, all-gather, all-reduce) also in a process group of ONE rank -- the sums are then the local gradients,
+        bit for bit, and the whole exchange path has run on its backend (what a one-GPU box can show of RCCL)."""
         self._params, self._sh, self._means3D = params, sh, means3D
+        self.force = bool(force)
         self.group, self._expand, self.factored = group, expand, factored
         self.agree_every = max(1, int(agree_every))
         self._direct = direct
@@ -153,7 +164,7 @@ class ViewParallelReducer:
         self.n_agreements = 0
         self._last_sig = None
         self._agree = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _exchanging(group, force):
             # host-side agreement channel: the default group when it is gloo already, else a gloo twin of it
             if dist.get_backend(group) == "gloo":
                 self._agree = group if group is not None else dist.group.WORLD
@@ -247,6 +258,7 @@ class ViewParallelReducer:
     def reduce(self, average=False):
         import time
         world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        multi = _exchanging(self.group, self.force)          # collectives are issued (world > 1, or forced at world 1)
         params, sh_parts, means3D = _resolve(self._params), self.sh_parts, self.means3D
         items, self.items = self.items or [], None
         dense = [p for p in params if not any(p is q for q in sh_parts)]
@@ -275,7 +287,7 @@ class ViewParallelReducer:
         mine = [n_local, P, M, degree, sum(p.numel() for p in dense), sum(q.numel() for q in sh_parts)]
         sig = (tuple(mine), bool(sh_dense))
         self._calls += 1
-        agree = world > 1 and (self.agree_every == 1 or self._calls == 1 or (self._calls - 1) % self.agree_every == 0
+        agree = multi and (self.agree_every == 1 or self._calls == 1 or (self._calls - 1) % self.agree_every == 0
                                or sig != self._last_sig or err is not None)
         self._last_sig = sig
         work_a, v, t_agree = None, None, 0.0
@@ -285,7 +297,7 @@ class ViewParallelReducer:
             work_a = dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._agree, async_op=True)
             self.n_agreements += 1
             t_agree = time.perf_counter() - t0
-        elif world == 1 and err is not None:
+        elif not multi and err is not None:
             raise RuntimeError(err)
         # ---- buffers: factors of the local views; the flat bucket (gradients that already live in it are not copied)
         buf = None
@@ -313,7 +325,7 @@ class ViewParallelReducer:
             raise RuntimeError(err)
         # ---- 2. factors on the wire first
         work_g = None
-        if buf is not None and world > 1:
+        if buf is not None and multi:
             allb = torch.empty(world * n_local, P + 1, 3, dtype=buf.dtype, device=buf.device)
             work_g = dist.all_gather_into_tensor(allb, buf, group=self.group, async_op=True)
             buf = allb
@@ -321,7 +333,7 @@ class ViewParallelReducer:
         flat_list = dense + (sh_parts if sh_dense else [])
         work_d, bucket, views = None, None, None
         self.last_packed = 0
-        if world > 1 and flat_list:
+        if multi and flat_list:
             bucket = self._bucket_for(flat_list)
             views = bucket.unpack()
             for p, view in zip(flat_list, views):
@@ -331,7 +343,7 @@ class ViewParallelReducer:
                 elif not (g.data_ptr() == view.data_ptr() and g.numel() == view.numel() and g.is_contiguous()):
                     view.copy_(g.reshape(view.shape)); self.last_packed += 1          # a gradient that lives elsewhere: one copy in
             work_d = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.last_bytes = (0 if bucket is None else bucket.flat.numel() * 4) + (0 if (buf is None or world == 1) else n_local * (P + 1) * 12)
+        self.last_bytes = (0 if bucket is None else bucket.flat.numel() * 4) + (0 if (buf is None or not multi) else n_local * (P + 1) * 12)
         # ---- 4. SH expansion overlaps the all-reduce
         g_sh = None
         if items:
@@ -369,7 +381,7 @@ def _resolve_dict(d):
     return {k: (v() if (callable(v) and not isinstance(v, torch.Tensor)) else v) for k, v in (d or {}).items()}
 
 
-def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None):
+def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, group=None, force=False):
     """Per-view statistics consumed by GaussianModel.add_densification_stats
     (scene/gaussian_model.py:600-604; train.py:400-410), reduced over the views of this step:
     returns (sum of ||grad[:, :2]||, sum of ||grad_abs[:, :2]||, visible count, max radii)."""
@@ -378,7 +390,7 @@ def allreduce_densification_stats(viewspace_grad, viewspace_grad_abs, radii, gro
     gna = torch.norm(viewspace_grad_abs[:, :2], dim=-1, keepdim=True) * vis[:, None]
     cnt = vis.to(torch.float32)[:, None]
     rmax = radii.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _exchanging(group, force):
         packed = torch.cat([gn, gna, cnt], dim=1).contiguous()
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         gn, gna, cnt = packed[:, 0:1], packed[:, 1:2], packed[:, 2:3]
@@ -426,10 +438,10 @@ class synchronized_densification_rng:
         return self._fork.__exit__(*exc)
 
 
-def assert_replicas_identical(tensors, group=None, what="parameters"):
+def assert_replicas_identical(tensors, group=None, what="parameters", force=False):
     """Cheap guard for the replicated-parameter invariant: one all-reduce (MIN and MAX) of a float64 checksum and the element count per
     tensor.  Raises on EVERY rank when any replica differs (e.g. a densification that ran with unsynchronised generators)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanging(group, force):
         return
     vals = []
     for t in _resolve(tensors):
@@ -508,7 +520,7 @@ class ShardedOptimizerStep:
     Every parameter of `optimizer` must be a per-Gaussian tensor (first dimension P); `sh` names the SH leaves whose gradient arrives
     factored (rasterizer.capture_sh_factors), `means3D` the positions.  `expand` / `adam` replace the HIP kernels in the CPU tests."""
 
-    def __init__(self, optimizer, sh=None, means3D=None, group=None, expand=None, adam=None, ordered=True):
+    def __init__(self, optimizer, sh=None, means3D=None, group=None, expand=None, adam=None, ordered=True, force=False):
         """ordered (default): the dense gradients travel by ALL-TO-ALL -- every rank sends each owner its block of rows, point to point -- and the
         owner adds the N blocks IN RANK ORDER: ((g0 + g1) + g2) + ..., the order of a single process accumulating the views one after the other,
         whatever the backend and however many ranks (round 5; bit-identical to that sequential sum at any world size, tests/test_dist_gloo.py at
@@ -516,6 +528,7 @@ class ShardedOptimizerStep:
         point-to-point transfers per rank instead of a ring).  ordered=False: the backend's reduce_scatter_tensor and its summation order."""
         self.opt, self._sh, self._means3D, self.group = optimizer, sh, means3D, group
         self.ordered = bool(ordered)
+        self.force = bool(force)          # issue the collectives in a group of one rank as well (ViewParallelReducer: force)
         self._expand, self._adam = expand, (adam or _fused_adam_rows)
         self.items = None
         self.last_bytes = 0
@@ -531,7 +544,7 @@ class ShardedOptimizerStep:
                 if not me.state_is_gathered:
                     raise RuntimeError("ShardedOptimizerStep: the Adam moments are sharded over the ranks; call gather_state() on EVERY rank before optimizer.state_dict()")
             optimizer.register_state_dict_pre_hook(_guard)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _exchanging(group, force):
             if dist.get_backend(group) == "gloo":
                 self._agree = group if group is not None else dist.group.WORLD
             else:
@@ -567,6 +580,7 @@ class ShardedOptimizerStep:
     def step(self, average=False):
         """average: divide the summed gradients by the number of ranks (ViewParallelReducer.reduce(average=True))"""
         world, rank = self._world()
+        multi = _exchanging(self.group, self.force)
         items, self.items = self.items or [], None
         sh_parts = _resolve(self._sh)
         m3 = _resolve(self._means3D)
@@ -586,7 +600,7 @@ class ShardedOptimizerStep:
         if err is None and items and sum(int(q.shape[1]) for q in sh_parts) != M:
             err = "ShardedOptimizerStep: the `sh` leaves hold %d coefficients, the captured views M = %d" % (sum(int(q.shape[1]) for q in sh_parts), M)
         has_grad = [int(p.grad is not None) for _, p in pairs]
-        if world > 1:          # ranks must agree on the collective sequence before the first one starts (as ViewParallelReducer does)
+        if multi:          # ranks must agree on the collective sequence before the first one starts (as ViewParallelReducer does)
             mine = [len(items), P, M, degree] + has_grad
             v = torch.tensor(mine + [-x for x in mine] + [int(err is not None)], dtype=torch.int64)
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._agree)
@@ -604,7 +618,7 @@ class ShardedOptimizerStep:
 
         def scatter_sum(g):          # (P, ...) local gradient -> (n, ...) all-rank sum of this rank's rows
             flat = g.reshape(P, -1)
-            if world == 1:
+            if not multi:
                 return flat
             k = flat.shape[1]
             if P == chunk * world and flat.is_contiguous():
@@ -627,7 +641,7 @@ class ShardedOptimizerStep:
         g_sh = None
         if items:
             n_local = len(items)
-            if world > 1:
+            if multi:
                 send = torch.zeros(world, n_local, chunk, 3, dtype=torch.float32, device=dev)
                 for i, it in enumerate(items):
                     pad = torch.zeros(chunk * world, 3, dtype=torch.float32, device=dev); pad[:P] = it["dcolor"]
@@ -672,7 +686,7 @@ class ShardedOptimizerStep:
                             "step": float(st["step"]), "full": p})
         self._adam(entries)
         # ---- 4. every rank gets every row back
-        if world > 1:
+        if multi:
             for e in entries:
                 self._gather_rows(e["full"].data, P, chunk, lo, hi, world)
             self.state_is_gathered = False
@@ -696,7 +710,7 @@ class ShardedOptimizerStep:
         """All-gather the Adam moments so that every rank holds them for every row (before densification surgery, checkpoints, or a change
         of the row ranges).  No-op when nothing has been stepped since the last call."""
         world, rank = self._world()
-        if world == 1 or self.state_is_gathered:
+        if not _exchanging(self.group, self.force) or self.state_is_gathered:
             self.state_is_gathered = True
             return
         for _, p in self._params():

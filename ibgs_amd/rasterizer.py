@@ -38,6 +38,10 @@ TILE_CULL = True
 # The reference's `if (power > 0.0f) continue;` (forward.cu:420, backward.cu:645): reproduced for the Gaussians whose conic is close enough
 # to singular for it to fire (csrc/common.h); False = IBGS_FLAG_NO_REF_POWER_SKIP, every Gaussian takes the fast path.
 REF_POWER_SKIP = True
+# The backward sums the pairs of those Gaussians in a well-conditioned form of the reference's chain (dL/dcov2D = 0.5 sum q l l^T: csrc/render_bwd.hip).  True =
+# IBGS_FLAG_REF_ARITH: the reference's own arithmetic for them instead -- its eight per-pair quantities in its association and the chain of backward.cu:405-420 on
+# their sums (SURVEY Q1 as a switch; farther from a float64 evaluation, like every fp32 evaluation of those expressions).
+REF_ARITH = False
 
 KEEP_DET_SCRATCH = False          # diagnostics: keep the last deterministic backward's scratch alive as _CModule.last_det
 # Deterministic backward (IBGS_FLAG_DETERMINISTIC): no float atomics, gradients bit-identical from run to run (CI mode, slower).
@@ -60,7 +64,7 @@ SPLIT_GEO_EPILOGUE = os.environ.get("IBGS_SPLIT_GEO_EPILOGUE", "0") == "1"
 
 def _shape_flag():
     return ({None: 0, "tile": _lib.FLAG_TILE_WAVES, "quadrant": _lib.FLAG_QUADRANT_WAVES}[WAVE_SHAPE]
-            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP) | (_lib.FLAG_SPLIT_GEO_EPILOGUE if SPLIT_GEO_EPILOGUE else 0))
+            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP) | (_lib.FLAG_REF_ARITH if REF_ARITH else 0) | (_lib.FLAG_SPLIT_GEO_EPILOGUE if SPLIT_GEO_EPILOGUE else 0))
 
 
 # View-parallel training (ibgs_amd/dist.py): while a `capture_sh_factors()` block is active the backward leaves

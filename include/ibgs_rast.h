@@ -89,6 +89,12 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                            csrc/common.h: conic_is_risky) and drop the pairs it drops; with this flag every Gaussian
                                            takes the fast path and such pairs are blended with alpha ~= opacity */
 
+#define IBGS_FLAG_REF_ARITH 4096u /* ibgs_backward only (SURVEY Q1 as a switch).  The pairs of a Gaussian whose conic is within 1e-3 of singular (csrc/common.h:
+                                     conic_takes_ref_power) are always evaluated with G = exp(power) at libm accuracy (backward.cu:648) and T / (1 - alpha) as an IEEE division
+                                     (:654).  By default their sums are formed in the well-conditioned form dL/dcov2D = 0.5 sum q l l^T, l = conic d -- algebraically the reference's
+                                     chain (backward.cu:405-420), without its cancellation: 3-10 x closer to a float64 evaluation than ANY fp32 evaluation of the reference's own
+                                     expressions (profiles/r06_ref_arith_ab.txt).  With this flag they are formed exactly as the reference forms them: the eight per-pair quantities of
+                                     backward.cu:779-804 in its association, uncontracted, and the chain of :405-420 on their sums.  Every other Gaussian: unchanged */
 #define IBGS_FLAG_SPLIT_GEO_EPILOGUE 2048u /* ibgs_forward, render_geo (experiment, round 5): run the per-pixel epilogue (median depth, source validity, warp;
                                               forward.cu:507-663) as its own pixel-parallel kernel behind the blend kernel instead of inside it.  Bit-identical outputs;
                                               SLOWER on MI355X (C3-geo forward 0.716 -> 0.844 ms, trained 0.367 -> 0.392: alone, the gathers have nothing to hide behind) */
@@ -247,13 +253,14 @@ typedef struct ibgs_backward_args {
     const float* dL_dcolor;   /* 3 x H x W */
     const float* dL_dnormal;  /* 3 x H x W */
     const float* dL_ddepth;   /* 1 x H x W */
-    const float* dL_dwarped;  /* 15 x H x W */
+    const float* dL_dwarped;  /* 15 x H x W   (both NULL: the median / warp window pass of the backward is not run and `tex` / `geo_table` are not touched -- same
+                                 gradients, bit for bit under IBGS_FLAG_DETERMINISTIC, as zero-filled arrays) */
     /* scratch: P x 16 floats, ZEROED by the caller (per-Gaussian accumulation rows) */
     float* grad_acc;
     /* gradient outputs: fully overwritten (dL_dscale / dL_drot only when scales is given, dL_dsh only when shs is) */
     float* dL_dmean2D;     /* P x 3 */
     float* dL_dmean2D_abs; /* P x 3 */
-    float* dL_dconic;      /* P x 4 (x,y,w used) */
+    float* dL_dconic;      /* P x 4 (x,y,w used); optional (may be NULL).  For a near-singular conic under the default summation (see IBGS_FLAG_REF_ARITH) it is derived back from dL/dcov2D */
     float* dL_dopacity;    /* P */
     float* dL_dcolors;     /* P x 3; may be NULL when shs is given without IBGS_FLAG_SH_FACTORED (it is the gradient of colors_precomp) */
     float* dL_dmean3D;     /* P x 3 */

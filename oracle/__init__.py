@@ -22,6 +22,7 @@ _SO = os.path.join(_HERE, "_build", "libibgs_oracle.so")
 _SO_FMA = os.path.join(_HERE, "_build", "libibgs_oracle_fma.so")
 _SO_F64 = os.path.join(_HERE, "_build", "libibgs_oracle_f64.so")
 _SO_ACC32 = os.path.join(_HERE, "_build", "libibgs_oracle_acc32.so")
+_SO_LFORM = os.path.join(_HERE, "_build", "libibgs_oracle_lform.so")
 _RT = np.float32          # element type of the float arrays at the C interface: float32, float64 inside `variant("f64")`
 _SRC = os.path.join(_HERE, "ibgs_oracle.c")
 _lib = None
@@ -40,7 +41,7 @@ def build(force=False):
     sums kept in float like the reference's atomicAdd (single-threaded, pixel order): a diagnostic for what float accumulation alone costs."""
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     for so, flags in ((_SO, ["-ffp-contract=off"]), (_SO_FMA, ["-ffp-contract=fast", "-mfma"]), (_SO_F64, ["-ffp-contract=off", "-DORC_F64"]),
-                      (_SO_ACC32, ["-ffp-contract=off", "-DORC_ACC_FLOAT"])):
+                      (_SO_ACC32, ["-ffp-contract=off", "-DORC_ACC_FLOAT"]), (_SO_LFORM, ["-ffp-contract=off", "-DORC_ACC_FLOAT", "-DORC_LFORM"])):
         if (not force) and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(_SRC):
             continue
         subprocess.check_call(["gcc", "-O2"] + flags + ["-fno-fast-math", "-fopenmp", "-shared", "-fPIC", "-o", so, _SRC, "-lm"])
@@ -69,8 +70,8 @@ class variant:
     build in which every float is a double (inputs are converted, results come back as float64 arrays) -- see build()."""
 
     def __init__(self, name):
-        assert name in ("fma", "plain", "f64", "acc32")
-        self.path = {"fma": _SO_FMA, "plain": _SO, "f64": _SO_F64, "acc32": _SO_ACC32}[name]
+        assert name in ("fma", "plain", "f64", "acc32", "lform")
+        self.path = {"fma": _SO_FMA, "plain": _SO, "f64": _SO_F64, "acc32": _SO_ACC32, "lform": _SO_LFORM}[name]
         self.rt = np.float64 if name == "f64" else np.float32
 
     def __enter__(self):

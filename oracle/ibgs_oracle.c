@@ -865,9 +865,20 @@ void orc_render_backward(
             ACC_ADD(acc_mean2D[2 * id + 1], my);
             ACC_ADD(acc_mean2D_abs[2 * id], fabsf(mx));
             ACC_ADD(acc_mean2D_abs[2 * id + 1], fabsf(my));
+#ifdef ORC_LFORM
+            /* diagnostic (oracle.variant("lform")): NOT the reference's arithmetic -- the conic sums in the well-conditioned form the HIP path uses for
+             * near-singular conics (csrc/render_bwd.hip): dL/dcov2D = 0.5 sum q l l^T with l = conic d, which the chain below then takes as it is */
+            {
+                const float lx = co[0] * dx + co[1] * dy, ly = co[1] * dx + co[2] * dy, q = G * dL_dG;
+                ACC_ADD(acc_conic[3 * id + 0], (0.5f * q * lx * lx));
+                ACC_ADD(acc_conic[3 * id + 1], (q * lx * ly));
+                ACC_ADD(acc_conic[3 * id + 2], (0.5f * q * ly * ly));
+            }
+#else
             ACC_ADD(acc_conic[3 * id + 0], (-0.5f * gdx * dx * dL_dG));
             ACC_ADD(acc_conic[3 * id + 1], (-0.5f * gdx * dy * dL_dG));
             ACC_ADD(acc_conic[3 * id + 2], (-0.5f * gdy * dy * dL_dG));
+#endif
             ACC_ADD(acc_opacity[id], (G * dL_dalpha));
         }
     }
@@ -908,9 +919,13 @@ void orc_preprocess_backward(
         const float d2inv = 1.0f / ((denom * denom) + 0.0000001f);
         float* gS = dL_dcov3D + 6 * i;
         if (d2inv != 0) {
+#ifdef ORC_LFORM
+            { const float kk = d2inv * (denom * denom); da = kk * gcx; db = kk * gcy; dc = kk * gcz; }
+#else
             da = d2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcz);
             dc = d2inv * (-a * a * gcz + 2 * a * b * gcy + (denom - a * c) * gcx);
             db = d2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcz);
+#endif
             gS[0] = (A[0][0] * A[0][0] * da + A[0][0] * A[1][0] * db + A[1][0] * A[1][0] * dc);
             gS[3] = (A[0][1] * A[0][1] * da + A[0][1] * A[1][1] * db + A[1][1] * A[1][1] * dc);
             gS[5] = (A[0][2] * A[0][2] * da + A[0][2] * A[1][2] * db + A[1][2] * A[1][2] * dc);

@@ -1,0 +1,115 @@
+"""The random cases of tools/fuzz_parity.py and tools/fuzz_fused.py as importable generators: the sweeps draw from them and tests/test_gpu_fuzz_pins.py
+replays single cases of a sweep by (seed, index) -- the cases the round-5 sweeps left outside the float64 arbiter's bar are pinned there.
+
+A case is everything the sweep draws for it from ONE numpy generator, in the sweep's order; replaying case k consumes the draws of cases 0 .. k - 1."""
+import numpy as np
+
+import oracle
+from ibgs_amd import synthetic as syn
+from tests.metrics import rel_l2
+
+
+# ---- tools/fuzz_parity.py --------------------------------------------------------------------------------------------------------------------------
+def draw_parity(rng, big):
+    """The parameters of the next case (big: None | "big" | "trained").  The upstream gradients are drawn by draw_parity_grads afterwards."""
+    c = {}
+    c["P"] = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000, 9000]))
+    c["W"], c["H"] = int(rng.integers(8, 320)), int(rng.integers(8, 240))
+    if big:
+        c["P"] = int(rng.choice([3000, 9000, 20000, 40000]))
+        c["W"], c["H"] = int(rng.integers(480, 1281)), int(rng.integers(360, 721))
+    c["deg"] = int(rng.integers(0, 4)); c["geo"] = bool(rng.integers(0, 3) == 0)
+    c["opacity"] = str(rng.choice(["init", "trained"])); c["smul"] = float(rng.choice([0.5, 1.0, 2.5]))
+    c["wave_shape"] = [None, "tile", "quadrant"][int(rng.integers(0, 3))]
+    if big:
+        c["wave_shape"] = None
+    c["sseed"] = int(rng.integers(0, 10**6))
+    c["n_src"], c["Lb"] = (int(rng.integers(1, 6)), int(rng.integers(1, 9))) if c["geo"] else (1, 4)
+    c["big"] = big
+    c["cull"] = not (big and c["sseed"] % 4 == 0)          # big modes: a quarter of the cases on the reference's AABB lists
+    return c
+
+
+def draw_parity_grads(rng, c):
+    H, W = c["H"], c["W"]
+    g = {"color": rng.standard_normal((3, H, W)).astype(np.float32)}
+    if c["geo"]:      # every differentiable geo output takes part
+        g["normal_map"] = rng.standard_normal((3, H, W)).astype(np.float32)
+        g["median_depth"] = rng.standard_normal((1, H, W)).astype(np.float32)
+        g["warped_image"] = rng.standard_normal((15, H, W)).astype(np.float32)
+    return g
+
+
+def build_parity(c):
+    """The oracle-style input dict of a drawn case."""
+    from tests.test_gpu_parity import add_sources, scene
+    if c["big"] == "trained":          # the trained generator's knobs as well (drawn from a generator of their own: the other modes' sequences stay what they were)
+        r2 = np.random.default_rng(c["sseed"])
+        aniso = [None, "plane", "needle", "mixed"][int(r2.integers(0, 4))]; cl = float(r2.choice([0.0, 0.3, 0.5])); sig = float(r2.choice([0.0, 1.0]))
+        inp = syn.make_scene(c["P"], c["W"], c["H"], sh_degree=c["deg"], seed=c["sseed"], opacity=c["opacity"], with_planes=c["geo"], anisotropy=aniso, scale_sigma=sig, cluster=cl)
+        mul = c["smul"] * (3.0 if sig == 0.0 else 6.0)
+        inp["scales"] = (inp["scales"] * mul).astype(np.float32)
+        if c["geo"]:
+            inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
+        c["knobs"] = "anisotropy %s cluster %.1f sigma %.0f" % (aniso, cl, sig)
+    else:
+        inp = scene(P=c["P"], W=c["W"], H=c["H"], deg=c["deg"], seed=c["sseed"], opacity=c["opacity"], planes=c["geo"], scale_mul=c["smul"] * (3.0 if c["big"] else 1.0))
+    if c["geo"]:
+        inp = add_sources(inp, n_src=c["n_src"], L=c["Lb"])
+    return inp
+
+
+def parity_case(seed, index, big):
+    """Case `index` of `tools/fuzz_parity.py N seed - big`: (parameters, input dict, upstream gradients)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(index):
+        draw_parity_grads(rng, draw_parity(rng, big))
+    c = draw_parity(rng, big)
+    inp = build_parity(c)
+    return c, inp, draw_parity_grads(rng, c)
+
+
+ALL_GRADS = {"dL_dmeans3D": "means3D", "dL_dmeans2D": "means2D", "dL_dopacity": "opacities", "dL_dsh": "shs", "dL_dscales": "scales", "dL_drotations": "rotations"}
+
+
+def oracle_builds(inp, g, cull, builds=("plain", "fma", "f64", "acc32")):
+    """{build: (forward dict, backward dict)} of the oracle's builds on one case."""
+    out = {}
+    for b in builds:
+        with oracle.variant(b):
+            r = oracle.forward(inp, cull=cull)
+            out[b] = (r, oracle.backward(inp, r, g["color"], g.get("normal_map"), g.get("median_depth"), g.get("warped_image")))
+    return out
+
+
+def arbiter_pairs(hip_grads, ob, geo):
+    """Per gradient: (HIP, oracle fp32, its fma twin, the oracle with float sums) as relative L2 distances from the float64 build."""
+    allk = dict(ALL_GRADS)
+    if geo:
+        allk["dL_dall_map"] = "all_map"
+    b64 = ob["f64"][1]
+    pairs = {}
+    for k, v in allk.items():
+        ref = np.asarray(ob["plain"][1][k])
+        if np.abs(ref).sum() == 0:
+            continue
+        f64 = np.asarray(b64[k]).reshape(ref.shape)
+        pairs[v] = tuple([rel_l2(np.asarray(hip_grads[v]).reshape(ref.shape), f64)] + [rel_l2(np.asarray(ob[b][1][k]).reshape(ref.shape), f64) for b in ("plain", "fma", "acc32")])
+    return pairs
+
+
+def arbiter_ratio(pairs, floor=1e-3):
+    """max over the gradients of |HIP - f64| / max(floor, the farthest fp32 build of the oracle): <= 2 is the arbiter's bar (tests/test_gpu_anisotropic.py: F64_K)."""
+    return max(p[0] / max(floor, max(p[1:])) for p in pairs.values())
+
+
+# ---- tools/fuzz_fused.py ---------------------------------------------------------------------------------------------------------------------------
+def draw_fused(rng):
+    return {"P": int(rng.choice([500, 2500, 6000])), "W": int(rng.integers(96, 520)), "H": int(rng.integers(80, 340)), "seed": int(rng.integers(0, 10**6)), "learnt": bool(rng.integers(0, 2))}
+
+
+def fused_case(seed, index):
+    rng = np.random.default_rng(seed)
+    for _ in range(index):
+        draw_fused(rng)
+    return draw_fused(rng)

@@ -485,3 +485,56 @@ def test_sharded_step_at_world_4_equals_one_process_accumulating_in_rank_order(t
                 assert torch.equal(r[P]["mA"][k], r[P]["mS"][k]), (P, k)
             for r in res[1:]:
                 assert torch.equal(r[P]["A"][k], res[0][P]["A"][k]), (P, k)      # identical replicas
+
+
+# ---- round 6: force=True issues every collective in a process group of ONE rank (what tests/test_gpu_rccl_world1.py runs over nccl on the GPU box) ----------
+def _worker_forced(rank, world, port, out_dir):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = vdist.init_from_env(backend="gloo", force=True)
+    assert (r, w) == (0, 1) and dist.is_initialized()
+    P, M, deg = 33, 16, 3
+    out = {}
+    for force in (False, True):
+        g = torch.Generator().manual_seed(0)
+        xyz = torch.randn(P, 3, generator=g).requires_grad_(True)
+        f_dc = torch.randn(P, 1, 3, generator=g).requires_grad_(True); f_rest = torch.randn(P, M - 1, 3, generator=g).requires_grad_(True)
+        opa = torch.rand(P, 1, generator=g).requires_grad_(True)
+        red = vdist.ViewParallelReducer([xyz, f_dc, f_rest, opa], sh=[f_dc, f_rest], means3D=xyz, expand=_expand_ref, force=force)
+        assert (red._agree is not None) == force
+        gr = torch.Generator().manual_seed(100)
+        with red.capture() as sink:
+            for v in range(2):
+                sink.append({"dcolor": torch.randn(P, 3, generator=gr), "campos": torch.randn(3, generator=gr) * 4.0, "degree": deg, "M": M})
+        xyz.grad = torch.randn(P, 3, generator=gr); opa.grad = torch.randn(P, 1, generator=gr)
+        red.reduce()
+        out[force] = {"xyz": xyz.grad.clone(), "opa": opa.grad.clone(), "sh": torch.cat([f_dc.grad, f_rest.grad], dim=1), "agreements": red.n_agreements, "bytes": red.last_bytes}
+        # the sharded step: all-to-all / reduce-scatter / all-gather at world 1
+        for ordered in (True, False):
+            s = {"xyz": torch.randn(P, 3, generator=g).requires_grad_(True), "opa": torch.rand(P, 1, generator=g).requires_grad_(True)}
+            opt = torch.optim.Adam([{"params": [s["xyz"]], "lr": 1e-2}, {"params": [s["opa"]], "lr": 5e-2}], lr=0.0, eps=1e-15)
+            sh = vdist.ShardedOptimizerStep(opt, means3D=s["xyz"], expand=_expand_ref, adam=_adam_ref, ordered=ordered, force=force)
+            for k in s:
+                s[k].grad = torch.randn(s[k].shape, generator=gr)
+            sh.step()
+            assert sh.state_is_gathered == (not force)
+            sh.gather_state()
+            out[force]["sharded_%d" % ordered] = {k: v.detach().clone() for k, v in s.items()}
+        st = vdist.allreduce_densification_stats(torch.randn(P, 3, generator=gr), torch.rand(P, 3, generator=gr), torch.arange(P, dtype=torch.int32) % 3, force=force)
+        out[force]["stats"] = [t.clone() for t in st]
+        vdist.assert_replicas_identical([xyz], force=force)
+    torch.save(out, os.path.join(out_dir, "forced.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forced_exchange_at_world_one_is_the_identity(tmp_path):
+    mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(tmp_path, "forced.pt"))
+    assert res[True]["agreements"] == 1 and res[False]["agreements"] == 0 and res[True]["bytes"] > 0 and res[False]["bytes"] == 0
+    for k in ("xyz", "opa", "sh"):
+        assert torch.equal(res[True][k], res[False][k]), k
+    for o in (0, 1):
+        for k in ("xyz", "opa"):
+            assert torch.equal(res[True]["sharded_%d" % o][k], res[False]["sharded_%d" % o][k])
+    for a, b in zip(res[True]["stats"], res[False]["stats"]):
+        assert torch.equal(a, b)
