@@ -59,11 +59,28 @@ def build_parity(c):
     return inp
 
 
-def parity_case(seed, index, big):
-    """Case `index` of `tools/fuzz_parity.py N seed - big`: (parameters, input dict, upstream gradients)."""
-    rng = np.random.default_rng(seed)
-    for _ in range(index):
-        draw_parity_grads(rng, draw_parity(rng, big))
+def _pinned_rng(seed, index, big):
+    """The generator as it stands right before case `index` is drawn, from tests/golden/fuzz_pins.json (tests/golden/make_fuzz_pins.py) when the case is pinned there."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_pins.json")
+    if os.path.exists(path):
+        for e in json.load(open(path)):
+            if e["kind"] == "parity" and (e["seed"], e["index"], e["mode"]) == (seed, index, big):
+                rng = np.random.default_rng(0)
+                rng.bit_generator.state = {"bit_generator": e["bit_generator"], "state": {"state": int(e["state"]["state"]), "inc": int(e["state"]["inc"])},
+                                           "has_uint32": e["has_uint32"], "uinteger": e["uinteger"]}
+                return rng
+    return None
+
+
+def parity_case(seed, index, big, replay=False):
+    """Case `index` of `tools/fuzz_parity.py N seed - big`: (parameters, input dict, upstream gradients).  replay: draw cases 0 .. index - 1 even when the
+    generator state of the case is pinned (what the pin is checked against)."""
+    rng = None if replay else _pinned_rng(seed, index, big)
+    if rng is None:
+        rng = np.random.default_rng(seed)
+        for _ in range(index):
+            draw_parity_grads(rng, draw_parity(rng, big))
     c = draw_parity(rng, big)
     inp = build_parity(c)
     return c, inp, draw_parity_grads(rng, c)

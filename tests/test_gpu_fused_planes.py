@@ -36,19 +36,29 @@ def _scene(P=2500, W=160, H=112, seed=7):
     return dev, g, cams, scene, pipe, args, bg
 
 
-def _run(fused, learnt, g, dev, cams, scene, pipe, args, bg, seed=3):
+def _run(fused, learnt, g, dev, cams, scene, pipe, args, bg, seed=3, planes_out=None, mask=None):
+    """planes_out: a dict that receives the plane map the kernels built themselves ("all_map": (P, 5), rows of the Gaussians with tiles; "have": which rows)."""
     pc = simple_scene.SimpleGaussians(g, sh_degree=2, device=dev)
     old = renderer.FUSED_PLANE_MAP
     renderer.FUSED_PLANE_MAP = fused
     try:
         out = renderer.render(cams[0], pc, scene, pipe, args, bg, learnt_normal=learnt, nb_src_frames=3, buffer_length=4,
                               render_geo=True, return_depth_normal=False)
+        if planes_out is not None:          # the records of the forward (geom arena), before backward() frees the saved tensors
+            from tests import hipref
+            P = int(pc.get_xyz.shape[0])
+            rec = hipref.internal_state({"color": out["render"]}, {"means3D": np.zeros((P, 3), np.float32), "W": cams[0].image_width, "H": cams[0].image_height})["rec"]
+            am = np.zeros((P, 5), np.float32)
+            am[:, :3] = rec[:, 12:15]; am[:, 3] = 1.0; am[:, 4] = rec[:, 7]
+            planes_out["all_map"] = am
+            planes_out["have"] = out["radii"].detach().cpu().numpy() > 0
         gen = torch.Generator(device=dev).manual_seed(seed)
         H, W = cams[0].image_height, cams[0].image_width
-        loss = ((out["render"] * torch.randn(3, H, W, device=dev, generator=gen)).sum()
-                + (out["rendered_normal"] * torch.randn(3, H, W, device=dev, generator=gen)).sum()
-                + (out["median_intersected_depth"] * torch.randn(1, H, W, device=dev, generator=gen)).sum()
-                + (out["warped_image"] * torch.randn(15, H, W, device=dev, generator=gen)).sum())
+        keep = 1.0 if mask is None else (~torch.as_tensor(mask, device=dev)).float().view(1, H, W)          # mask: pixels whose upstream gradients are zeroed (all four outputs)
+        loss = ((out["render"] * (torch.randn(3, H, W, device=dev, generator=gen) * keep)).sum()
+                + (out["rendered_normal"] * (torch.randn(3, H, W, device=dev, generator=gen) * keep)).sum()
+                + (out["median_intersected_depth"] * (torch.randn(1, H, W, device=dev, generator=gen) * keep)).sum()
+                + (out["warped_image"] * (torch.randn(15, H, W, device=dev, generator=gen) * keep)).sum())
         loss.backward()
     finally:
         renderer.FUSED_PLANE_MAP = old
@@ -78,14 +88,21 @@ def test_fused_glue_equals_torch_glue(learnt):
         assert g_fus["_normal"] is None and g_fus["_offset"] is None
 
 
-def _oracle_chain(learnt, g, dev, cams, scene, bg, seed=3):
+def _oracle_chain(learnt, g, dev, cams, scene, bg, seed=3, planes=None, mask=None):
     """The same step as _run(fused=True, ...) WITHOUT any HIP kernel: the reference's torch glue (renderer._plane_map and
-    the activations of SimpleGaussians) on CPU tensors -> oracle.forward / oracle.backward -> torch.autograd through the glue."""
+    the activations of SimpleGaussians) on CPU tensors -> oracle.forward / oracle.backward -> torch.autograd through the glue.
+    planes (from _run(planes_out=...)): evaluate the rasterizer at the plane map the KERNELS built instead of the torch glue's -- the two agree to an ulp of the
+    normal, and at a pixel a plane is seen edge-on (depth = -dist / (n . ray), n . ray ~ 1e-5) that ulp is per cents of the depth and of everything behind it:
+    an input-conditioning effect no arithmetic can undo, so the float64 arbiter must look at the same inputs (tests/test_gpu_fuzz_pins.py).  The gradient still
+    flows back through the torch glue (straight-through: the values are replaced, the derivative is the glue's)."""
     cpu = torch.device("cpu")
     pc = simple_scene.SimpleGaussians(g, sh_degree=2, device=cpu)
     cam = cams[0]
     ccam = simple_scene.SimpleNamespace(world_view_transform=cam.world_view_transform.cpu(), camera_center=cam.camera_center.cpu())
     am = renderer._plane_map(pc, ccam, learnt, pc.get_xyz)
+    if planes is not None:
+        want = torch.as_tensor(planes["all_map"]); have = torch.as_tensor(planes["have"])[:, None]
+        am = am + (torch.where(have, want, am.detach()) - am.detach())
     chosen = cam.nearest_id[:3]
     r2s, scp = syn.ref_to_src({"viewmatrix": cam.world_view_transform.cpu().numpy()},
                               [{"viewmatrix": cams[j].world_view_transform.cpu().numpy()} for j in chosen])
@@ -100,6 +117,8 @@ def _oracle_chain(learnt, g, dev, cams, scene, bg, seed=3):
     ref = oracle.forward(inp, cull=True)
     gen = torch.Generator(device=dev).manual_seed(seed)            # the very gradients _run() draws, in its order
     gr = [torch.randn(c, H, W, device=dev, generator=gen).cpu().numpy() for c in (3, 3, 1, 15)]
+    if mask is not None:          # (as _run: zero upstream gradients at the masked pixels)
+        gr = [x * (~np.asarray(mask)).astype(np.float32).reshape(1, H, W) for x in gr]
     rb = oracle.backward(inp, ref, gr[0], gr[1], gr[2], gr[3])
     total = 0
     for k, rk in (("means3D", "dL_dmeans3D"), ("shs", "dL_dsh"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),

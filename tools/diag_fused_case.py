@@ -14,10 +14,14 @@ seed, index = int(sys.argv[1]), int(sys.argv[2])
 c = fc.fused_case(seed, index)
 print("case", c)
 dev, g, cams, scene, pipe, args, bg = _scene(P=c["P"], W=c["W"], H=c["H"], seed=c["seed"])
-o_fus, g_fus = _run(True, c["learnt"], g, dev, cams, scene, pipe, args, bg)
-ref32, g32 = _oracle_chain(c["learnt"], g, dev, cams, scene, bg)
+planes = {} if os.environ.get("DIAG_SAME_PLANES", "1") == "1" else None          # 1 (default): the oracle is evaluated at the plane map the kernels built (see _oracle_chain)
+o_fus, g_fus = _run(True, c["learnt"], g, dev, cams, scene, pipe, args, bg, planes_out=planes)
+ref32, g32 = _oracle_chain(c["learnt"], g, dev, cams, scene, bg, planes=planes)
 with oracle.variant("f64"):
-    ref64, g64 = _oracle_chain(c["learnt"], g, dev, cams, scene, bg)
+    ref64, g64 = _oracle_chain(c["learnt"], g, dev, cams, scene, bg, planes=planes)
+if planes is not None:
+    from ibgs_amd import renderer as _r, simple_scene as _ss
+    print("plane map of the kernels vs the torch glue: see tests/test_gpu_glue_golden.py; rows with tiles: %d of %d" % (planes["have"].sum(), planes["have"].size))
 H, W = c["H"], c["W"]
 names = ["_xyz", "_rotation", "_scaling", "_opacity"]
 for n in names:

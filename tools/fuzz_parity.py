@@ -7,9 +7,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from ibgs_amd import rasterizer, synthetic as syn
-from tests import hipref
+from tests import fuzz_cases as fc, hipref
 from tests.metrics import l1, rel_l2
-from tests.test_gpu_parity import add_sources, scene
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -19,36 +18,17 @@ rasterizer.DETERMINISTIC = os.environ.get("FUZZ_DETERMINISTIC") == "1"          
 worst = {"color": 0.0, "grad": 0.0, "ncontrib": 1.0}
 bad = 0
 for case in range(n_cases):
-    P = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000, 9000]))
-    W, H = int(rng.integers(8, 320)), int(rng.integers(8, 240))
-    if BIG:
-        P = int(rng.choice([3000, 9000, 20000, 40000]))
-        W, H = int(rng.integers(480, 1281)), int(rng.integers(360, 721))
-    deg = int(rng.integers(0, 4)); geo = bool(rng.integers(0, 3) == 0)
-    opacity = str(rng.choice(["init", "trained"])); smul = float(rng.choice([0.5, 1.0, 2.5]))
-    rasterizer.WAVE_SHAPE = [None, "tile", "quadrant"][int(rng.integers(0, 3))]
-    if BIG:
-        rasterizer.WAVE_SHAPE = None
-    sseed = int(rng.integers(0, 10**6))
-    n_src, Lb = (int(rng.integers(1, 6)), int(rng.integers(1, 9))) if geo else (1, 4)
+    # the draws live in tests/fuzz_cases.py (tests/test_gpu_fuzz_pins.py replays single cases of a sweep from there)
+    c = fc.draw_parity(rng, BIG)
+    P, W, H, deg, geo, sseed = c["P"], c["W"], c["H"], c["deg"], c["geo"], c["sseed"]
+    rasterizer.WAVE_SHAPE = c["wave_shape"]
     if only is not None and case != only:          # consume the same draws as the full run
-        rng.standard_normal((3, H, W))
-        if geo: rng.standard_normal((3, H, W)); rng.standard_normal((1, H, W)); rng.standard_normal((15, H, W))
+        fc.draw_parity_grads(rng, c)
         continue
-    if BIG == "trained":          # the trained generator's knobs as well (drawn from a generator of their own: the other modes' sequences stay what they were)
-        r2 = np.random.default_rng(sseed)
-        aniso = [None, "plane", "needle", "mixed"][int(r2.integers(0, 4))]; cl = float(r2.choice([0.0, 0.3, 0.5])); sig = float(r2.choice([0.0, 1.0]))
-        inp = syn.make_scene(P, W, H, sh_degree=deg, seed=sseed, opacity=opacity, with_planes=geo, anisotropy=aniso, scale_sigma=sig, cluster=cl)
-        mul = smul * (3.0 if sig == 0.0 else 6.0)
-        inp["scales"] = (inp["scales"] * mul).astype(np.float32)
-        if geo:
-            inp["all_map"] = syn.plane_all_map(inp["means3D"], inp["scales"], inp["rotations"], inp["_cam"])
-        print("     case %d: anisotropy %s cluster %.1f sigma %.0f" % (case, aniso, cl, sig))
-    else:
-        inp = scene(P=P, W=W, H=H, deg=deg, seed=sseed, opacity=opacity, planes=geo, scale_mul=smul * (3.0 if BIG else 1.0))
-    if geo:
-        inp = add_sources(inp, n_src=n_src, L=Lb)
-    cull = not (BIG and sseed % 4 == 0)          # big modes: a quarter of the cases on the reference's AABB lists
+    inp = fc.build_parity(c)
+    if BIG == "trained":
+        print("     case %d: %s" % (case, c["knobs"]))
+    cull = c["cull"]
     rasterizer.TILE_CULL = cull
     ref = oracle.forward(inp, cull=cull)
     outs, lv, _ = hipref.run_forward(inp)
@@ -57,10 +37,10 @@ for case in range(n_cases):
     ok = ist["R"] == ref["num_rendered"] and np.array_equal(ist["point_list"], ref["point_list"]) and np.array_equal(o["radii"], ref["radii"])
     dc = l1(o["color"], ref["color"])
     nc = float((ist["n_contrib"] == ref["n_contrib"]).mean())
-    g = rng.standard_normal((3, H, W)).astype(np.float32)
+    gd = fc.draw_parity_grads(rng, c)
+    g = gd["color"]
     if geo:      # every differentiable geo output takes part
-        gn = rng.standard_normal((3, H, W)).astype(np.float32); gdp = rng.standard_normal((1, H, W)).astype(np.float32)
-        gw = rng.standard_normal((15, H, W)).astype(np.float32)
+        gn, gdp, gw = gd["normal_map"], gd["median_depth"], gd["warped_image"]
         ((outs["color"] * torch.as_tensor(g, device="cuda")).sum() + (outs["normal_map"] * torch.as_tensor(gn, device="cuda")).sum()
          + (outs["median_depth"] * torch.as_tensor(gdp, device="cuda")).sum() + (outs["warped_image"] * torch.as_tensor(gw, device="cuda")).sum()).backward()
         rb = oracle.backward(inp, ref, g, gn, gdp, gw)
