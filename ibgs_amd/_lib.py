@@ -23,7 +23,6 @@ FLAG_DETERMINISTIC = 128
 FLAG_TEX_PACKED = 256
 FLAG_NO_REF_POWER_SKIP = 512
 FLAG_NO_ABS_GRAD = 1024
-FLAG_SPLIT_GEO_EPILOGUE = 2048
 FLAG_REF_ARITH = 4096
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 MAX_VIEWS = 8
@@ -61,7 +60,6 @@ class ForwardArgs(ctypes.Structure):
         ("tile_order_hint", ctypes.c_void_p),
         ("binning", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
         ("shs_rest", c_float_p),
-        ("depth_bound_hint", c_float_p), ("depth_bound_out", c_float_p),
     ]
 
 
@@ -117,7 +115,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
            "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
-           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_densify_stats", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats",
+           "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_densify_stats", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats", "ibgs_check_async",
            "ibgs_required_l1", "ibgs_l1_loss", "ibgs_l1_grad", "ibgs_l1_rescale",
            "ibgs_depth_normal_forward", "ibgs_depth_normal_backward", "ibgs_activate_forward", "ibgs_activate_backward",
            "ibgs_last_error", "ibgs_version"]
@@ -201,6 +199,8 @@ def load():
     lib.ibgs_required_geo_table.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.ibgs_last_forward_stats.restype = None
     lib.ibgs_last_forward_stats.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+    lib.ibgs_check_async.restype = ctypes.c_int32
+    lib.ibgs_check_async.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.ibgs_required_geo_table_for.restype = ctypes.c_size_t
     lib.ibgs_required_geo_table_for.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     lib.ibgs_required_deterministic_for.restype = ctypes.c_size_t

@@ -18,20 +18,10 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <map>
+#include <mutex>
 
 namespace ibgs {
-
-TileMap tile_map_from_env(const char* name, TileMap dflt)
-{   // "rr" | "g<N>" | "b<X>x<Y>" (common.h); anything else keeps the default
-    const char* v = getenv(name);
-    if (!v) return dflt;
-    TileMap m = dflt;
-    int a = 0, b = 0;
-    if (v[0] == 'r') m = TileMap{TMAP_RR, 1, 1, 1};
-    else if (v[0] == 'g' && sscanf(v + 1, "%d", &a) == 1 && a >= 1 && a <= 4096) m = TileMap{TMAP_GROUP, a, 1, 1};
-    else if (v[0] == 'b' && sscanf(v + 1, "%dx%d", &a, &b) == 2 && a >= 1 && b >= 1 && a * b <= 4096) m = TileMap{TMAP_BLOCK, 1, a, b};
-    return m;
-}
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...)
@@ -71,7 +61,6 @@ GeomState GeomState::carve(char* base, size_t P, size_t* total)
     g.offsets = c.take<uint32_t>(P + 5);
     g.hist_elems = radix_hist_elems(P);
     g.hist = c.take<uint32_t>(g.hist_elems);
-    g.tile_partial2 = c.take<uint32_t>((P + 63) / 64 + 1);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return g;
 }
@@ -93,7 +82,6 @@ ImgState ImgState::carve(char* base, int W, int H, size_t* total)
     im.slot_c = c.take<uint32_t>(HW * IBGS_MAX_BUFFER_LENGTH);
     im.tile_walked = c.take<uint32_t>(tiles * 4);
     im.tile_order = c.take<uint32_t>((tiles + ORDER_CLASSES - 1) / ORDER_CLASSES * ORDER_CLASSES);
-    im.tile_done = c.take<uint32_t>(tiles * 4);
     im.tile_risky = c.take<uint32_t>(tiles * 4);
     if (total) *total = (size_t)(c.cur - reinterpret_cast<uintptr_t>(base)) + 128;
     return im;
@@ -159,12 +147,10 @@ static int stage_check(hipStream_t s, bool debug, const char* what)
 
 // R of a hinted forward without a copy, an event or a second stream (round 5): ONE workgroup adds up the per-wave tile sums the preprocess kernel left and stores
 // the total, then a ticket, straight into pinned host memory; the host polls the ticket (ibgs_forward).  The four runtime calls it replaces -- event
-// record, stream wait, copy, event record -- cost the forward ~12 us of host time, and the copy engine's own latency on top.  The ticket counts in
-// DEVICE memory (a kernel argument could not change from call to call were this sequence ever replayed from a graph); the host knows which one it waits for.
-__global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __restrict__ partial, uint32_t nwords, uint32_t* __restrict__ seq_dev, volatile uint32_t* host_words,
-                                                             uint32_t* __restrict__ zero2 /* two words to clear (the depth-bound check's verdict, img meta[12..13]) or nullptr */)
+// record, stream wait, copy, event record -- cost the forward ~12 us of host time, and the copy engine's own latency on top.  The ticket is a kernel argument
+// (round 6: until round 5 a device word counted it, for a replay from a hipGraph that no longer exists; an argument cannot get out of step after a failed call).
+__global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __restrict__ partial, uint32_t nwords, uint32_t ticket, volatile uint32_t* host_words)
 {
-    if (zero2 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
     __shared__ unsigned long long s_w[16];
     unsigned long long sum = 0;
     for (uint32_t i = threadIdx.x; i < nwords; i += 1024) sum += partial[i];
@@ -176,8 +162,6 @@ __global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __r
         for (int w = 0; w < 16; w++) t += s_w[w];
         host_words[0] = (uint32_t)t; host_words[1] = (uint32_t)(t >> 32);
         __threadfence_system();                                   // the total is visible to the host before the ticket is
-        const uint32_t ticket = *seq_dev + 1u;
-        *seq_dev = ticket;
         __hip_atomic_store(const_cast<uint32_t*>(host_words) + 2, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -247,7 +231,7 @@ size_t ibgs_tile_order_slots(int32_t W, int32_t H)
 int64_t ibgs_img_offset(int32_t W, int32_t H, const char* name)
 {
     size_t t; ImgState im = ImgState::carve(nullptr, W, H, &t);
-    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order); OFF(im, tile_done); OFF(im, tile_risky);
+    OFF(im, ranges); OFF(im, final_T); OFF(im, n_contrib); OFF(im, sum_w); OFF(im, low_high); OFF(im, valid_idx); OFF(im, valid_w); OFF(im, slot_c); OFF(im, meta); OFF(im, tile_walked); OFF(im, tile_order); OFF(im, tile_risky);
     return -1;
 }
 int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
@@ -258,48 +242,68 @@ int64_t ibgs_binning_offset(int64_t R, int32_t W, int32_t H, const char* name)
 }
 #undef OFF
 
-// Pinned host words + event for the R read-back, one per calling thread AND device (created on first use, never freed): an event
-// belongs to the device that was current when it was created, so a thread that drives several GPUs needs one per device.
+// Pinned host words + event for the R read-back, one per (device, stream) of the PROCESS (created on first use, never freed).  Keyed by the stream, not by the
+// calling thread (round 6): PyTorch runs the backward on an autograd worker thread, and the backward must find the slot of the forward it belongs to -- which it
+// does through the stream both were queued on.  (Two threads driving one stream at the same time would share a slot: they would be racing on the stream anyway.)
 struct RSlot {
-    uint32_t* host; hipEvent_t ev;
-    uint32_t* stats; bool stats_pending;          // R as the binning counted it, -, C: diagnostics the binning's last kernel stores HERE (pinned host words), read when somebody asks
-    bool flag_pending;                                                 // stats[3] = the depth sort's STICKY error word, stored by that kernel too; a hinted forward has not been vouched for yet
-    hipStream_t last_stream;                                           // the stream of that forward (ibgs_last_forward_stats drains it before it reads)
-    uint32_t* seq_dev; uint32_t seq_host;                              // ticket counter of rendered_note_kernel (device word) and the last ticket the host has waited for
+    uint32_t* host; hipEvent_t ev;             // 64 bytes of pinned, host-coherent memory: [0..1] R, [2] the ticket of rendered_note_kernel; stats = host + 8
+    uint32_t* stats; bool stats_pending;       // stats[0] R as the binning counted it, [2] C, [3] the depth sort's STICKY error word, [4] the ticket of the binning's note: all stored by
+                                               // tile_ranges_kernel of a hinted forward, read when somebody asks (stats) or at the next point somebody is waiting anyway (the error word)
+    bool flag_pending;                         // a hinted forward whose depth sort nobody has vouched for yet
+    hipStream_t last_stream;
+    uint32_t seq;                              // tickets handed out on this slot; the last hinted forward's = what stats[4] shows once its binning has run
 };
-static RSlot* rslot()
+static std::mutex g_slot_mutex;
+static std::map<std::pair<int, hipStream_t>, RSlot*> g_slots;
+static RSlot* rslot(hipStream_t s, bool create)
 {
-    constexpr int MAX_DEV = 32;
-    static thread_local RSlot slots[MAX_DEV] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { set_error("hipGetDevice failed / device index out of range"); return nullptr; }
-    RSlot& slot = slots[dev];
-    if (!slot.host) {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
-        if (hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return nullptr; }
-        slot.host = static_cast<uint32_t*>(p);
-        memset(p, 0, 64);          // (stats[3] is a sticky error word the GPU only ever sets; host[2] the last ticket)
-        void* sq = nullptr;
-        if (hipMalloc(&sq, 64) != hipSuccess || hipMemset(sq, 0, 64) != hipSuccess) { set_error("hipMalloc for the ticket word failed"); return nullptr; }
-        slot.seq_dev = static_cast<uint32_t*>(sq); slot.seq_host = 0;
-        slot.stats = slot.host + 8;
-    }
-    return &slot;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("hipGetDevice failed"); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_slot_mutex);
+    auto it = g_slots.find({dev, s});
+    if (it != g_slots.end()) return it->second;
+    if (!create) return nullptr;
+    RSlot* slot = new RSlot();
+    void* p = nullptr;
+    // host-coherent and mapped, whatever HIP_HOST_COHERENT says: the device stores into it from running kernels and the host polls it
+    if (hipHostMalloc(&p, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { delete slot; set_error("hipHostMalloc for the R read-back failed"); return nullptr; }
+    if (hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); delete slot; set_error("hipEventCreate failed"); return nullptr; }
+    slot->host = static_cast<uint32_t*>(p);
+    memset(p, 0, 64);          // (stats[3] is a sticky error word the GPU only ever sets; host[2] / stats[4] the last tickets)
+    slot->stats = slot->host + 8;
+    slot->stats_pending = false; slot->flag_pending = false; slot->last_stream = s; slot->seq = 0;
+    g_slots[{dev, s}] = slot;
+    return slot;
 }
-// The depth sort's error word of a hinted forward is stored into pinned host memory by the binning's last kernel (tile_ranges_kernel), together with
-// the diagnostics; nobody queues anything for it and nobody waits for it inside that call (round 5: the tiles-touched sums leave right after the
-// preprocess kernel, so that the host is released while the GPU is still sorting).  The word is sticky.  It is looked at by the next entry into the
-// library on this thread at a point where the stream has provably passed that kernel -- after the next forward's wait for ITS R -- or, without
-// waiting, by a backward that finds it set, and reported THERE: an asynchronous error, like HIP's own.  (The look-back of the onesweep passes times
-// out only if a workgroup is starved for seconds.)
-static int check_sort_flag(RSlot* rs)
+// The depth sort's error word of a hinted forward is stored into pinned host memory by the binning's last kernel (tile_ranges_kernel), together with the
+// diagnostics and -- behind a system-scope fence -- that forward's ticket; nobody queues anything for it and nobody waits for it inside ibgs_forward (round 5: the
+// tiles-touched sums leave right after the preprocess kernel, so that the host is released while the GPU is still sorting).  The word is sticky.  It is reported
+//   * by the ibgs_backward of the SAME step (round 6): at its end, with every kernel of the backward queued, it waits -- briefly, bounded -- for the binning's note
+//     of its forward (normally long there: the loss and the backward's own launches have passed) and fails the call if the word is set: the optimiser never sees
+//     gradients of mis-ordered lists;
+//   * by the next ibgs_forward on the stream after its own wait for R (a forward that no backward followed), and by ibgs_check_async (eval-only callers).
+// (The look-back of the onesweep passes times out only if a workgroup is starved for seconds.)
+static int check_sort_flag(RSlot* rs, bool wait_for_note)
 {
     if (!rs || !rs->flag_pending) return 0;
+    volatile uint32_t* note = rs->stats + 4;
+    bool final_ = __atomic_load_n(const_cast<uint32_t*>(note), __ATOMIC_ACQUIRE) == rs->seq;
+    if (!final_ && wait_for_note) {
+        // bounded: ~2 ms of polling, then the check stays with the next entry into the library (an asynchronous error, like HIP's own)
+        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (uint32_t spins = 1; !final_; spins++) {
+            final_ = __atomic_load_n(const_cast<uint32_t*>(note), __ATOMIC_ACQUIRE) == rs->seq;
+            if ((spins & 255u) == 0) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 2000000ll) break;
+            }
+        }
+    }
     if (*(volatile uint32_t*)(rs->stats + 3)) {
         rs->stats[3] = 0u; rs->flag_pending = false;
-        set_error("depth sort of an earlier forward: decoupled look-back timed out (its lists were mis-ordered)"); return -IBGS_ERR_HIP;
+        set_error("depth sort: decoupled look-back timed out (the lists of this stream's last forward were mis-ordered)"); return -IBGS_ERR_HIP;
     }
+    if (final_) rs->flag_pending = false;          // that forward's binning has run and left the word clear: vouched for
     return 0;
 }
 
@@ -314,6 +318,18 @@ void ibgs_last_forward_stats(int64_t* out)
         g_stats_slot->stats_pending = false;
     }
     out[0] = g_last_stats[0]; out[1] = g_last_stats[1]; out[2] = g_last_stats[2];
+}
+// The asynchronous error of the forwards queued on `stream` (the depth sort's look-back time-out, see check_sort_flag), for callers no backward follows
+// (evaluation renders, the last forward of a run).  wait != 0: the stream is drained first, the answer is then final; else only what has arrived is reported.
+// tests only: the look-back patience of the depth sort's single-launch passes (0 = give up at the first unpublished word: provokes the asynchronous error path)
+void ibgs_debug_set_lookback_spins(uint32_t v) { radix_set_lookback_spins(v); }
+int32_t ibgs_check_async(void* stream, int32_t wait)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RSlot* rs = rslot(s, false);
+    if (!rs || !rs->flag_pending) return 0;
+    if (wait) IBGS_HIP(hipStreamSynchronize(s));
+    return check_sort_flag(rs, false);
 }
 
 int64_t ibgs_forward(const ibgs_forward_args* ap)
@@ -379,25 +395,20 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     const int gx = (a.W + TILE - 1) / TILE, gy = nv * ((a.H + TILE - 1) / TILE);
 
     const bool deferred = a.rendered_hint > 0 && !debug;
-    // depth-bound hint (ibgs_rast.h): the split preprocess path of a hinted colour / geo pass, and only where the sort's kernels can run guarded
-    const bool bound_ok = deferred && nv == 1 && !a.render_depth_only && a.shs && !a.colors_precomp && radix_uses_onesweep((size_t)Pn, 32) && preprocess_is_split(a);
-    const bool use_bound = bound_ok && a.depth_bound_hint != nullptr;
-    const bool track_done = bound_ok && (a.depth_bound_hint || a.depth_bound_out);
     const size_t nwaves = (size_t)nv * (((size_t)a.P + 63) / 64);          // words of per-wave tile sums the preprocess kernel wrote; the depth sort's error flag follows them
-    RSlot* rs = rslot();
+    RSlot* rs = rslot(s, true);
     if (!rs) return -IBGS_ERR_HIP;
+    uint32_t ticket = 0;
     { StageTimer t(s, IBGS_STAGE_PREPROCESS);
-      if ((rc = launch_preprocess(s, a, g, deferred ? 1 : 0, use_bound ? a.depth_bound_hint : nullptr))) return rc;
+      if ((rc = launch_preprocess(s, a, g, deferred ? 1 : 0))) return rc;
       if (deferred) {
           // R = the sum of the tiles touched, final as soon as the geometry kernel is: a one-workgroup kernel adds the per-wave sums up HERE and stores the
           // total + a ticket into pinned host memory, while the stream goes on with the SH colours and the depth sort.  (Until round 4 the sums left
           // behind the sort, by a copy on a second stream, together with the sort's error flag: on small frames the host then sat out five sort launches'
           // worth of GPU latency -- ~45 us of a 0.34 ms call pair, profiles/r05_host_split.txt -- before it could queue the loss and the backward.)
-          // (under a depth-bound hint: R of the UNBOUNDED lists, which the repair pass must be able to store -- the preprocess kernel sums both)
-          hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, use_bound ? g.tile_partial2 : g.tile_partial, (uint32_t)nwaves, rs->seq_dev, rs->host,
-                             track_done ? im.meta + 12 : nullptr);
+          ticket = ++rs->seq;          // (wraps after 4 G forwards on one stream: the comparison below is for equality)
+          hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, g.tile_partial, (uint32_t)nwaves, ticket, rs->host);
           IBGS_HIP(hipGetLastError());
-          rs->seq_host++;          // the ticket that kernel will write
           if ((rc = launch_preprocess(s, a, g, 2))) return rc;
       }
     }
@@ -432,7 +443,6 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if (deferred) cap = a.rendered_hint < (int64_t)0xFFFF0000ll ? a.rendered_hint : (int64_t)0xFFFF0000ll;
     else { if ((rc = exact_R(&R))) return rc; cap = R; }
 
-    BinState b_first{};
     auto tail = [&](int64_t n, bool read_back) -> int {
         int rc;
         // the hinted pass may use an arena the caller sized for the hint beforehand (ibgs_forward_args.binning: no call back into the caller, which
@@ -441,11 +451,10 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
         char* bin_mem = (read_back && a.binning && a.binning_bytes >= need) ? a.binning : a.binning_alloc(need, a.binning_user);
         if (!bin_mem) { set_error("binning_alloc returned NULL for R=%lld", (long long)n); return -IBGS_ERR_ALLOC; }
         BinState b = BinState::carve(bin_mem, (size_t)n, a.W, Hn, nullptr);
-        b_first = b;
         // hinted pass: the binning's last kernel leaves R as it counted it, the coarse slots in use and the depth sort's error word in pinned host memory
         // (diagnostics nobody waits for: ibgs_last_forward_stats; the error word: check_sort_flag)
         { StageTimer t(s, IBGS_STAGE_EMIT);
-          if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta, nv, read_back ? g.tile_partial + nwaves : nullptr, read_back ? rs->stats : nullptr))) return rc; }
+          if ((rc = launch_binning(s, Pn, n, gx, gy, g, b, im.ranges, a.tile_order_hint, im.meta, nv, read_back ? g.tile_partial + nwaves : nullptr, read_back ? rs->stats : nullptr, ticket))) return rc; }
         if (read_back) { rs->flag_pending = true; rs->last_stream = s; }
         { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, n, gx, gy, b))) return rc; }
         if ((rc = stage_check(s, debug, "binning"))) return rc;
@@ -460,32 +469,12 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     };
     const bool prev_pending = rs->flag_pending;          // a hinted forward before this one whose sort nobody has vouched for yet
     if ((rc = tail(cap, deferred))) return rc;
-    const int ntiles_img = gx * gy;
-    if (use_bound) {
-        // Was the bound sound?  bound_verify_kernel sets meta[12] if a tile's pixels did not all terminate in front of its bound; the REPAIR PASS queued right
-        // behind it -- the whole forward once more, without a bound, into the same arenas -- reads that word in every kernel and leaves at once when it is zero
-        // (~20 empty launches).  The host never waits for the verdict.
-        const uint32_t* guard = im.meta + 12;
-        { StageTimer t(s, IBGS_STAGE_PREPROCESS);
-          if ((rc = launch_bound_verify(s, ntiles_img, g, b_first, im, a.depth_bound_hint))) return rc;
-          if ((rc = launch_preprocess(s, a, g, 0, nullptr, guard))) return rc; }
-        { StageTimer t(s, IBGS_STAGE_DEPTH_SORT);
-          if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.tile_partial + nwaves, g.offsets + Pn + 3, true, g.offsets + Pn + 4, guard))) return rc; }
-        { StageTimer t(s, IBGS_STAGE_EMIT);
-          if ((rc = launch_binning(s, Pn, cap, gx, gy, g, b_first, im.ranges, a.tile_order_hint, im.meta, nv, g.tile_partial + nwaves, rs->stats, guard))) return rc; }
-        { StageTimer t(s, IBGS_STAGE_TILE_SORT); if ((rc = launch_binning_scatter(s, cap, gx, gy, b_first, guard))) return rc; }
-        { StageTimer t(s, IBGS_STAGE_RENDER_FWD);
-          const float4* rgba = a.render_geo ? reinterpret_cast<const float4*>((reinterpret_cast<uintptr_t>(a.tex) + 127) & ~uintptr_t(127)) : nullptr;
-          if ((rc = launch_render_forward(s, a, g, b_first, im, rgba, guard))) return rc; }
-    }
-    // the bound for this camera's next forward (when the hint turns out too small below, the lists are rebuilt first and this kernel runs again)
-    if (track_done && a.depth_bound_out && (rc = launch_bound_update(s, ntiles_img, g, b_first, im, use_bound ? a.depth_bound_hint : nullptr, a.depth_bound_out))) return rc;
     g_last_stats[1] = -1; g_last_stats[2] = 0;
     g_stats_slot = rs; rs->stats_pending = false;
     if (deferred) {
         {   // wait for the ticket: a few thousand polls of one pinned cache line, then yield between polls; bounded (a lost ticket must not hang the trainer)
             volatile uint32_t* tk = rs->host + 2;
-            const uint32_t want = rs->seq_host;
+            const uint32_t want = ticket;
             uint64_t spins = 0;
             struct timespec t0; bool timed = false;
             while (__atomic_load_n(const_cast<uint32_t*>(tk), __ATOMIC_ACQUIRE) != want) {
@@ -504,7 +493,7 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
                 }
             }
         }
-        // (this stream has now passed every kernel of the forwards before this one: their sticky error word is final)
+        // (this stream has now passed every kernel of the forwards before this one: their sticky error word is final -- a forward no backward followed)
         if (prev_pending && *(volatile uint32_t*)(rs->stats + 3)) {
             rs->stats[3] = 0u;
             set_error("depth sort of the previous forward: decoupled look-back timed out (its lists were mis-ordered)"); return -IBGS_ERR_HIP;
@@ -517,16 +506,8 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
             // second callback) and redo binning + render with the exact size (every output element is rewritten).  Same results
             // as without a hint, one wasted pass.
             IBGS_HIP(hipStreamSynchronize(s));
-            if ((rc = check_sort_flag(rs))) return rc;          // (the stream is drained: this forward's own word is final too)
-            if (use_bound) {          // the geometry state may be the bounded one: preprocess + depth sort once more without a bound
-                if ((rc = launch_preprocess(s, a, g, 0))) return rc;
-                if ((rc = radix_sort_pairs(s, g.sort_key, g.sort_val, (size_t)Pn, 32, g.hist, g.hist_elems, g.tile_partial + nwaves, g.offsets + Pn + 3, true, g.offsets + Pn + 4))) return rc;
-            }
+            if ((rc = check_sort_flag(rs, false))) return rc;          // (the stream is drained: this forward's own word is final too, and its note has arrived)
             if ((rc = tail(R, false))) return rc;
-            if (track_done && a.depth_bound_out) {
-                IBGS_HIP(hipMemsetAsync(im.meta + 12, 0, 2 * sizeof(uint32_t), s));
-                if ((rc = launch_bound_update(s, ntiles_img, g, b_first, im, nullptr, a.depth_bound_out))) return rc;
-            }
         } else rs->stats_pending = true;
     }
     g_last_stats[0] = R;
@@ -540,7 +521,8 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     hipStream_t s = reinterpret_cast<hipStream_t>(a.stream);
     const bool debug = (a.flags & IBGS_FLAG_DEBUG) != 0;
     if (a.P <= 0) return 0;                                       // rasterize_points.cu:221
-    { int frc = check_sort_flag(g_stats_slot); if (frc) return frc; }          // (no wait: reports the word if the GPU has already set it)
+    RSlot* rs = rslot(s, false);          // the slot of the forward queued on this stream (whichever thread calls: PyTorch's autograd worker, usually)
+    { int frc = check_sort_flag(rs, false); if (frc) return frc; }          // (no wait: reports the word if the GPU has already set it)
     if (!a.geom || !a.img || (!a.binning && a.R > 0)) { set_error("backward needs the forward's arenas"); return -IBGS_ERR_INVALID; }
     if (!a.grad_acc) { set_error("grad_acc scratch required"); return -IBGS_ERR_INVALID; }
     if (!a.dL_dmean2D || (!a.dL_dmean2D_abs && !(a.flags & IBGS_FLAG_NO_ABS_GRAD)) || !a.dL_dopacity || !a.dL_dmean3D) {
@@ -597,7 +579,8 @@ int32_t ibgs_backward(const ibgs_backward_args* ap)
     }
     { StageTimer t(s, IBGS_STAGE_PREPROCESS_BWD); if ((rc = launch_preprocess_backward(s, a, g))) return rc; }
     if ((rc = stage_check(s, debug, "preprocess backward"))) return rc;
-    return 0;
+    // everything is queued: was the forward these gradients belong to sound?  (check_sort_flag: a bounded wait for its binning's note, which has normally long arrived)
+    return check_sort_flag(rs, true);
 }
 
 int32_t ibgs_sh_grad_from_views(void* stream, int32_t P, int32_t D, int32_t M, int32_t n_views, const float* means3D,

@@ -223,9 +223,8 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg,
                                                                    const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fpr, const uint64_t* __restrict__ tmask_hi, const float4* __restrict__ rec,
                                                                    uint4* __restrict__ fp_sorted /* the footprints in depth order, for the place kernel */,
-                                                                   uint32_t* __restrict__ cnt /* ncells x nblk */, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                                   uint32_t* __restrict__ cnt /* ncells x nblk */)
 {
-    if (run_if && *run_if == 0u) return;
     extern __shared__ uint32_t s_cnt[];
     __shared__ uint32_t s_runs[PLACE_THREADS / 64][64];
     const uint32_t* __restrict__ order = n_kept[1] ? order1 : order0;          // (the depth sort's last pass may have left the result in its input buffer, scan_sort.hip)
@@ -265,9 +264,8 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg,
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) cnt[(size_t)(pg.c0 + c) * pg.nblk + blk] = s_cnt[c];
 }
 
-__global__ void __launch_bounds__(256) cell_colscan_kernel(int nblk, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cell_total, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+__global__ void __launch_bounds__(256) cell_colscan_kernel(int nblk, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cell_total)
 {
-    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_part[256];
     uint32_t* row = cnt + (size_t)blockIdx.x * nblk;
     const int per = (nblk + 255) / 256;
@@ -291,9 +289,8 @@ __global__ void __launch_bounds__(256) cell_colscan_kernel(int nblk, uint32_t* _
 // First entry of every cell + chunk bookkeeping + C, ONE workgroup (ncells <= a few thousand)
 __global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const uint32_t* __restrict__ cell_total, int ncells,
                                                          uint32_t* __restrict__ cell_start /* ncells + 1 */,
-                                                         uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */, uint32_t* __restrict__ C_out, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                         uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */, uint32_t* __restrict__ C_out)
 {
-    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_part[256], s_chunks[256];
     // exclusive scans over the cells (sequential per thread over a strip, then over the 256 strip sums), entries first
     const int per = (ncells + 255) / 256;
@@ -366,9 +363,8 @@ __device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __r
 __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order0, const uint32_t* __restrict__ order1, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi, const float4* __restrict__ rec,
                                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
-                                                                   uint4* __restrict__ cent, int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                                   uint4* __restrict__ cent, int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
 {
-    if (run_if && *run_if == 0u) return;
     // the extra workgroup (first slice only) is workgroup 0: dispatched first, it runs beside the placement instead of after it
     extern __shared__ unsigned long long s_place[];        // 4 x nc lane words (one table per wave), then nc next-free slots
     if (meta) { if (blockIdx.x == 0) { check_order_hint(ntiles, order_hint, meta, reinterpret_cast<uint32_t*>(s_place)); return; } }
@@ -450,9 +446,8 @@ __device__ __forceinline__ int cell_of_chunk(const uint32_t* __restrict__ cell_c
 // that lane t holds column t, and counts its bits -- instead of 64 ballots.
 __global__ void __launch_bounds__(64) expand_count_kernel(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_chunk0, int ncells,
                                                           const uint4* __restrict__ cent,
-                                                          uint32_t* __restrict__ chunk_cnt /* nchunks x 64 */, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                          uint32_t* __restrict__ chunk_cnt /* nchunks x 64 */)
 {
-    if (run_if && *run_if == 0u) return;
     const uint32_t ch = blockIdx.x;
     if (ch >= cell_chunk0[ncells]) return;
     const int lane = threadIdx.x;
@@ -482,9 +477,8 @@ __global__ void __launch_bounds__(64) expand_count_kernel(const uint32_t* __rest
 // crowded cell alone: 26 us instead of 7 when half of the Gaussians sit in one blob (`bench.py --cluster 0.5`).
 constexpr int CSCAN_WAVES = 8;
 __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint32_t* __restrict__ cell_chunk0, int ncells, int cgx, int gx, int gy,
-                                                                     uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ tile_total /* ntiles */, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                                     uint32_t* __restrict__ chunk_cnt, uint32_t* __restrict__ tile_total /* ntiles */)
 {
-    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_sum[CSCAN_WAVES][64];
     const int cell = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c0 = cell_chunk0[cell], c1 = cell_chunk0[cell + 1];
@@ -520,9 +514,8 @@ __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint3
 __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
                                                            uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
                                                            const uint32_t* __restrict__ sort_flag /* the depth sort's error word, or nullptr */,
-                                                           uint32_t* __restrict__ host_note /* pinned HOST words or nullptr: [0] R, [2] C, [3] |= sort error */, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                           uint32_t* __restrict__ host_note /* pinned HOST words or nullptr: [0] R, [2] C, [3] |= sort error, [4] = note_ticket */, uint32_t note_ticket)
 {
-    if (run_if && *run_if == 0u) return;
     // Every wave owns a contiguous range of tiles and walks it 64 tiles at a time: coalesced loads and stores, a wave-level scan per step.
     // (A strip of consecutive tiles per THREAD made every lane touch its own cache line, per step: 11 us at 1080p, 54 us for the 32 640 tiles
     // of a four-view batched depth pass.)  The totals stay in registers between the summing pass and the writing pass.
@@ -564,7 +557,11 @@ __global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t*
         tile_start[ntiles] = run; counters[0] = run;      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
         // what the host looks at LATER without having queued anything for it (api.hip, round 5: the copies, events and the stream wait that carried these words
         // cost the forward ~10 us of host time): diagnostics and the depth sort's sticky error word, stored straight into pinned host memory
-        if (host_note) { host_note[0] = run; host_note[2] = counters[2]; if (sort_flag && *sort_flag) host_note[3] = 1u; }
+        if (host_note) {
+            host_note[0] = run; host_note[2] = counters[2]; if (sort_flag && *sort_flag) host_note[3] = 1u;
+            __threadfence_system();          // the words above are visible to the host before the ticket that says "this forward's binning has run" (api.hip: check_sort_flag)
+            __hip_atomic_store(host_note + 4, note_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -579,9 +576,8 @@ constexpr int SCAT_STAGE = 4096;
 __global__ void __launch_bounds__(64) expand_scatter_kernel(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ cell_chunk0, int ncells,
                                                             int cgx, int gx, int gy, const uint4* __restrict__ cent,
                                                             const uint32_t* __restrict__ chunk_pref, const uint32_t* __restrict__ tile_start,
-                                                            uint32_t cap, uint32_t* __restrict__ point_list, const uint32_t* __restrict__ run_if /* guard of the repair pass (api.hip) or nullptr */)
+                                                            uint32_t cap, uint32_t* __restrict__ point_list)
 {
-    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_id[XCHUNK / 64][64];
     __shared__ uint8_t s_out[SCAT_STAGE];              // which entry of the chunk (round << 6 | lane): one byte per id, the id itself stays in s_id
     const uint32_t ch = blockIdx.x;
@@ -662,7 +658,7 @@ static int place_block_ranks(int P, size_t cnt_elems, int ncells)
 // Part 1: everything up to the tile ranges and the counters the host reads back (R, C); part 2 (launch_binning_scatter) writes the
 // lists.  Split so that the host's read-back can be queued between them and is served while scatter + render still run.
 int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const GeomState& g, const BinState& b, uint32_t* ranges,
-                   const uint32_t* order_hint, uint32_t* meta, int n_views, const uint32_t* sort_flag, uint32_t* host_note, const uint32_t* run_if)
+                   const uint32_t* order_hint, uint32_t* meta, int n_views, const uint32_t* sort_flag, uint32_t* host_note, uint32_t note_ticket)
 {
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy, ntiles = gx * gy;
     uint32_t* counters = g.offsets + P;               // R, depth sort error flag, C: what the host reads back in ONE copy (api.hip)
@@ -682,12 +678,12 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     const uint32_t* order = g.sort_val[0];
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
-        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_val[1], g.offsets + P + 3, g.fp, g.tmask_hi, rec, g.fp_sorted, b.cnt, run_if);
+        hipLaunchKernelGGL(cell_count_kernel, dim3((unsigned)pg.nblk), dim3(PLACE_THREADS), sizeof(uint32_t) * (size_t)pg.nc, s, pg, order, g.sort_val[1], g.offsets + P + 3, g.fp, g.tmask_hi, rec, g.fp_sorted, b.cnt);
         IBGS_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total, run_if);
+    hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total);
     IBGS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cell_setup_kernel, dim3(1), dim3(256), 0, s, ccap, b.cell_total, ncells, b.cell_start, b.cell_chunk0, counters + 2, run_if);
+    hipLaunchKernelGGL(cell_setup_kernel, dim3(1), dim3(256), 0, s, ccap, b.cell_total, ncells, b.cell_start, b.cell_chunk0, counters + 2);
     IBGS_HIP(hipGetLastError());
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
@@ -695,27 +691,27 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
         size_t lds = 36u * (size_t)pg.nc;
         if (check && order_hint && ntiles <= HINT_MAX_TILES) lds = max(lds, sizeof(uint32_t) * (size_t)((ntiles + 31) / 32));
         hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), lds, s, pg, ccap, order, g.sort_val[1], g.offsets + P + 3, g.fp_sorted, g.tmask_hi, rec,
-                           b.cnt, b.cell_start, b.cent, ntiles, order_hint, check ? meta : nullptr, run_if);
+                           b.cnt, b.cell_start, b.cent, ntiles, order_hint, check ? meta : nullptr);
         IBGS_HIP(hipGetLastError());
     }
     const unsigned nchunks_max = (unsigned)(ccap / XCHUNK + (size_t)ncells + 1);
-    hipLaunchKernelGGL(expand_count_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, b.cent, b.chunk_cnt, run_if);
+    hipLaunchKernelGGL(expand_count_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, b.cent, b.chunk_cnt);
     IBGS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total, run_if);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
-                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), sort_flag, host_note, run_if);
+                       (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), sort_flag, host_note, note_ticket);
     IBGS_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, const uint32_t* run_if)
+int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b)
 {
     if (cap <= 0) return 0;
     const int cgx = (gx + CB - 1) / CB, cgy = (gy + CB - 1) / CB, ncells = cgx * cgy;
     const unsigned nchunks_max = (unsigned)(b.ccap / XCHUNK + (size_t)ncells + 1);
     hipLaunchKernelGGL(expand_scatter_kernel, dim3(nchunks_max), dim3(64), 0, s, b.cell_start, b.cell_chunk0, ncells, cgx, gx, gy, b.cent,
-                       b.chunk_cnt, b.tile_total, (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), b.point_list, run_if);
+                       b.chunk_cnt, b.tile_total, (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), b.point_list);
     IBGS_HIP(hipGetLastError());
     return 0;
 }

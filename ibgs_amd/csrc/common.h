@@ -57,7 +57,6 @@ struct GeomState {
                            //      together; [P+3] = Gaussians with tiles (what the depth sort keeps); [P+4] = 1 when the depth order lies in sort_val[1]
     uint32_t* hist;        // radix histogram + scan scratch
     size_t hist_elems;
-    uint32_t* tile_partial2; // ceil(P / 64)   depth-bound hint in use: the tiles every wave's Gaussians would touch WITHOUT the bound (R of the unbounded lists: sizes the repair pass)
     static GeomState carve(char* base, size_t P, size_t* total);
 };
 
@@ -73,8 +72,6 @@ struct ImgState {
     uint32_t* slot_c;      // 8 x HW (geo) contributor number (1-based list position) of every median buffer slot, 0 = empty
     uint32_t* tile_walked; // tiles x 4   how far the forward walked every tile's list (largest n_contrib), per wave of the tile ([tile * waves + wave]) = the backward's work there
     uint32_t* tile_order;  // tiles rounded up to 1024   launch order of the colour backward: workgroup -> tile (render_bwd.hip, balanced placement)
-    uint32_t* tile_done;   // tiles x 4   per wave of the tile (layout of tile_walked): the 1-based list position at which its last pixel terminated, 0xFFFFFFFF if one was still
-                           //             open at the end of the list; meta[12] = 1: the depth bound was violated somewhere and the guarded repair pass ran, [13] = dirty tiles
     uint32_t* tile_risky;  // tiles x 4   per wave of the tile: non-zero when the forward staged a record whose conic is near-singular (conic_takes_ref_power) -- the backward walks such
                            //             tiles with its reference-arithmetic kernels (render_bwd.hip)
     static ImgState carve(char* base, int W, int H, size_t* total);
@@ -336,10 +333,9 @@ __device__ __forceinline__ PlaneEval plane_eval(int mode, const float* __restric
 //   RR     item = workgroup id: neighbouring items on different XCDs (best balance, every output line split over two L2s)
 //   GROUP  runs of `g` consecutive items per XCD: with g x (waves per tile) covering 2+ tiles, output lines are completed in one L2
 //   BLOCK  bx x by tile blocks per XCD (2-D locality for the gathers)
-// IBGS_TILE_MAP_{FWD,BWD,FWD_GEO,BWD_GEO} = "rr" | "g<N>" | "b<X>x<Y>" override the defaults (experiments: tools/sweep_tile_map.sh).
+// (Round 6: the layouts are fixed in the launchers -- 8 x 8 blocks, 8 x 4 for the geo backward; the environment overrides of rounds 3-5 are gone with their sweeps.)
 enum { TMAP_RR = 0, TMAP_GROUP = 1, TMAP_BLOCK = 2 };
 struct TileMap { int mode, g, bx, by; };
-TileMap tile_map_from_env(const char* name, TileMap dflt);
 inline int tile_map_grid(const TileMap& m, int gx, int gy, int ipt)
 {
     if (m.mode == TMAP_BLOCK) {
@@ -403,13 +399,11 @@ constexpr int HYBRID_THETA = 50;
 // Frames of fewer than HYBRID_MIN_TILES tiles: a SIMD's fair share is less than a tile, nearly every tile would be split -- plain quadrant waves, without the
 // order kernel in front (400 x 400 / 10 k Gaussians, BASELINE's C1: backward 0.29 -> 0.20 ms).
 constexpr int HYBRID_MIN_TILES = 768;
-// colour passes of frames with fewer tiles than this use the hybrid kernels (the env: experiments)
-inline int hybrid_max_tiles() { static const int v = getenv("IBGS_HYBRID_MAX_TILES") ? atoi(getenv("IBGS_HYBRID_MAX_TILES")) : 4096; return v; }
-inline int hybrid_theta() { static const int v = getenv("IBGS_HYBRID_THETA") ? atoi(getenv("IBGS_HYBRID_THETA")) : HYBRID_THETA; return v > 0 ? v : HYBRID_THETA; }      // (the env: experiments)
+// colour passes of frames with fewer tiles than this use the hybrid kernels
+constexpr int hybrid_max_tiles() { return 4096; }
+constexpr int hybrid_theta() { return HYBRID_THETA; }
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0, const float* bound = nullptr /* depth-bound hint (split colour pass only) */,
-                      const uint32_t* run_if = nullptr /* guard of the repair pass */);
-bool preprocess_is_split(const ibgs_forward_args& a);          // geometry and SH colours in two kernels (the only path that takes a depth-bound hint)
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0);
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
 
 // device-wide primitives (scan_sort.hip)
@@ -417,8 +411,7 @@ size_t radix_hist_elems(size_t n);      // scratch (uint32 elements) needed by r
 // Stable LSD radix sort of (key,val) pairs on key bits [0, nbits). Result lands in keys[0]/vals[0].
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits,
                      uint32_t* hist, size_t hist_elems, uint32_t* err_dev = nullptr, uint32_t* kept_dev = nullptr, bool scratch_is_zero = false,
-                     uint32_t* result_alt = nullptr, const uint32_t* run_if = nullptr /* guard of a repair pass: every kernel leaves at once when *run_if == 0 */);
-bool radix_uses_onesweep(size_t n, int nbits);      // the single-launch passes -- the only ones that can run guarded -- would be taken
+                     uint32_t* result_alt = nullptr);
 // result_alt: device word (zeroed by the caller).  When given (32-bit keys, single-launch passes), a LAST pass in which every key carries the same digit --
 //          the top byte of depths within [2, 8), say -- moves nothing and sets *result_alt = 1: the result is then in keys[1] / vals[1] (else, as always, in [0])
 size_t radix_zero_elems(size_t n, int nbits);      // leading words of `hist` the sort needs zeroed (see scratch_is_zero)
@@ -433,6 +426,7 @@ int exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, size_t 
                        size_t scratch_elems, bool with_total);
 size_t scan_scratch_elems(size_t n);
 void radix_set_onesweep(bool on);       // default on; off = hist + scan + scatter launches per pass
+void radix_set_lookback_spins(uint32_t v);      // tests: how often a look-back sleeps on an unpublished word before its pass gives up (default 2^26)
 
 // per-tile lists + tile ranges from the depth-ordered Gaussians (two-level binning, binning.hip); `cap` = capacity of point_list
 // part 1 (ranges + counters; returns the sort buffer index >= 0, or an error < 0) and part 2 (the lists themselves)
@@ -440,18 +434,16 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
                    const uint32_t* order_hint = nullptr, uint32_t* meta = nullptr /* meta[11] = 1 when the hint is a valid tile order */,
                    int n_views = 1 /* batched depth views: P = n_views x instances, gy = n_views x rows */,
                    const uint32_t* sort_flag = nullptr, uint32_t* host_note = nullptr /* pinned host words the last kernel leaves R, C and the sort's error word in */,
-                   const uint32_t* run_if = nullptr /* guard of the repair pass */);
+                   uint32_t note_ticket = 0 /* ... and then, behind a system-scope fence, this ticket (host_note[4]): the forward's binning has run */);
 constexpr int ORDER_CLASSES = 1024;          // SIMDs of the chip = classes of the balanced launch order (render_bwd.hip)
-int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b, const uint32_t* run_if = nullptr);
+int launch_binning_scatter(hipStream_t s, int64_t cap, int gx, int gy, const BinState& b);
 
 int launch_pack_rgba(hipStream_t s, const float* src, float4* dst, int W, int H, int n);
 // geo backward: per-pixel table of the median / warp terms of every buffered contributor (render_bwd.hip), 6 words per slot
 constexpr int GEO_TAB_FIELDS = 6;
 inline size_t geo_table_floats(int W, int H) { return (size_t)W * H * IBGS_MAX_BUFFER_LENGTH * GEO_TAB_FIELDS; }
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
-                          const ImgState& im, const float4* src_rgba, const uint32_t* run_if = nullptr /* guard of the repair pass */);
-int launch_bound_verify(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound);      // depth-bound hint: meta[12] = 1 when it was violated
-int launch_bound_update(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound_in, float* bound_out);      // ... the bound for the camera's next forward
+                          const ImgState& im, const float4* src_rgba);
 int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g, const BinState& b,
                            const ImgState& im, const float4* src_rgba, float* slab = nullptr, float* geo_tab = nullptr);
 int launch_preprocess_backward(hipStream_t s, const ibgs_backward_args& a, const GeomState& g);

@@ -40,9 +40,6 @@ struct PreParams {
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
     uint32_t* zero_a; uint32_t zero_a_n; uint32_t* zero_b; uint32_t zero_b_n;      // words the next stages want zeroed (the depth sort's scratch, its counters)
-    const float* bound;           // depth-bound hint: per tile, the depth behind which the previous forward of this camera walked nothing (+inf: no bound), or nullptr
-    uint32_t* tile_partial2;      // ... then: the tiles every wave's Gaussians touch BEFORE the bound is applied (R of the unbounded lists)
-    const uint32_t* run_if;       // guard of the repair pass: the kernel leaves at once when *run_if == 0 (nullptr: always runs)
     uint32_t* tile_partial; int partial0; int partial_err;      // tiles touched per wave: this launch's first word; the word that follows ALL waves' words (the depth sort's error flag, zeroed here)
 };
 
@@ -117,10 +114,9 @@ constexpr int CULL_COOP_ROWS = 16;          // rectangles taller than this are w
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
 // WITH_SH = false: the SH -> RGB evaluation is left to sh_color_kernel below (the launcher's default when SH coefficients are given):
 // without the 48 coefficients and 16 basis values live next to the cull state this kernel needs far fewer registers.
-template <bool WITH_SH, bool BOUND = false>          // BOUND: a depth-bound hint is applied (its own instantiation: the plain kernel's code stays what it was)
+template <bool WITH_SH>
 __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam)
 {
-    if (p.run_if && *p.run_if == 0u) return;          // (wave-uniform scalar load; nullptr on every ordinary pass)
     __shared__ float4 s_stage_all[4][64 * 5];                 // 64 records at a stride of 5 quads (conflict-free 16-byte LDS accesses)
     float4* s_stage = s_stage_all[threadIdx.x >> 6];          // private to the wave: LDS operations of one wave execute in order, no barrier needed
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,26 +369,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
         }
     }
 
-    if constexpr (BOUND) {
-        // Depth-bound hint (round 5): bound[t] = the depth behind which this camera's previous forward walked nothing in tile t -- all of the tile's pixels
-        // had finished -- or +inf.  A Gaussian that lies behind the bound of EVERY tile of its rectangle (rectangles of up to 16 tiles; larger ones are kept)
-        // is reached by no walk if the tiles saturate where they did before: it takes no part in the depth sort, the binning and the SH pass.  Its radius is
-        // reported as always.  Whether the assumption held is checked after the blend (bound_verify_kernel); if not, the guarded repair pass redoes the
-        // frame without a bound.  The tiles it WOULD have touched are summed on the side: R of the unbounded lists, which the arena must be able to hold.
-        uint32_t tfull = valid ? ntiles : 0u;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) tfull += (uint32_t)__shfl_xor((int)tfull, d, 64);
-        if ((threadIdx.x & 63) == 0) p.tile_partial2[p.partial0 + (gi >> 6)] = tfull;
-        if (valid && alive && ntiles > 0) {
-            const int bx0 = (int)(rx & 0xFFFFu), bx1 = (int)(rx >> 16), by0 = (int)(ry & 0xFFFFu) - p.tile_row0, by1 = (int)(ry >> 16) - p.tile_row0;
-            if ((bx1 - bx0) * (by1 - by0) <= 16) {
-                float mb = 0.f;
-                for (int ty = by0; ty < by1; ty++)
-                    for (int tx = bx0; tx < bx1; tx++) mb = fmaxf(mb, p.bound[ty * cam.gx + tx]);
-                if (depth > mb) ntiles = 0u;
-            }
-        }
-    }
     if (p.alive64) {          // (a full-wave ballot: lanes past the end are still here)
         const uint64_t am = __ballot(valid && alive && ntiles > 0);
         if ((threadIdx.x & 63) == 0) p.alive64[gi >> 6] = am;
@@ -442,7 +418,6 @@ constexpr int SHC_ROW = 52;          // LDS words per row: 48 coefficients + 4 w
 template <bool SPLIT>          // SPLIT: DC and rest coefficients in two arrays (ibgs_forward_args.shs_rest) -- its own instantiation, so that the combined layout's code stays what it was
 __global__ void __launch_bounds__(256) sh_color_kernel(PreParams p, Cam cam)
 {
-    if (p.run_if && *p.run_if == 0u) return;
     __shared__ float s_sh_all[4][32 * SHC_ROW];
     float* s_sh = s_sh_all[threadIdx.x >> 6];          // private to the wave (LDS operations of one wave execute in order)
     const int lane = threadIdx.x & 63;
@@ -585,13 +560,12 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* m
     present[i] = z > 0.2f ? 1 : 0;
 }
 
-bool preprocess_is_split(const ibgs_forward_args& a)
+static bool preprocess_is_split(const ibgs_forward_args& a)          // geometry and SH colours in two kernels
 {
-    static const bool split_env = !(getenv("IBGS_PREPROCESS_SPLIT") && atoi(getenv("IBGS_PREPROCESS_SPLIT")) == 0);
-    return split_env && a.shs && !a.colors_precomp && !a.render_depth_only;
+    return a.shs && !a.colors_precomp && !a.render_depth_only;
 }
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase, const float* bound, const uint32_t* run_if)
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase)
 {   // phase 0: everything; 1: the geometry kernel(s) alone -- after them the tiles-touched sums are final; 2: what phase 1 left out (the SH colours)
     PreParams p;
     p.P = a.P; p.D = a.D; p.M = a.M;
@@ -601,7 +575,6 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
     p.scale_modifier = a.scale_modifier; p.depth_only = a.render_depth_only;
     p.radii = a.radii; p.rec = g.rec; p.depths = g.depths; p.cov3D = g.cov3D; p.tiles = g.tiles; p.fp = g.fp; p.tmask_hi = g.tmask_hi;
     p.clamped = g.clamped; p.sort_key = g.sort_key[0]; p.sort_val = g.sort_val[0];
-    p.bound = bound; p.tile_partial2 = g.tile_partial2; p.run_if = run_if;
     // depth-only with a 1-slot buffer depends on list positions (the per-round 'break' of forward.cu:484-488)
     p.cull = !(a.flags & IBGS_FLAG_NO_TILE_CULL) && !(a.render_depth_only && a.buffer_length == 1);
     const int blocks = (a.P + 255) / 256;
@@ -615,25 +588,19 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         const Cam cam = make_cam(a.viewmatrix + 16 * v, a.projmatrix + 16 * v, a.campos + 3 * v, a.bg,
                                  nv > 1 ? a.view_tanfovx[v] : a.tanfovx, nv > 1 ? a.view_tanfovy[v] : a.tanfovy, a.W, a.H);
         // SH coefficients: geometry first (few registers, every Gaussian), then the colours of the Gaussians that reach a tile
-        // (coalesced row loads); IBGS_PREPROCESS_SPLIT=0 keeps the one-kernel form for comparisons
+        // (coalesced row loads)
         const bool split = preprocess_is_split(a);
         p.alive64 = split ? g.alive64 : nullptr;
         // no SH evaluation at all (depth-only passes, precomputed colours): the geometry kernel alone -- the one-kernel form carries the SH path's
         // registers (120 VGPRs, 4 waves per SIMD against 65 / 7) whether it runs or not: 73 -> ~50 us per source view of a test-time frame
         const bool no_sh = a.render_depth_only || a.colors_precomp || !a.shs;
         if (split) {
-            if (phase != 2) {
-                if (bound) hipLaunchKernelGGL((preprocess_kernel<false, true>), dim3(blocks), dim3(256), 0, s, p, cam);
-                else hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
-            }
+            if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
             if (phase != 1) {
                 if (p.shs_rest) hipLaunchKernelGGL(sh_color_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
                 else hipLaunchKernelGGL(sh_color_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
             }
-        } else if (phase != 2) {
-            if (no_sh) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
-            else hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, s, p, cam);
-        }
+        } else if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);          // (no_sh: nothing else can get here)
     }
     IBGS_HIP(hipGetLastError());
     return 0;

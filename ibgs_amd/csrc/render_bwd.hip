@@ -1025,9 +1025,7 @@ int launch_render_backward(hipStream_t s, const ibgs_backward_args& a, const Geo
     p.tab_slots = (a.buffer_length >= 1 && a.buffer_length < IBGS_MAX_BUFFER_LENGTH) ? a.buffer_length + 1 : IBGS_MAX_BUFFER_LENGTH;          // as ibgs_required_geo_table_for sizes it
     const int nt = p.ntiles;
     // as the forward (render_fwd.hip): blocks of tiles per XCD; geo 8 x 4 (fetch traffic 0.73 -> 0.35 GB, clustered image 1.92 -> 1.83 ms)
-    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_BWD", TileMap{TMAP_BLOCK, 1, 8, 8});
-    static const TileMap map_geo = tile_map_from_env("IBGS_TILE_MAP_BWD_GEO", TileMap{TMAP_BLOCK, 1, 8, 4});
-    p.tmap = a.render_geo ? map_geo : map_color;
+    p.tmap = a.render_geo ? TileMap{TMAP_BLOCK, 1, 8, 4} : TileMap{TMAP_BLOCK, 1, 8, 8};
     auto grid = [&](int ipt) { return dim3((unsigned)tile_map_grid(p.tmap, p.cam.gx, p.cam.gy, ipt)); };
     // the flagged tiles' kernel, launched behind whichever blend kernel ran: over the slots of its launch order, or over the tiles (no flag set: every wave leaves at once)
     auto launch_risk = [&](int nslots_or_0) {

@@ -42,9 +42,6 @@ struct FwdParams {
     uint32_t* risky;          // ImgState::tile_risky (4 words per tile): this wave staged a record whose conic is near-singular
     int hybrid_grid1;    // ... its first hybrid_grid1 workgroups are the tiles' first waves (hybrid_item, common.h)
     int hybrid;          // 1: render_fwd_color_hybrid_kernel
-    const uint32_t* run_if;   // guard of the repair pass (api.hip): the kernel leaves at once when *run_if == 0; nullptr on every ordinary pass
-    uint32_t* done;           // per (tile, wave of the tile), layout of `walked`: the list position (end of the staging round) by which the wave's last pixel had terminated, 0xFFFFFFFF if one was still open at the end of the list (depth-bound verification)
-    int split_epilogue;  // geo: the blend kernel only parks its median buffer (slot_c, and the weights in the first L planes of out_cam_feat); geo_epilogue_kernel does the rest
     const uint32_t* order;      // the caller's launch order hint (colour, one wave per tile), checked by an extra workgroup of cell_place_kernel: meta[11]; nullptr: the tile map
     // outputs
     float* out_color; float* out_normal; float* out_depth; float* out_cam_feat; float* out_warped;
@@ -397,21 +394,13 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
         for (int q = 0; q < PPL; q++) m = max(m, inside[q] ? lastc[q] : 0u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
-        // ... and whether every pixel of this wave had finished by then (no pixel left that a Gaussian further back could still reach): what the check of a
-        // depth-bound hint needs (bound_verify_kernel)
-        uint64_t left = 0ull;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) left |= live[q];
-        // the end of the round in which the last pixel terminated (at an entry that is NOT blended: it lies behind the last contributor, within that
-        // round), or "a pixel was still open": the loop is only ever left early through its all-finished exit, with `base` still on that round
-        const uint32_t fin = left == 0ull ? (uint32_t)min(n, base + CHUNK) : 0xFFFFFFFFu;
         if (p.hybrid) {
             // hybrid colour kernel: four words per tile whichever shape walked it (a tile wave leaves the other three at zero)
-            if (IPT == 1) { if (lane < 4) { p.walked[(size_t)tile * 4 + lane] = lane == 0 ? m : 0u; p.done[(size_t)tile * 4 + lane] = lane == 0 ? fin : 0u; } }
-            else if (lane == 0) { p.walked[(size_t)tile * 4 + sub] = m; p.done[(size_t)tile * 4 + sub] = fin; }
+            if (IPT == 1) { if (lane < 4) p.walked[(size_t)tile * 4 + lane] = lane == 0 ? m : 0u; }
+            else if (lane == 0) p.walked[(size_t)tile * 4 + sub] = m;
             if (lane == 0 && tile == 0 && sub == 0) p.meta[10] = 4u;
         }
-        else if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; p.done[(size_t)tile * IPT + sub] = fin; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
+        else if (lane == 0) { p.walked[(size_t)tile * IPT + sub] = m; if (tile == 0 && sub == 0) p.meta[10] = (uint32_t)IPT; }          // (workgroup 0 may hold no tile under a launch order hint)
         // four flag words per tile whatever the variant (wave `sub` of IPT writes words sub, sub + IPT, ...): non-zero = this wave staged a near-singular conic, i.e. the
         // backward may meet one here (it walks no further than the forward did)
         if (!DEPTH && p.risky && lane < PPL) p.risky[(size_t)tile * 4 + sub + lane * IPT] = riskany != 0ull ? 1u : 0u;
@@ -429,23 +418,6 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
             const int pxq = tx0 + (qq & 1) * 8 + (lane & 7), pyq = ty0 + (qq >> 1) * 8 + (lane >> 3);
             if (!(pxq < W && pyq < H)) continue;
             const size_t pix = vbase + (size_t)pyq * W + pxq;
-            if (p.split_epilogue) {
-                // the per-pixel epilogue runs as its own pixel-parallel kernel (geo_epilogue_kernel below): this wave only parks the pixel's median
-                // buffer -- contributor numbers where the backward's window pass expects them anyway, weights in the first L planes of out_cam_feat,
-                // which that kernel reads before it writes the planes' final content (same thread, same pixel)
-#pragma unroll 1
-                for (int s = 0; s < L; s++) {
-                    float w = 0.f; uint32_t c = 0;
-                    if (RING_LDS) { w = s_bw[q][s][lane]; c = s_bc[q][s][lane]; }
-                    else {
-#pragma unroll
-                        for (int k = 0; k < (RING_LDS ? 1 : MAXL); k++) if (k == s) { w = bw[q][k]; c = bc[q][k]; }
-                    }
-                    p.slot_c[(size_t)s * HW + pix] = (w == 0.0f) ? 0u : c;
-                    p.out_cam_feat[(size_t)s * HW + pix] = w;
-                }
-                continue;
-            }
             const float pxfq = (float)pxq, pyfq = (float)pyq;
             const float rayxq = (pxfq - cx) / fx, rayyq = (pyfq - cy) / fy;          // as before the blend loop: the same two divisions
             const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
@@ -574,7 +546,6 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
 template <int MODE, int PPL, int MAXL>
 __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 : 1) render_fwd_kernel(FwdParams p)
 {
-    if (p.run_if && *p.run_if == 0u) return;
     __shared__ float4 s_rec[(MODE == MODE_GEO) ? 4 : 3][(MODE == MODE_GEO) ? 16 : WAVE];
     constexpr int IPT = 4 / PPL;
     int tile, sub;
@@ -600,7 +571,6 @@ __global__ void __launch_bounds__(64, (MODE == 2 && PPL == 4 && MAXL == 4) ? 5 :
 // operations, TILE_Q above): the hint that may steer the choice stays a pure performance matter.
 __global__ void __launch_bounds__(64, 8) render_fwd_color_hybrid_kernel(FwdParams p)
 {
-    if (p.run_if && *p.run_if == 0u) return;
     __shared__ float4 s_rec[3][WAVE];
     int tile, sub; bool split;
     if (p.order && p.meta[11] == 1u) {
@@ -629,210 +599,10 @@ __global__ void __launch_bounds__(64, 8) render_fwd_color_hybrid_kernel(FwdParam
     else if (sub == 0) render_fwd_body<MODE_COLOR, 4, 4>(p, tile, 0, s_rec);
 }
 
-// ---- geo epilogue as its own kernel (round 5) -----------------------------------------------------------------------------------------------
-// forward.cu:507-663 per pixel: median depth from the buffered contributors, the world point and camera ray, source by source the depth
-// consistency test and -- for the valid ones -- the warp of the buffered points into the source image; 228 B of output per pixel.  Inside the blend
-// kernel it ran quadrant after quadrant on waves shaped for the blend loop (two per tile, the register budget and LDS ring of that loop): 0.19 ms of
-// the 0.70 ms kernel at C3-geo, two thirds of it the 35 plane stores issued 64 pixels at a time between gathers (profiles/r04_probe_plane_stores.txt:
-// the stores alone need 62 us).  Here: one thread per pixel, one workgroup per 16 x 16 tile (same 8 x 8-tile blocks over the XCDs as the blend
-// kernel, for the source texels' L2 locality), nothing live but the pixel's own L slots.  The arithmetic is the fused epilogue's, operation by
-// operation and in its order (no contraction: it takes decisions on what it computes), so every output is bit-identical to it.
-// MEASURED (round 5, A/B on one box, 30 steps each, twice): C3-geo render forward 0.716 -> 0.844 ms, trained scene 0.367 -> 0.392 ms -- the separate
-// kernel LOSES 0.13 / 0.025 ms: inside the blend kernel the epilogue's dependent gathers (record -> depth -> source depth -> texels) overlap with the
-// blend loops of the other waves on the SIMD; alone, every wave of the kernel is in the same latency-bound phase.  Kept behind IBGS_FLAG_SPLIT_GEO_EPILOGUE
-// (default off) with its parity tests.
-template <int MAXL>
-__global__ void __launch_bounds__(256) geo_epilogue_kernel(FwdParams p)
-{
-#pragma clang fp contract(off)
-    if (p.run_if && *p.run_if == 0u) return;
-    int tile, sub;
-    if (!tile_map_item(p.tmap, blockIdx.x, p.cam.gx, p.cam.gy, 1, tile, sub)) return;
-    const int W = p.cam.W, H = p.cam.H;
-    const int tx0 = (tile % p.cam.gx) * TILE, ty0 = (tile / p.cam.gx) * TILE;
-    // lane -> pixel as in the blend kernel's quadrants (8 x 8 blocks of pixels per wave: a wave's gathers stay within a small window of the source image)
-    const int lane = threadIdx.x & 63, qq = threadIdx.x >> 6;
-    const int pxq = tx0 + (qq & 1) * 8 + (lane & 7), pyq = ty0 + (qq >> 1) * 8 + (lane >> 3);
-    if (!(pxq < W && pyq < H)) return;
-    const size_t HW = (size_t)W * H;
-    const size_t pix = (size_t)pyq * W + pxq;
-    const int L = p.L;
-    const float fx = p.cam.fx, fy = p.cam.fy;
-    const float cx = (float)(W * 0.5f), cy = (float)(H * 0.5f);
-    const float eps = 1.0e-8f;
-    const uint32_t r0 = p.ranges[2 * tile];
-    float bw[MAXL]; uint32_t bc[MAXL]; float dv[MAXL];
-#pragma unroll
-    for (int s = 0; s < MAXL; s++) {
-        bw[s] = 0.f; bc[s] = 0u; dv[s] = 0.f;
-        if (s < L) { bw[s] = p.out_cam_feat[(size_t)s * HW + pix]; bc[s] = p.slot_c[(size_t)s * HW + pix]; }
-    }
-    const float pxfq = (float)pxq, pyfq = (float)pyq;
-    const float rayxq = (pxfq - cx) / fx, rayyq = (pyfq - cy) / fy;
-    const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
-    const float pdx = pxfq - cx, pdy = pyfq - cy;
-    float tw = 0.f, med = 0.f;
-    uint32_t lo = bc[0], hi = lo;     // Q4: slot 0 even when empty
-#pragma unroll
-    for (int s = 0; s < MAXL; s++) {
-        if (s < L && bw[s] != 0.0f) {
-            const uint32_t gid = p.point_list[r0 + bc[s] - 1u];
-            const float4 g1 = p.rec[(size_t)gid * 4 + 1], g3 = p.rec[(size_t)gid * 4 + 3];
-            const float d = -g1.w / (g3.x * rayxq + g3.y * rayyq + g3.z + eps);
-            dv[s] = d;
-            tw += bw[s]; med += bw[s] * d;
-            lo = min(lo, bc[s]); hi = max(hi, bc[s]);
-        }
-    }
-    p.low_high[2 * pix] = lo; p.low_high[2 * pix + 1] = hi; p.sum_w[pix] = tw;
-    med /= (tw + eps);
-    const float mX = pdx * med * inv_fx, mY = pdy * med * inv_fy, mZ = med;
-    const float* vm = p.cam.vm;
-    const float qx = mX - vm[12], qy = mY - vm[13], qz = mZ - vm[14];
-    const float wx = vm[0] * qx + vm[1] * qy + vm[2] * qz;
-    const float wy = vm[4] * qx + vm[5] * qy + vm[6] * qz;
-    const float wz = vm[8] * qx + vm[9] * qy + vm[10] * qz;
-    float rd0 = wx - p.cam.campos[0], rd1 = wy - p.cam.campos[1], rd2 = wz - p.cam.campos[2];
-    const float rl = sqrtf(rd0 * rd0 + rd1 * rd1 + rd2 * rd2) + eps;
-    rd0 /= rl; rd1 /= rl; rd2 /= rl;
-    p.out_camera_ray[pix] = rd0; p.out_camera_ray[HW + pix] = rd1; p.out_camera_ray[2 * HW + pix] = rd2;
-
-    int nvalid = 0, first_ok = 0; float min_err = 1.0f;
-#pragma unroll 1
-    for (int si = 0; si < p.n_src; si++) {
-        if (nvalid >= IBGS_MAX_SRC) break;
-        const float* r = p.ref_to_src + 16 * si;
-        const float r0_ = r[0], r1_ = r[1], r2_ = r[2], r3_ = r[3], r4_ = r[4], r5_ = r[5], r6_ = r[6], r7_ = r[7], r8_ = r[8], r9_ = r[9], r10_ = r[10], r11_ = r[11];
-        float wdep = 0.0f, err, tzm, izm;
-        {
-            const float tx = r0_ * mX + r1_ * mY + r2_ * mZ + r3_ * 1.0f;
-            const float ty = r4_ * mX + r5_ * mY + r6_ * mZ + r7_ * 1.0f;
-            tzm = r8_ * mX + r9_ * mY + r10_ * mZ + r11_ * 1.0f;
-            izm = 1.0f / (tzm + eps);
-            const float u = tx * fx * izm + cx, v = ty * fy * izm + cy;
-            if (u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1))
-                wdep = tex_depth(p.src_depths + (size_t)si * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
-            err = fabsf(wdep - tzm) * izm;
-        }
-        if (!(wdep > 0.0f && err < p.thr)) continue;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, tws = 0.f;
-        const float4* img = p.src_rgba + (size_t)si * HW;
-#pragma unroll
-        for (int s = 0; s < MAXL; s++) {
-            if (s < L) {
-                const float w = bw[s], d = dv[s];
-                const float X = pdx * d * inv_fx, Y = pdy * d * inv_fy, Z = d;
-                const float tx = r0_ * X + r1_ * Y + r2_ * Z + r3_ * 1.0f;
-                const float ty = r4_ * X + r5_ * Y + r6_ * Z + r7_ * 1.0f;
-                const float tz = r8_ * X + r9_ * Y + r10_ * Z + r11_ * 1.0f;
-                const float iz = 1.0f / (tz + eps);
-                const float u = tx * fx * iz + cx, v = ty * fy * iz + cy;
-                if (w != 0.0f && u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1)) {
-                    const float4 col = tex_rgba(img, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
-                    c0 += w * col.x; c1 += w * col.y; c2 += w * col.z; tws += w;
-                }
-            }
-        }
-        const float iw = 1.0f / (tws + eps);
-        const float* sp = p.src_cam_pos + 3 * si;
-        p.out_cam_feat[((size_t)nvalid * 4 + 0) * HW + pix] = p.cam.campos[0] - sp[0];
-        p.out_cam_feat[((size_t)nvalid * 4 + 1) * HW + pix] = p.cam.campos[1] - sp[1];
-        p.out_cam_feat[((size_t)nvalid * 4 + 2) * HW + pix] = p.cam.campos[2] - sp[2];
-        p.out_warped[((size_t)nvalid * 3 + 0) * HW + pix] = c0 * iw;
-        p.out_warped[((size_t)nvalid * 3 + 1) * HW + pix] = c1 * iw;
-        p.out_warped[((size_t)nvalid * 3 + 2) * HW + pix] = c2 * iw;
-        float s0 = wx - sp[0], s1 = wy - sp[1], s2 = wz - sp[2];
-        const float sl = sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + eps;
-        s0 /= sl; s1 /= sl; s2 /= sl;
-        p.out_cam_feat[((size_t)nvalid * 4 + 3) * HW + pix] = s0 * rd0 + s1 * rd1 + s2 * rd2;
-        if (si == 0) first_ok = 1;
-        p.valid_idx[(size_t)nvalid * HW + pix] = si;
-        p.valid_w[(size_t)nvalid * HW + pix] = tws;
-        nvalid++;
-        min_err = fminf(min_err, err);
-    }
-    if (nvalid <= IBGS_MAX_SRC - 1) p.valid_idx[(size_t)nvalid * HW + pix] = -1;
-    for (int k = nvalid; k < IBGS_MAX_SRC; k++) {
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) p.out_cam_feat[((size_t)k * 4 + ch) * HW + pix] = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) p.out_warped[((size_t)k * 3 + ch) * HW + pix] = 0.f;
-    }
-    p.out_mask[pix] = first_ok;
-    p.out_min_depth_diff[pix] = min_err;
-    p.out_depth[pix] = med;
-}
-
-// ---- depth-bound hint: check and renewal (round 5) -----------------------------------------------------------------------------------------------
-// bound[t] = the depth behind which nothing of tile t was reached by this camera's previous forward, or +inf (preprocess.hip applies it).  After the
-// blend, tile t is FINE if no Gaussian the bound removed could have been reached there: bound[t] = +inf (then nothing that touches t was removed: a
-// Gaussian goes only if it lies behind the bound of every tile of its rectangle), or every pixel of the tile terminated (T < 1e-4, tile_done) at an
-// entry no deeper than bound[t]: whatever was removed from the list lies strictly behind that entry in the depth order, so the list the pixels saw up
-// to their termination is the unbounded one, entry for entry.  One tile that is not fine sets meta[12] = 1: the guarded
-// repair pass queued behind this kernel then redoes the frame without a bound; otherwise its kernels leave at once.
-__global__ void __launch_bounds__(256) bound_verify_kernel(int ntiles, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float* __restrict__ depths,
-                                                           const uint32_t* __restrict__ done, const float* __restrict__ bound, uint32_t* __restrict__ meta)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    bool bad = false;
-    if (t < ntiles) {
-        const float bt = bound[t];
-        if (!(bt == INFINITY)) {          // (anything else counts as a bound, NaN included: preprocess.hip's fmaxf skips a NaN, so the tile's neighbours' bounds applied)
-            const uint32_t ipt = meta[10];
-            uint32_t w = 0;          // by which list position the tile's last pixel had terminated, 0xFFFFFFFF: one never did
-            for (uint32_t k = 0; k < ipt; k++) w = max(w, done[(size_t)t * ipt + k]);
-            const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
-            if (w == 0u || w > r1 - r0) bad = true;          // (0: an empty list under a bound)
-            else if (!(depths[point_list[r0 + w - 1u]] <= bt)) bad = true;
-        }
-    }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
-    if (m != 0ull && (threadIdx.x & 63) == 0) { atomicOr(meta + 12, 1u); atomicAdd(meta + 13, (uint32_t)__builtin_popcountll(m)); }
-}
-
-// The bound for this camera's NEXT forward, from what this one walked (after the repair pass, if it ran): a tile whose pixels all finished gets the
-// depth of the entry BOUND_SLACK positions behind its last contributor, widened by BOUND_MARGIN -- room for the scene to move a little between two
-// visits of the camera; a tile with a pixel still open (or a list that ends within the slack) gets +inf.
-constexpr uint32_t BOUND_SLACK = 64;
-constexpr float BOUND_MARGIN = 1.02f;
-__global__ void __launch_bounds__(256) bound_update_kernel(int ntiles, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float* __restrict__ depths,
-                                                           const uint32_t* __restrict__ done, const uint32_t* __restrict__ meta, const float* __restrict__ bound_in, float* __restrict__ bound_out)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ntiles) return;
-    const uint32_t ipt = meta[10];
-    uint32_t w = 0;
-    for (uint32_t k = 0; k < ipt; k++) w = max(w, done[(size_t)t * ipt + k]);
-    const uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
-    float b = INFINITY;
-    if (w != 0xFFFFFFFFu && w > 0u) {
-        if (w + BOUND_SLACK < r1 - r0) b = depths[point_list[r0 + w + BOUND_SLACK - 1u]] * BOUND_MARGIN;
-        // a list that the bound in force cut short behind the terminator: that bound served, keep it (else the tile would go back and forth between
-        // a bounded and an unbounded frame)
-        else if (bound_in && meta[12] == 0u) b = bound_in[t];
-    }
-    bound_out[t] = b;
-}
-
-int launch_bound_verify(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound)
-{
-    hipLaunchKernelGGL(bound_verify_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, ntiles, im.ranges, b.point_list, g.depths, im.tile_done, bound, im.meta);
-    IBGS_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_bound_update(hipStream_t s, int ntiles, const GeomState& g, const BinState& b, const ImgState& im, const float* bound_in, float* bound_out)
-{
-    hipLaunchKernelGGL(bound_update_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, ntiles, im.ranges, b.point_list, g.depths, im.tile_done, im.meta, bound_in, bound_out);
-    IBGS_HIP(hipGetLastError());
-    return 0;
-}
-
 int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, const BinState& b,
-                          const ImgState& im, const float4* src_rgba, const uint32_t* run_if)
+                          const ImgState& im, const float4* src_rgba)
 {
     FwdParams p;
-    p.run_if = run_if; p.done = im.tile_done;
     p.ranges = im.ranges; p.point_list = b.point_list; p.rec = reinterpret_cast<const float4*>(g.rec);
     p.cam = make_cam(a.viewmatrix, a.projmatrix, a.campos, a.bg, a.tanfovx, a.tanfovy, a.W, a.H);
     p.ntiles = p.cam.gx * p.cam.gy;
@@ -846,9 +616,6 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.out_warped = a.out_warped; p.out_min_depth_diff = a.out_min_depth_diff; p.out_camera_ray = a.out_camera_ray;
     p.out_mask = a.out_mask;
     p.hybrid = 0;
-    // geo, experiment: the per-pixel epilogue as its own kernel (IBGS_FLAG_SPLIT_GEO_EPILOGUE; measured slower, see geo_epilogue_kernel).  The parked weights
-    // use the first buffer_length planes of out_cam_feat (20 planes: any buffer_length fits)
-    p.split_epilogue = (a.render_geo && (a.flags & IBGS_FLAG_SPLIT_GEO_EPILOGUE)) ? 1 : 0;
     p.n_views = a.n_views > 1 ? a.n_views : 1; p.gyv = p.cam.gy;
     for (int v = 0; v < IBGS_MAX_VIEWS; v++) {
         p.fxv[v] = (v < p.n_views && p.n_views > 1) ? a.W / (2.0f * a.view_tanfovx[v]) : p.cam.fx;
@@ -860,9 +627,7 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     // measured (profiles/r03_tile_map.txt): the colour / depth kernels are VALU-bound on every layout and within +-1.5 % of each other;
     // 8 x 8-tile blocks are the fastest on the uniform scene and equal to round-robin on a clustered one.  The geo kernel's epilogue gathers from the packed source images: 8 x 8-tile blocks cut its L2 <-> fabric traffic
     // from 2.39 GB to 1.37 GB (= the algorithmic bytes) and its time by 3 %
-    static const TileMap map_color = tile_map_from_env("IBGS_TILE_MAP_FWD", TileMap{TMAP_BLOCK, 1, 8, 8});
-    static const TileMap map_geo = tile_map_from_env("IBGS_TILE_MAP_FWD_GEO", TileMap{TMAP_BLOCK, 1, 8, 8});
-    p.tmap = a.render_geo ? map_geo : map_color;
+    p.tmap = TileMap{TMAP_BLOCK, 1, 8, 8};          // colour and geo alike (docs/EXPERIMENTS.md section 7 keeps the sweep over the other layouts)
     auto grid = [&](int ipt) { return dim3((unsigned)tile_map_grid(p.tmap, gx, gyt, ipt)); };
     if (a.render_depth_only && !a.render_geo) {
         if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_DEPTH, 4, 4>), grid(1), dim3(64), 0, s, p);
@@ -877,11 +642,6 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
         else if (half && a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 2, 4>), grid(2), dim3(64), 0, s, p);
         else if (a.buffer_length <= 4) hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 4>), grid(4), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((render_fwd_kernel<MODE_GEO, 1, 8>), grid(4), dim3(64), 0, s, p);
-        if (p.split_epilogue) {
-            IBGS_HIP(hipGetLastError());
-            if (a.buffer_length <= 4) hipLaunchKernelGGL(geo_epilogue_kernel<4>, grid(1), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(geo_epilogue_kernel<8>, grid(1), dim3(256), 0, s, p);
-        }
     } else {
         // Small frames: one wave per 8x8 quadrant instead of per tile, otherwise the chip (1024 SIMDs x 8 waves) stays
         // mostly empty and every wave walks its list alone (800x800 has 2500 tiles).

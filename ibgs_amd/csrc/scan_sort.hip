@@ -295,10 +295,8 @@ constexpr int OS_THREADS = 512, OS_WAVES = OS_THREADS / 64, OS_ITEMS = RS_CHUNK 
 
 __global__ void __launch_bounds__(OS_HIST_THREADS) onesweep_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int npass, int dbits,
                                                                    uint32_t* __restrict__ ghist /* npass x 256 */,
-                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept,
-                                                                   const uint32_t* __restrict__ run_if /* guard of a repair pass (api.hip), or nullptr */)
+                                                                   int drop_max /* keys 0xFFFFFFFF take no part */, uint32_t* __restrict__ n_kept)
 {
-    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t h[OS_MAX_PASS][RS_MAX_BINS];
     __shared__ uint32_t s_kept;
     for (int k = threadIdx.x; k < OS_MAX_PASS * RS_MAX_BINS; k += OS_HIST_THREADS) (&h[0][0])[k] = 0;
@@ -331,9 +329,8 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
                                                                    int drop_here /* first pass of a sort that drops the 0xFFFFFFFF keys */,
                                                                    const uint32_t* __restrict__ n_kept /* items that take part (device) */,
                                                                    uint32_t* __restrict__ stays /* last pass only, or nullptr: a pass that would move nothing may leave its input where it is and say so */,
-                                                                   const uint32_t* __restrict__ run_if /* guard of a repair pass, or nullptr */)
+                                                                   uint32_t spin_limit /* look-back: sleeps on an unpublished word before the pass gives up (sets *err) */)
 {
-    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t wcnt[OS_WAVES][RS_MAX_BINS];
     __shared__ unsigned long long ptab[OS_WAVES][RS_MAX_BINS];      // match-any slots (wave_rank)
     __shared__ uint32_t dstart[RS_MAX_BINS];
@@ -397,6 +394,7 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
     uint32_t gtotal, ltotal;
     const uint32_t gstart = block_exclusive_scan_256(threadIdx.x < nbins ? ghist[threadIdx.x] : 0u, &gtotal, lds_wave);
     const uint32_t ds = block_exclusive_scan_256(tot, &ltotal, lds_wave);
+    if (spin_limit == 0u && bid == 0 && threadIdx.x == 0) *err = 1u;          // tests only (ibgs_debug_set_lookback_spins(0)): report a time-out that did not happen -- the sort itself is sound
     if (threadIdx.x < nbins) {
         uint32_t excl = 0;
         if (bid > 0) {
@@ -426,7 +424,7 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
                 }
                 b -= used;
                 if (!done && used < LOOKBACK) {                   // met an unpublished word
-                    if (++spins > (1u << 26)) { *err = 1u; break; }      // bounded: never hang the device
+                    if (++spins > (spin_limit ? spin_limit : (1u << 26))) { *err = 1u; break; }      // bounded: never hang the device (0: the tests' hook above, with the default patience here)
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
@@ -467,8 +465,13 @@ __global__ void __launch_bounds__(OS_THREADS) onesweep_pass_kernel(const uint32_
 // the first INCLUSIVE prefix appears.  So it is used where it wins -- sorts of at most OS_AUTO_MAX_CHUNKS chunks (the
 // launch-bound depth sort: 6 launches instead of 20) -- and the hist + scan + scatter passes everywhere else.
 // IBGS_RADIX_ONESWEEP=1 / =0 forces it on / off for experiments.
-static int g_use_onesweep = getenv("IBGS_RADIX_ONESWEEP") ? atoi(getenv("IBGS_RADIX_ONESWEEP")) : -1;   // -1 = by size
+static int g_use_onesweep = getenv("IBGS_RADIX_ONESWEEP") ? atoi(getenv("IBGS_RADIX_ONESWEEP")) : -1;   // -1 = by size (read once, when the library is loaded: tests/test_gpu_parity.py)
+// look-back patience of the single-launch passes.  2^26 sleeps = seconds: only a starved workgroup ever gets there.  ibgs_debug_set_lookback_spins (tests): 0 makes
+// every pass REPORT a time-out that did not happen (a real one cannot be staged: workgroups start in order, a predecessor has practically always published by the
+// time its successor looks) -- how tests/test_gpu_async_sort_error.py drives the asynchronous error path; the sort itself stays sound
+static uint32_t g_lookback_spins = 1u << 26;
 void radix_set_onesweep(bool on) { g_use_onesweep = on ? 1 : 0; }
+void radix_set_lookback_spins(uint32_t v) { g_lookback_spins = v; }
 constexpr size_t OS_AUTO_MAX_CHUNKS = 4096;          // (round 1: 512 -- with 256-thread chunks the look-back of ~3000 workgroups lost against hist + scan + scatter; with 512-thread chunks and
                                                      // eight predecessors per look-back round trip the single-launch passes win up to at least 5 M keys: 0.178 vs 0.296 ms)
 
@@ -479,8 +482,7 @@ static size_t onesweep_elems(size_t n)
 }
 
 static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int npass, int dbits,
-                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt,
-                                     const uint32_t* run_if)
+                                     uint32_t* scratch, size_t scratch_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt)
 {
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
     const int nbins = 1 << dbits;
@@ -492,19 +494,18 @@ static int radix_sort_pairs_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t*
     if (!scratch_is_zero) IBGS_HIP(hipMemsetAsync(scratch, 0, need * sizeof(uint32_t), s));
     const unsigned hb = (unsigned)((n + 8u * OS_HIST_THREADS - 1) / (8u * OS_HIST_THREADS));          // ~8 keys per thread (4 and 16 measured: 12.1 / 17.2 us against 12.2)
     const unsigned hblocks = hb < 256u ? (hb ? hb : 1u) : 256u;
-    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33, run_if);
+    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hblocks), dim3(OS_HIST_THREADS), 0, s, keys[0], n, npass, dbits, ghist, kept_dev ? 1 : 0, kept_dev ? kept_dev : tickets + 33);
     IBGS_HIP(hipGetLastError());
     int cur = 0;
     for (int pass = 0; pass < npass; pass++) {
         hipLaunchKernelGGL(onesweep_pass_kernel, dim3(nblocks), dim3(OS_THREADS), 0, s, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
                            n, pass * dbits, dbits, nbins, ghist + pass * RS_MAX_BINS, status + (size_t)pass * nblocks * RS_MAX_BINS,
                            tickets + pass, err_dev ? err_dev : tickets + 32, (kept_dev && pass == 0) ? 1 : 0, kept_dev ? kept_dev : tickets + 33,
-                           (result_alt && npass == 4 && pass == 3) ? result_alt : (uint32_t*)nullptr, run_if);
+                           (result_alt && npass == 4 && pass == 3) ? result_alt : (uint32_t*)nullptr, g_lookback_spins);
         IBGS_HIP(hipGetLastError());
         cur ^= 1;
     }
     if (cur != 0) {
-        if (run_if) { set_error("guarded radix sort: an odd number of passes would need an unguarded copy"); return -IBGS_ERR_INVALID; }
         IBGS_HIP(hipMemcpyAsync(keys[0], keys[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         IBGS_HIP(hipMemcpyAsync(vals[0], vals[1], n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     }
@@ -549,17 +550,8 @@ size_t radix_zero_elems(size_t n, int nbits_total)
     return (size_t)OS_MAX_PASS * RS_MAX_BINS + 64 + (size_t)npass * nblocks * RS_MAX_BINS;
 }
 
-bool radix_uses_onesweep(size_t n, int nbits_total)          // the single-launch passes (the only ones that can run guarded) would be taken for this sort
-{
-    if (n == 0 || nbits_total <= 0) return false;
-    const size_t nblocks = (n + RS_CHUNK - 1) / RS_CHUNK;
-    const int npass = (nbits_total + 7) / 8;
-    const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
-    return want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK;
-}
-
 int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t n, int nbits_total,
-                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt, const uint32_t* run_if)
+                     uint32_t* hist, size_t hist_elems, uint32_t* err_dev, uint32_t* kept_dev, bool scratch_is_zero, uint32_t* result_alt)
 {
     if (n == 0 || nbits_total <= 0) return 0;
     const unsigned nblocks = (unsigned)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -568,8 +560,7 @@ int radix_sort_pairs(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], size_t
     const int nbins = 1 << dbits;
     const bool want_os = g_use_onesweep >= 0 ? g_use_onesweep != 0 : nblocks <= OS_AUTO_MAX_CHUNKS;
     if (want_os && npass <= OS_MAX_PASS && n < (size_t)OS_VAL_MASK)
-        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero, result_alt, run_if);
-    if (run_if) { set_error("guarded radix sort: only the single-launch passes can run guarded"); return -IBGS_ERR_INVALID; }
+        return radix_sort_pairs_onesweep(s, keys, vals, n, npass, dbits, hist, hist_elems, err_dev, kept_dev, scratch_is_zero, result_alt);
     const size_t hist_n = (size_t)nbins * nblocks;
     if (hist_elems < hist_n + 1 + 64) { set_error("radix scratch too small"); return -IBGS_ERR_ALLOC; }
     uint32_t* scan_scratch = hist + hist_n + 1 + 63;

@@ -15,6 +15,7 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 HIP library.  If the library is missing the import of ``_lib`` raises -- there is no fallback.
 """
 import collections
+import weakref
 import ctypes
 import os
 import threading
@@ -56,15 +57,9 @@ NO_ABS_GRAD_WHEN_UNUSED = True
 WAVE_SHAPE = None
 
 
-# Experiment (round 5): the geo forward's per-pixel epilogue (median depth, source validity, warp) as its own pixel-parallel kernel behind the blend
-# kernel (IBGS_FLAG_SPLIT_GEO_EPILOGUE).  Bit-identical outputs (tests run both), but slower: inside the blend kernel the epilogue's gathers hide behind other
-# waves' blend loops, alone they do not (C3-geo forward 0.716 -> 0.844 ms).  Default off.
-SPLIT_GEO_EPILOGUE = os.environ.get("IBGS_SPLIT_GEO_EPILOGUE", "0") == "1"
-
-
 def _shape_flag():
     return ({None: 0, "tile": _lib.FLAG_TILE_WAVES, "quadrant": _lib.FLAG_QUADRANT_WAVES}[WAVE_SHAPE]
-            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP) | (_lib.FLAG_REF_ARITH if REF_ARITH else 0) | (_lib.FLAG_SPLIT_GEO_EPILOGUE if SPLIT_GEO_EPILOGUE else 0))
+            | (0 if REF_POWER_SKIP else _lib.FLAG_NO_REF_POWER_SKIP) | (_lib.FLAG_REF_ARITH if REF_ARITH else 0))
 
 
 # View-parallel training (ibgs_amd/dist.py): while a `capture_sh_factors()` block is active the backward leaves
@@ -128,17 +123,6 @@ ORDER_HINT = True
 ORDER_HINT_GEO = os.environ.get("IBGS_ORDER_HINT_GEO", "0") == "1"          # (the environment switch is for A/B runs: tools/ab_env.sh)
 ORDER_HINT_MAX = 512          # cameras remembered (32 KB each at 1080p); the least recently used one goes first
 _order_hints = collections.OrderedDict()
-
-# Depth-bound hints (include/ibgs_rast.h: ibgs_forward_args.depth_bound_hint / depth_bound_out): per camera, the depth per tile behind which its last forward
-# reached nothing.  The next forward of that camera drops the Gaussians behind it before the depth sort, the SH pass and the binning -- most of a trained
-# scene's visible Gaussians -- and a device-side check plus a guarded repair pass keep the result exact when the scene has moved past the bound (so a stale
-# or foreign buffer -- a recycled view-matrix address -- costs time, never correctness).  One buffer per camera, updated in place by every forward.
-# OFF by default: on MI355X the repair pass's ~20 empty launches (2-3 us of GPU time each, queued behind the blend whether or not they have work) cost
-# more than the shorter sort / SH pass / binning bring -- C3 1080p steps: init 1.745 -> 1.795 ms, trained opacities 0.805 -> 0.868 ms, trained geo
-# 1.796 -> 1.807 ms with 36 % / 26 % / 70 % of the depth sort's input gone (tools/depth_bound_ab.py, docs/EXPERIMENTS.md section 11).
-DEPTH_BOUND = os.environ.get("IBGS_DEPTH_BOUND", "0") == "1"          # (the environment switch is for A/B runs)
-DEPTH_BOUND_MAX = 512          # cameras remembered (32 KB each at 1080p)
-_bound_hints = collections.OrderedDict()
 
 
 def _camera_key(viewmatrix, device, W, H, geo, stream):
@@ -207,12 +191,30 @@ _tex_writes = [0]
 # whose pack is still held -- same object, same version counter (no in-place write since), same n / W / H -- the pack kernel is skipped
 # (IBGS_FLAG_TEX_PACKED).  Round 5: the packs are kept PER SOURCE STACK (least recently used first out, TEX_CACHE_BYTES in total per stream), not
 # only the last one: a trainer hops between cameras, each with its own stack (renderer.render keeps those per camera), and with one slot every
-# step packed again (40 us per geo forward at 1080p).  A slot keeps a reference to its tensor, so that memory cannot be recycled for another
-# image stack behind the cache's back; a fresh `torch.stack(...)` per call is a different object and packs again (into the shared scratch slot).
-# TEX_CACHE = False: always pack.
+# step packed again (40 us per geo forward at 1080p).  A slot remembers its tensor by WEAK reference (round 6: a strong one kept discarded scenes alive): a stack
+# that has been freed -- and whose id() a new tensor may have inherited -- no longer matches.  A stack marked `_ibgs_transient` (renderer.render: sources drawn with
+# random.sample, a fresh stack per call that would never hit) packs into the shared scratch slot instead of filling the pool with dead entries.
+# TEX_CACHE = False: always pack.  TEX_CACHE_BYTES = None: min(16 GiB, 5 % of the device memory that is free at first use) per stream; clear_caches() drops everything.
 TEX_CACHE = True
-TEX_CACHE_BYTES = 16 << 30
+TEX_CACHE_BYTES = None
 _tex_pool = {}          # stream key -> OrderedDict[slot -> buffer]; slot = ("src", id(source tensor)) or "scratch"
+
+
+def _cache_cap(device, configured, ceiling, fraction):
+    """A cache's byte cap: the configured number, or -- None -- a fraction of what the device has free right now, under a ceiling (decided once per device)."""
+    if configured is not None:
+        return int(configured)
+    if device.type != "cuda":          # (the glue's CPU tests: nothing to ask)
+        return int(ceiling)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), ceiling, fraction)
+    cap = _cache_caps.get(key)
+    if cap is None:
+        free, _total = torch.cuda.mem_get_info(device)
+        cap = _cache_caps[key] = int(min(ceiling, fraction * free))
+    return cap
+
+
+_cache_caps = {}
 
 
 def _tex_slot(device, nbytes, slot):
@@ -226,7 +228,8 @@ def _tex_slot(device, nbytes, slot):
         buf = pool[slot] = torch.empty(nbytes, dtype=torch.uint8, device=device)
     pool.move_to_end(slot)
     total = sum(x.numel() for x in pool.values())
-    while total > TEX_CACHE_BYTES and len(pool) > 1:
+    cap = _cache_cap(device, TEX_CACHE_BYTES, 16 << 30, 0.05)
+    while total > cap and len(pool) > 1:
         k0 = next(iter(pool))
         if k0 == slot:
             break
@@ -238,11 +241,12 @@ def _tex_packed(device, nbytes, source=None):
     """The buffer that receives the packed source RGBA (T1), plus a ticket that names this pack: a later call that holds the ticket and finds
     it still current (`_tex_still(ticket)`) knows that nothing overwrote the buffer in between.
     `source` = (tensor, its version counter, n, W, H): what is being packed (see _tex_cached); None / unversioned: the shared scratch slot."""
-    slot = ("src", id(source[0])) if (TEX_CACHE and source is not None and source[1] is not None) else "scratch"
+    cacheable = TEX_CACHE and source is not None and source[1] is not None and not getattr(source[0], "_ibgs_transient", False)
+    slot = ("src", id(source[0])) if cacheable else "scratch"
     buf = _tex_slot(device, nbytes, slot)
     _tex_writes[0] += 1
     buf._ibgs_ticket = _tex_writes[0]
-    buf._ibgs_src = source
+    buf._ibgs_src = (weakref.ref(source[0]),) + tuple(source[1:]) if cacheable else None
     return buf, (_stream_key(device), slot, _tex_writes[0], nbytes)
 
 
@@ -253,6 +257,12 @@ def _tensor_version(t):
         return t._version
     except (RuntimeError, AttributeError):
         return None
+
+
+def clear_caches():
+    """Drop every buffer the shim keeps between calls: the source-RGBA packs (TEX_CACHE), the per-stream scratch (texture, geo table, moment rows), the
+    per-camera launch orders and the R history.  The next calls allocate what they need again.  (renderer.clear_caches() calls this one too.)"""
+    _tex_pool.clear(); _tex_scratch.clear(); _gacc_scratch.clear(); _order_hints.clear(); _last_rendered.clear(); _cache_caps.clear()
 
 
 def invalidate_tex_cache():
@@ -270,7 +280,7 @@ def _tex_cached(device, nbytes, source):
     slot = ("src", id(source[0]))
     buf = pool.get(slot) if pool is not None else None
     had = getattr(buf, "_ibgs_src", None) if buf is not None else None
-    if had is None or buf.numel() < nbytes or had[0] is not source[0] or had[1:] != source[1:]:
+    if had is None or buf.numel() < nbytes or had[0]() is not source[0] or had[1:] != tuple(source[1:]):
         return None
     pool.move_to_end(slot)
     return buf, (_stream_key(device), slot, buf._ibgs_ticket, nbytes)
@@ -498,18 +508,6 @@ class _CModule:
                     if oh is not None:
                         _order_hints.move_to_end(ckey)
                         a.tile_order_hint = oh.data_ptr()
-                if DEPTH_BOUND and RENDERED_HINT and sh_c is not None and not render_depth_only and not debug:
-                    bkey = _camera_key(viewmatrix, device, W, H, render_geo, stream)
-                    if bkey is not None:
-                        bh = _bound_hints.get(bkey)
-                        if bh is None:          # +inf everywhere = no bound: what the buffer says until a forward of this camera has left its own
-                            while len(_bound_hints) >= DEPTH_BOUND_MAX:
-                                _bound_hints.popitem(last=False)          # (a buffer an enqueued kernel still uses stays alive in the stream's allocator until it ran)
-                            bh = _bound_hints[bkey] = torch.full((((W + 15) // 16) * ((H + 15) // 16),), float("inf"), dtype=torch.float32, device=device)
-                        else:
-                            _bound_hints.move_to_end(bkey)
-                            a.depth_bound_hint = bh.data_ptr()
-                        a.depth_bound_out = bh.data_ptr()
                 hkey = (device.index, P, W, H, render_geo, render_depth_only)
                 hist = _last_rendered.get(hkey) if (RENDERED_HINT and not debug) else None
                 prev = (max(hist) if isinstance(hist, list) else int(hist)) if hist else 0
@@ -702,6 +700,17 @@ class _CModule:
 
 
 _C = _CModule()
+
+
+def check_async_errors(device=None, wait=True):
+    """The library's one asynchronous error -- a depth sort whose look-back timed out in a forward that did not wait for it (include/ibgs_rast.h:
+    ibgs_check_async) -- for callers no backward follows: evaluation renders, the last forward of a run.  (A training step needs nothing: its own backward
+    reports the error of its forward.)  wait=True drains the device's current stream first; raises RuntimeError when a forward on it produced mis-ordered lists."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(device):
+        rc = _lib.load().ibgs_check_async(torch.cuda.current_stream(device).cuda_stream, 1 if wait else 0)
+    if rc < 0:
+        raise RuntimeError("ibgs_check_async failed (%d): %s" % (rc, _lib.last_error()))
 
 
 def rasterize_gaussians(means3D, means2D, means2D_abs, sh, colors_precomp, opacities, scales, rotations,

@@ -19,12 +19,14 @@ Unlike the reference nothing here hard-codes ``device="cuda"``: tensors follow `
 """
 import math
 import random
+import weakref
 from typing import Optional
 
 import numpy as np
 import torch
 
 from .activations import fused_activations, standard_model
+from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 _C0 = 0.28209479177387814
@@ -206,10 +208,13 @@ def _sinks(pc):
         if ent is None:
             if len(_sink_zeros) > 8:
                 _sink_zeros.clear()
-            ent = _sink_zeros[key] = (torch.zeros_like(xyz, requires_grad=False), torch.zeros(1, device=xyz.device, requires_grad=True))
-        z, anchor = ent
+            # (the third member: what a caller gets as `viewspace_points_abs` when nobody tracks it -- a zero-stride expansion of ONE row of zeros, which torch
+            # refuses to write into; handing out the shared buffer itself let an in-place write corrupt every later call's zeros: ADVICE r5)
+            ent = _sink_zeros[key] = (torch.zeros_like(xyz, requires_grad=False), torch.zeros(1, device=xyz.device, requires_grad=True),
+                                      torch.zeros((1,) + tuple(xyz.shape[1:]), dtype=xyz.dtype, device=xyz.device).expand(tuple(xyz.shape)))
+        z, anchor, z_ro = ent
         a = _SinkView.apply(z, anchor)
-        b = _SinkView.apply(z, anchor) if TRACK_ABS_GRAD else z
+        b = _SinkView.apply(z, anchor) if TRACK_ABS_GRAD else z_ro
         if a.requires_grad:          # (not under torch.no_grad(): render.py:297)
             a.retain_grad()
             if TRACK_ABS_GRAD:
@@ -319,9 +324,19 @@ def find_closest_frames(viewpoint_camera, scene, args):
 # stack of source images (4 x 3 x H x W: a 100 MB copy per call at 1080p, and a NEW tensor object each time -- which also defeats the rasterizer's
 # one-pack-per-source-stack cache, rasterizer.TEX_CACHE: +1 pack kernel) and the pose algebra (two LU inversions through rocSOLVER: ~15 small kernels).  Both
 # are kept per (tables' identity + version counters, camera matrix identity + version, chosen indices); an in-place write to a table moves its version
-# counter and drops the entry.  Same tensors, same arithmetic -- computed once.  SOURCE_CACHE_BYTES bounds the image stacks kept (least recently used first out).
-SOURCE_CACHE_BYTES = 8 << 30
-_src_cache = {}          # key -> [stacked images, ref_to_src_list, src_cam_pos]
+# counter and drops the entry.  Same tensors, same arithmetic -- computed once.  SOURCE_CACHE_BYTES bounds the image stacks kept (least recently used first out):
+# None = min(8 GiB, 2.5 % of the device memory free at first use).  Round 6: the scene's tables are remembered by WEAK reference (a discarded Scene is
+# not kept alive; its entries go with the next insertion), and sources drawn with random.sample (`args.shuffle_source_frame`) are not cached at all -- their key
+# space is combinatorial, every call would miss and leave a dead stack (and a dead RGBA pack in rasterizer.TEX_CACHE) behind.  The cached stacks and the sinks are
+# READ-ONLY for callers; clear_caches() drops everything.
+SOURCE_CACHE_BYTES = None
+_src_cache = {}          # key -> [versions, weak references to the tables, stacked images, ref_to_src_list, src_cam_pos]
+
+
+def clear_caches():
+    """Drop everything this module and the rasterizer shim keep between calls (source stacks, pose algebra, RGBA packs, scratch, launch orders, sinks)."""
+    _src_cache.clear(); _sink_zeros.clear()
+    _rz.clear_caches()
 
 
 def _version(t):
@@ -338,7 +353,7 @@ def _cached_sources(scene, viewpoint_camera, chosen, dev):
         return None, None
     key = (id(imgs), id(w2s_all), id(V), tuple(int(i) for i in chosen), str(dev))
     ent = _src_cache.get(key)
-    if ent is not None and ent[0] == vers and ent[1][0] is imgs and ent[1][1] is w2s_all and ent[1][2] is V:
+    if ent is not None and ent[0] == vers and ent[1][0]() is imgs and ent[1][1]() is w2s_all and ent[1][2]() is V:
         _src_cache[key] = _src_cache.pop(key)          # most recently used last
         return ent, key
     return None, key
@@ -349,9 +364,12 @@ def _remember_sources(key, scene, viewpoint_camera, src_images, ref_to_src_list,
         return
     imgs, w2s_all, V = scene.original_image_list, scene.world_view_transforms, viewpoint_camera.world_view_transform
     _src_cache.pop(key, None)
-    _src_cache[key] = [(_version(imgs), _version(w2s_all), _version(V)), (imgs, w2s_all, V), src_images, ref_to_src_list, src_cam_pos]
+    for k in [k for k, e in _src_cache.items() if any(r() is None for r in e[1])]:          # entries of tables that no longer exist
+        del _src_cache[k]
+    _src_cache[key] = [(_version(imgs), _version(w2s_all), _version(V)), (weakref.ref(imgs), weakref.ref(w2s_all), weakref.ref(V)), src_images, ref_to_src_list, src_cam_pos]
     total = sum(e[2].numel() * e[2].element_size() for e in _src_cache.values())
-    while total > SOURCE_CACHE_BYTES and len(_src_cache) > 1:
+    cap = _rz._cache_cap(src_images.device, SOURCE_CACHE_BYTES, 8 << 30, 0.025)
+    while total > cap and len(_src_cache) > 1:
         k0 = next(iter(_src_cache))
         e = _src_cache.pop(k0)
         total -= e[2].numel() * e[2].element_size()
@@ -383,11 +401,12 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
             nb_src_frames, ref_to_src_list, src_images, src_rendered_depths, src_cam_pos = _no_sources(viewpoint_camera, dev)
         else:
             nb_src_frames = min(nb_src_frames, len(nearest))
-            if getattr(args, "shuffle_source_frame", False):
+            shuffled = bool(getattr(args, "shuffle_source_frame", False))
+            if shuffled:
                 chosen = random.sample(list(nearest), nb_src_frames)
             else:
                 chosen = list(nearest[:nb_src_frames])
-            cached, ckey = _cached_sources(scene, viewpoint_camera, chosen, dev)
+            cached, ckey = (None, None) if shuffled else _cached_sources(scene, viewpoint_camera, chosen, dev)          # (a random draw: nothing to cache, see SOURCE_CACHE_BYTES)
             src_images = cached[2] if cached is not None else _rows(scene.original_image_list, chosen)
             if do_render_src_depth:
                 # the reference loops render_depth over the sources (:245-253); here they share ONE rasterizer pass
@@ -408,6 +427,8 @@ def render(viewpoint_camera, pc, scene, pipe, args, bg_color: torch.Tensor, lear
                 ref_to_src_list = world_to_src @ ref_to_world.unsqueeze(0)
                 src_cam_pos = src_to_world[:, :3, 3].contiguous()
                 src_images = src_images.to(dev)
+                if shuffled:
+                    src_images._ibgs_transient = True          # one-off stack: the rasterizer packs its RGBA into the shared scratch slot (rasterizer.TEX_CACHE)
                 _remember_sources(ckey, scene, viewpoint_camera, src_images, ref_to_src_list, src_cam_pos)
             src_rendered_depths = src_rendered_depths.to(dev)
     else:

@@ -95,9 +95,6 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                      chain (backward.cu:405-420), without its cancellation: 3-10 x closer to a float64 evaluation than ANY fp32 evaluation of the reference's own
                                      expressions (profiles/r06_ref_arith_ab.txt).  With this flag they are formed exactly as the reference forms them: the eight per-pair quantities of
                                      backward.cu:779-804 in its association, uncontracted, and the chain of :405-420 on their sums.  Every other Gaussian: unchanged */
-#define IBGS_FLAG_SPLIT_GEO_EPILOGUE 2048u /* ibgs_forward, render_geo (experiment, round 5): run the per-pixel epilogue (median depth, source validity, warp;
-                                              forward.cu:507-663) as its own pixel-parallel kernel behind the blend kernel instead of inside it.  Bit-identical outputs;
-                                              SLOWER on MI355X (C3-geo forward 0.716 -> 0.844 ms, trained 0.367 -> 0.392: alone, the gathers have nothing to hide behind) */
 #define IBGS_FLAG_NO_ABS_GRAD 1024u /* ibgs_backward only: dL_dmean2D_abs is not wanted (it may be NULL and is not written).  It is the densification statistic of
                                        train.py:400-410 (sum over pixels of |dL/dmean2D| per Gaussian, backward.cu:793-804): nobody reads it after
                                        densify_until_iter or at test time.  The colour blend then skips the two |.| moments (conic x d per quadrant, two fma per
@@ -207,17 +204,6 @@ typedef struct ibgs_forward_args {
      * torch.cat of scene/gaussian_model.py:140-143 (192 B read + written per Gaussian and call at M = 16, and its mirror image in the backward).  Both 16-byte aligned.
      * Results are bit-identical to the concatenated form. */
     const float* shs_rest;
-    /* Optional depth-bound hint (device pointers, ceil(W/16) x ceil(H/16) floats each; either may be NULL).  depth_bound_out receives, per tile, a depth a little
-     * behind the entry at which the tile's last pixel terminated in THIS forward (+inf where a pixel was still open).  Handed to a later forward of the SAME
-     * camera as depth_bound_hint, it lets the preprocess stage drop every Gaussian that lies behind the bound of all the tiles its rectangle covers before
-     * the depth sort, the SH evaluation and the binning see it: in a trained scene most visible Gaussians sit behind saturated pixels and are never reached.
-     * EXACT whatever the buffer holds: after the blend a kernel checks, per tile, that every pixel terminated in front of the tile's bound (then the lists
-     * the pixels saw are the unbounded ones entry for entry); if one did not -- the scene or the camera moved, garbage -- the frame is redone without a
-     * bound by a second pass queued behind the check, whose kernels all leave at once when the check was clean.  Outputs, arenas and gradients are those
-     * of a forward without the hint (the lists of an unrepaired frame lack entries no pixel reaches); the return value is R of the unbounded lists.
-     * Colour and render_geo passes with a rendered_hint; ignored with IBGS_FLAG_DEBUG, render_depth_only, n_views > 1, precomputed colours. */
-    const float* depth_bound_hint;
-    float* depth_bound_out;
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {
@@ -315,6 +301,11 @@ int64_t ibgs_forward(const ibgs_forward_args* args);
 /* diagnostics of the calling thread's last ibgs_forward: out[0] = R, out[1] = coarse binning entries (-1 unless rendered_hint was used),
  * out[2] = 1 when the hint was too small and binning + render ran a second time with the exact size */
 void ibgs_last_forward_stats(int64_t* out3);
+/* The one asynchronous error of the library: a forward with a rendered_hint does not wait for its depth sort, whose decoupled look-back gives up (and leaves mis-ordered
+ * lists) if a workgroup is starved for seconds.  The sticky error word is reported by the ibgs_backward of the same step (it waits briefly for the word of its forward, with
+ * its own kernels already queued: no optimiser step sees such gradients), else by the next ibgs_forward on the stream, else HERE -- for callers no backward follows
+ * (evaluation renders, the last forward of a run).  wait != 0 drains the stream first (the answer is then final); returns 0 or -IBGS_ERR_HIP (ibgs_last_error). */
+int32_t ibgs_check_async(void* stream, int32_t wait);
 int32_t ibgs_backward(const ibgs_backward_args* args);
 int32_t ibgs_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                           const float* projmatrix, uint8_t* present /* P bools */);

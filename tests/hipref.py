@@ -49,21 +49,13 @@ def leaf_inputs(inp, dev, requires_grad=True):
     return d
 
 
-def run_forward(inp, dev="cuda", debug=False, requires_grad=True, depth_bound=False):
-    """depth_bound = False: no depth-bound hint whatever `rasterizer.DEPTH_BOUND` says -- the tests that go through here look at the arenas (lists, ranges,
-    tile counts), which a bounded frame fills with fewer entries; tests/test_gpu_depth_bound.py passes True."""
-    from ibgs_amd import rasterizer as _r
+def run_forward(inp, dev="cuda", debug=False, requires_grad=True):
     st = settings_from(inp, dev, debug)
     lv = leaf_inputs(inp, dev, requires_grad)
     rast = GaussianRasterizer(st)
-    old = _r.DEPTH_BOUND
-    _r.DEPTH_BOUND = bool(depth_bound)
-    try:
-        outs = rast(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
-                    shs=lv["shs"], colors_precomp=lv["colors_precomp"], scales=lv["scales"], rotations=lv["rotations"],
-                    cov3D_precomp=lv["cov3D_precomp"], all_map=lv["all_map"])
-    finally:
-        _r.DEPTH_BOUND = old
+    outs = rast(means3D=lv["means3D"], means2D=lv["means2D"], means2D_abs=lv["means2D_abs"], opacities=lv["opacities"],
+                shs=lv["shs"], colors_precomp=lv["colors_precomp"], scales=lv["scales"], rotations=lv["rotations"],
+                cov3D_precomp=lv["cov3D_precomp"], all_map=lv["all_map"])
     names = ["color", "radii", "normal_map", "median_depth", "cam_feat", "warped_image", "min_depth_diff",
              "camera_ray", "use_first_src_frame_mask"]
     return dict(zip(names, outs)), lv, st

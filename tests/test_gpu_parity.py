@@ -427,37 +427,3 @@ def test_inputs_that_are_views_into_the_middle_of_an_allocation():
         setattr(a, k, dummy.data_ptr())
     a.radii = dummy.data_ptr(); a.shs = shifted.data_ptr()
     assert _lib.load().ibgs_forward(ctypes.byref(a)) < 0 and "16-byte aligned" in _lib.last_error()
-
-
-@pytest.mark.parametrize("L,n_src", [(4, 3), (5, 2)])
-def test_split_geo_epilogue_is_bit_identical(L, n_src):
-    """IBGS_FLAG_SPLIT_GEO_EPILOGUE (experiment, round 5: the per-pixel epilogue of the geo forward as its own kernel; measured slower, default off):
-    every output plane and every per-pixel cache the backward reads must equal the fused path's bit for bit -- and so must the gradients."""
-    inp = add_sources(scene(P=2500, W=176, H=112, deg=2, seed=44, opacity="trained", planes=True, scale_mul=1.5), n_src=n_src, L=L)
-    H, W = inp["H"], inp["W"]
-    grads = {"color": rnd((3, H, W), 7), "normal_map": rnd((3, H, W), 8), "median_depth": rnd((1, H, W), 9), "warped_image": rnd((15, H, W), 10)}
-    res = {}
-    old = (rasterizer.SPLIT_GEO_EPILOGUE, rasterizer.DETERMINISTIC)
-    try:
-        rasterizer.DETERMINISTIC = True          # no float atomics: the gradients are comparable bit for bit
-        for split in (False, True):
-            rasterizer.SPLIT_GEO_EPILOGUE = split
-            outs, leaves, _ = hipref.run_forward(inp)
-            ist = hipref.internal_state(outs, inp)
-            loss = 0
-            for k, g in grads.items():
-                loss = loss + (outs[k] * torch.as_tensor(g, device="cuda")).sum()
-            loss.backward()
-            res[split] = (hipref.to_np(outs), ist, {k: v.grad.cpu().numpy() for k, v in leaves.items() if v is not None and v.grad is not None})
-    finally:
-        rasterizer.SPLIT_GEO_EPILOGUE, rasterizer.DETERMINISTIC = old
-    a, b = res[False], res[True]
-    assert (a[1]["valid_idx"][0] >= 0).mean() > 0.2, "scene does not exercise the warp path"
-    for k in a[0]:
-        assert np.array_equal(a[0][k], b[0][k]), k
-    for k in ("sum_w", "low_high", "n_contrib", "final_T"):
-        assert np.array_equal(a[1][k], b[1][k]), k
-    va, vb = canon_valid(a[1]["valid_idx"]), canon_valid(b[1]["valid_idx"])          # (defined up to the -1 terminator; the words behind it are never written)
-    assert np.array_equal(va, vb) and np.array_equal(a[1]["valid_w"][va >= 0], b[1]["valid_w"][vb >= 0])
-    for k in a[2]:
-        assert np.array_equal(a[2][k], b[2][k]), k
