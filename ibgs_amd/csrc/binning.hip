@@ -54,6 +54,33 @@ __device__ __forceinline__ Footprint make_footprint(const uint4 rr, const uint64
     return f;
 }
 
+// Lane g's footprint, handed to every lane of the wave out of the owner's REGISTERS (round 6).  The cooperative walks below used to load it again from memory --
+// wave-uniform addresses, lines the owner had just touched, but a chain of two or three DEPENDENT loads per large Gaussian (footprint -> mask words -> record), ~1 us
+// each time, one Gaussian after the other: on a trained scene (a heavy tail of sizes: 1-2 large rectangles in every batch of 64 depth ranks, ten in the unluckiest)
+// that chain, not any throughput, was what cell_count / cell_place took 43 / 77 us for instead of 25 / 29 (profiles/r06_frontend.txt).
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int g) { return (uint32_t)__builtin_amdgcn_readlane((int)v, g); }
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int g) { return ((uint64_t)bcast_u32((uint32_t)(v >> 32), g) << 32) | bcast_u32((uint32_t)v, g); }
+__device__ __forceinline__ float bcast_f32(float v, int g) { return __uint_as_float(bcast_u32(__float_as_uint(v), g)); }
+__device__ __forceinline__ Footprint bcast_footprint(const Footprint& f, int g)
+{
+    Footprint o;
+    o.r = RectU{bcast_u32(f.r.x0, g), bcast_u32(f.r.x1, g), bcast_u32(f.r.y0, g), bcast_u32(f.r.y1, g)};
+    o.m0 = bcast_u64(f.m0, g); o.m1 = bcast_u64(f.m1, g); o.m2 = bcast_u64(f.m2, g); o.m3 = bcast_u64(f.m3, g);
+    const uint32_t area = (o.r.x1 - o.r.x0) * (o.r.y1 - o.r.y0);          // (as make_footprint)
+    o.masked = area <= (uint32_t)IBGS_CULL_MAX_TILES;
+    o.rows = !o.masked && o.m0 == 0ull;
+    return o;
+}
+// ... and what a row-culled rectangle's runs are computed from: quads 0 and 1 of the Gaussian's record (x, y, opacity; conic), loaded by the owner lane
+struct RowsRec { float x, y, o, a, b, c; };
+__device__ __forceinline__ RowsRec load_rows_rec(const float4* __restrict__ rec, uint32_t id, bool want)
+{
+    RowsRec r{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (want) { const float4 q0 = rec[(size_t)id * 4], q1 = rec[(size_t)id * 4 + 1]; r = RowsRec{q0.x, q0.y, q0.z, q1.x, q1.y, q1.z}; }
+    return r;
+}
+__device__ __forceinline__ RowsRec bcast_rows_rec(const RowsRec& r, int g) { return RowsRec{bcast_f32(r.x, g), bcast_f32(r.y, g), bcast_f32(r.o, g), bcast_f32(r.a, g), bcast_f32(r.b, g), bcast_f32(r.c, g)}; }
+
 // up to 8 bits of the row-major tile mask, starting at bit `start`
 __device__ __forceinline__ uint32_t mask_bits(const Footprint& f, uint32_t start, uint32_t len)
 {
@@ -131,21 +158,6 @@ __device__ __forceinline__ bool small_cells(const PlaceGeom& pg, const Footprint
     return true;
 }
 
-// larger rectangles: calls f(cell, mask) for every cell of the slice that holds a surviving tile of the Gaussian
-template <typename F>
-__device__ __forceinline__ void for_cells(const PlaceGeom& pg, const Footprint& fp, F f)
-{
-    const RectU& r = fp.r;
-    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
-    for (uint32_t cy = c0y; cy <= c1y; cy++)
-        for (uint32_t cx = c0x; cx <= c1x; cx++) {
-            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
-            if (cell < 0 || cell >= pg.nc) continue;
-            const uint64_t m = cell_mask(fp, cx, cy);
-            if (m != 0ull) f(cell, m);
-        }
-}
-
 // ---- large rectangles: the whole wave walks one Gaussian's cells ---------------------------------------------------------------------------
 // A lane that walks the 20 .. 135 cells of a large rectangle on its own keeps the other 63 lanes of its batch waiting, and on a trained scene
 // (a heavy tail of sizes) nearly every batch of 64 depth ranks holds such a Gaussian: cell_count 23 -> 78 us, cell_place 28 -> 165 us on the
@@ -162,60 +174,153 @@ __device__ __forceinline__ bool wants_coop(const Footprint& f)
     return f.rows || cw * chh > COOP_MIN_CELLS;
 }
 // the job of a row-culled Gaussian from its record (quads 0, 1: x, y, opacity; conic) -- what preprocess.hip's cull_setup built
-__device__ __forceinline__ CullRows rows_job(const PlaceGeom& pg, const Footprint& f, const float4* __restrict__ rec, uint32_t id, int& row_off)
+__device__ __forceinline__ CullRows rows_job(const PlaceGeom& pg, const Footprint& f, const RowsRec& q, uint32_t id, int& row_off)
 {
-    const float4 q0 = rec[(size_t)id * 4], q1 = rec[(size_t)id * 4 + 1];
     CullRows j;
-    cull_rows_setup_conic(j, q0.x, q0.y, q1.x, q1.y, q1.z, cull_qmax(q0.z), (int)f.r.x0, (int)f.r.x1);
+    cull_rows_setup_conic(j, q.x, q.y, q.a, q.b, q.c, cull_qmax(q.o), (int)f.r.x0, (int)f.r.x1);
     row_off = (int)(id / (uint32_t)pg.Pv) * pg.gyv;          // batched views: the record's y is the view's own, the rectangle's rows are the stacked grid's
     return j;
 }
 // All 64 lanes call this with the same (wave-uniform) footprint; f(cell, mask) runs on the lane that owns the cell.
+// CoopCache (round 6): cell_place_kernel walks every large rectangle of a batch TWICE (who touches which cell; then the entries themselves), and on a trained scene
+// that walk is what the kernel spends its time on -- ~600 wave instructions per row-culled rectangle and pass (the exact row runs: two square roots and IEEE
+// divisions per tile row, then eight rows per cell), 1-2 such rectangles in every batch of 64 depth ranks: 2 370 instructions per wave against 645 on the init
+// scene, the kernel VALU-bound chip-wide at 77 us (profiles/r06_frontend.txt).  The first walk therefore parks the mask of every (iteration, lane) in LDS --
+// COOP_SLOTS iterations per wave, 2 KB each -- and the second one reads them back instead of computing the runs again; iterations beyond the slots are recomputed.
+constexpr int COOP_SLOTS = 8;
+struct CoopCache { unsigned long long* base; int slot; int mode; };          // base: [COOP_SLOTS][64] words of this wave; mode 0: none, 1: fill, 2: read
 template <typename F>
-__device__ __forceinline__ void wave_for_cells(const PlaceGeom& pg, const Footprint& fp, const float4* __restrict__ rec, uint32_t id, int lane,
-                                               uint32_t* __restrict__ s_runs /* 64 words of this wave */, F f)
+__device__ __forceinline__ void wave_for_cells(const PlaceGeom& pg, const Footprint& fp, const RowsRec& rq, uint32_t id, int lane,
+                                               uint32_t* __restrict__ s_runs /* 64 words of this wave */, F f, CoopCache* cc = nullptr)
 {
     const RectU& r = fp.r;
     const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB, c1x = (r.x1 - 1) / CB, c1y = (r.y1 - 1) / CB;
     const uint32_t cw = c1x - c0x + 1;
+    const int mode = cc ? cc->mode : 0;
+    // one iteration of the walk: the lane's cell (or none) and its mask -- computed by `compute`, or taken from / left in the cache
+    auto iteration = [&](int cell, auto compute) {
+        const bool cached = mode != 0 && cc->slot < COOP_SLOTS;          // wave-uniform
+        uint64_t m = 0ull;
+        if (mode == 2 && cached) m = cc->base[cc->slot * 64 + lane];
+        else if (cell >= 0) m = compute();
+        if (mode == 1 && cached) cc->base[cc->slot * 64 + lane] = m;
+        if (mode != 0) cc->slot++;
+        if (cell >= 0 && m != 0ull) f(cell, m);
+    };
     if (!fp.rows) {
         const uint32_t ncell = cw * (c1y - c0y + 1);
-        for (uint32_t idx = (uint32_t)lane; idx < ncell; idx += 64u) {
+        for (uint32_t i0 = 0; i0 < ncell; i0 += 64u) {
+            const uint32_t idx = i0 + (uint32_t)lane;
             const uint32_t cy = c0y + idx / cw, cx = c0x + idx % cw;
-            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
-            if (cell < 0 || cell >= pg.nc) continue;
-            const uint64_t m = cell_mask(fp, cx, cy);
-            if (m != 0ull) f(cell, m);
+            int cell = idx < ncell ? (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0 : -1;
+            if (cell >= pg.nc) cell = -1;
+            iteration(cell, [&]() { return cell_mask(fp, cx, cy); });
         }
         return;
     }
     int row_off;
-    const CullRows j = rows_job(pg, fp, rec, id, row_off);
+    const CullRows j = rows_job(pg, fp, rq, id, row_off);
     for (uint32_t sy = c0y; sy <= c1y; sy += 8u) {          // strips of eight cell rows = 64 tile rows
-        const int ty = (int)(sy * CB) + lane;
-        int t0 = 1, t1 = 0;
-        if (ty >= (int)r.y0 && ty < (int)r.y1) { if (!cull_row_run(j, ty - row_off, t0, t1)) { t0 = 1; t1 = 0; } }
-        __builtin_amdgcn_wave_barrier();
-        s_runs[lane] = (uint32_t)t0 | ((uint32_t)t1 << 16);          // (LDS operations of one wave execute in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         const uint32_t nrow = min(8u, c1y - sy + 1u);
-        for (uint32_t idx = (uint32_t)lane; idx < nrow * cw; idx += 64u) {
-            const uint32_t dy = idx / cw, cy = sy + dy, cx = c0x + idx % cw;
-            const int cell = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
-            if (cell < 0 || cell >= pg.nc) continue;
-            const int cx0 = (int)(cx * CB);
-            uint64_t m = 0ull;
-#pragma unroll
-            for (int rr = 0; rr < CB; rr++) {
-                const uint32_t run = s_runs[dy * CB + rr];
-                const int lo = max((int)(run & 0xFFFFu), cx0), hi = min((int)(run >> 16), cx0 + CB - 1);
-                if (lo <= hi) m |= (uint64_t)((1u << (hi - lo + 1)) - 1u) << (rr * CB + (lo - cx0));
-            }
-            if (m != 0ull) f(cell, m);
+        const int iters = (int)((nrow * cw + 63u) / 64u);
+        const bool all_cached = mode == 2 && cc->slot + iters <= COOP_SLOTS;          // wave-uniform: nobody needs this strip's runs
+        if (!all_cached) {
+            const int ty = (int)(sy * CB) + lane;
+            int t0 = 1, t1 = 0;
+            if (ty >= (int)r.y0 && ty < (int)r.y1) { if (!cull_row_run(j, ty - row_off, t0, t1)) { t0 = 1; t1 = 0; } }
+            __builtin_amdgcn_wave_barrier();
+            s_runs[lane] = (uint32_t)t0 | ((uint32_t)t1 << 16);          // (LDS operations of one wave execute in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i0 = 0; i0 < nrow * cw; i0 += 64u) {
+            const uint32_t idx = i0 + (uint32_t)lane;
+            const uint32_t dy = idx / cw, cy = sy + dy, cx = c0x + idx % cw;
+            int cell = idx < nrow * cw ? (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0 : -1;
+            if (cell >= pg.nc) cell = -1;
+            iteration(cell, [&]() {
+                const int cx0 = (int)(cx * CB);
+                uint64_t m = 0ull;
+#pragma unroll
+                for (int rr = 0; rr < CB; rr++) {
+                    const uint32_t run = s_runs[dy * CB + rr];
+                    const int lo = max((int)(run & 0xFFFFu), cx0), hi = min((int)(run >> 16), cx0 + CB - 1);
+                    if (lo <= hi) m |= (uint64_t)((1u << (hi - lo + 1)) - 1u) << (rr * CB + (lo - cx0));
+                }
+                return m;
+            });
+        }
+        if (!all_cached) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---- medium rectangles: all of a batch at once, one (Gaussian, cell) item per lane ------------------------------------------------------------------
+// A rectangle wider or taller than 8 tiles that stays below the cooperative walk's threshold (<= 9 cells, mask-culled) was walked by its owner lane alone
+// (for_cells): up to 9 cells x ~120 instructions while the other lanes of the batch waited.  On the init scene 1 lane in 54 is such a rectangle; on a trained
+// scene (log-normal sizes) 3.6 lanes of every batch are, the longest of them 5.5 cells: ~660 wave instructions per walk, three walks per Gaussian (count, touch,
+// place) -- 1 320 of the 2 370 instructions a wave of cell_place_kernel executed there (645 on the init scene), the kernel VALU-bound chip-wide at 77 us
+// (profiles/r06_frontend.txt).  Here the batch's medium rectangles are flattened: the lanes' cell counts are scanned, item i of the batch = cell k of
+// owner o (binary search over the scan with shuffles), every lane fetches ITS owner's footprint out of the owner's registers (ds_bpermute) and computes one
+// cell's mask: ~190 wave instructions per 64 items (15 items per batch on the trained scene) instead of 660.
+// FlatCache: cell_place_kernel walks the items twice (touch, place); the first walk keeps (cell, mask, owner) of its first FLAT_SLOTS x 64 items in registers.
+constexpr int FLAT_SLOTS = 2;
+struct FlatCache { int cell[FLAT_SLOTS]; uint64_t m[FLAT_SLOTS]; uint32_t who[FLAT_SLOTS]; /* owner lane | owner id is fetched again: one shuffle */ };
+template <int MODE /* 0: no cache, 1: fill, 2: read */, typename F>
+__device__ __forceinline__ void wave_flat_cells(const PlaceGeom& pg, const Footprint& fp, uint32_t id, bool medium, int lane, F f /* (cell, mask, owner lane, owner id) */, FlatCache* fc = nullptr)
+{
+    const RectU& r = fp.r;
+    const uint32_t c0x = r.x0 / CB, c0y = r.y0 / CB;
+    const uint32_t cw = medium ? (r.x1 - 1) / CB - c0x + 1 : 0u, chh = medium ? (r.y1 - 1) / CB - c0y + 1 : 0u;
+    const uint32_t n = cw * chh;
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0u) return;          // wave-uniform
+    const uint32_t px = r.x0 | (r.x1 << 16), py = r.y0 | (r.y1 << 16);
+    auto item_of = [&](uint32_t base, int& cell, uint64_t& m, uint32_t& owner) {
+        const uint32_t item = base + (uint32_t)lane;
+        const bool valid = item < total;
+        int lo = 0;          // number of lanes whose inclusive count is <= item = the owner (incl is non-decreasing)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) { const uint32_t v = (uint32_t)__shfl((int)incl, lo + step - 1, 64); if (v <= item) lo += step; }
+        owner = (uint32_t)min(lo, 63);
+        Footprint fo;
+        const uint32_t qx = (uint32_t)__shfl((int)px, (int)owner, 64), qy = (uint32_t)__shfl((int)py, (int)owner, 64);
+        fo.r = RectU{qx & 0xFFFFu, qx >> 16, qy & 0xFFFFu, qy >> 16};
+        auto sh64 = [&](uint64_t v) { return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)owner, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)v, (int)owner, 64); };
+        fo.m0 = sh64(fp.m0); fo.m1 = sh64(fp.m1); fo.m2 = sh64(fp.m2); fo.m3 = sh64(fp.m3);
+        const uint32_t excl_o = (uint32_t)__shfl((int)(incl - n), (int)owner, 64), cw_o = (uint32_t)__shfl((int)cw, (int)owner, 64);
+        fo.masked = (fo.r.x1 - fo.r.x0) * (fo.r.y1 - fo.r.y0) <= (uint32_t)IBGS_CULL_MAX_TILES;          // (as make_footprint; a medium rectangle is never row-culled)
+        fo.rows = false;
+        cell = -1; m = 0ull;
+        if (valid) {
+            const uint32_t k = item - excl_o;
+            const uint32_t cx = fo.r.x0 / CB + k % cw_o, cy = fo.r.y0 / CB + k / cw_o;
+            const int c = (int)(cy * (uint32_t)pg.cgx + cx) - pg.c0;
+            if (c >= 0 && c < pg.nc) { m = cell_mask(fo, cx, cy); if (m != 0ull) cell = c; }
+        }
+    };
+    uint32_t base = 0;
+#pragma unroll
+    for (int it = 0; it < FLAT_SLOTS; it++) {          // (static indices into the cache: it lives in registers)
+        if (base >= total) break;          // wave-uniform
+        int cell; uint64_t m; uint32_t owner;
+        if (MODE == 2) { cell = fc->cell[it]; m = fc->m[it]; owner = fc->who[it]; }
+        else item_of(base, cell, m, owner);
+        if (MODE == 1) { fc->cell[it] = cell; fc->m[it] = m; fc->who[it] = owner; }
+        const uint32_t oid = (uint32_t)__shfl((int)id, (int)owner, 64);
+        if (cell >= 0) f(cell, m, (int)owner, oid);
+        base += 64u;
+    }
+    for (; base < total; base += 64u) {          // more than FLAT_SLOTS x 64 items in one batch: computed in either walk
+        int cell; uint64_t m; uint32_t owner;
+        item_of(base, cell, m, owner);
+        const uint32_t oid = (uint32_t)__shfl((int)id, (int)owner, 64);
+        if (cell >= 0) f(cell, m, (int)owner, oid);
     }
 }
 
@@ -235,58 +340,45 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg,
     for (int j0 = blk * pg.G + wave * 64; j0 < j1; j0 += PLACE_THREADS) {          // wave-uniform: a batch of 64 consecutive ranks per wave
         const int j = j0 + lane;
         const bool have = j < j1;
-        bool coop = false;
+        bool coop = false, medium = false;
         uint32_t id = 0u;
+        Footprint fp{};
         if (have) {
             id = order[j];
             const uint4 rr = fpr[id];                             // the one random 16-byte gather per Gaussian of the binning stage
             if (pg.c0 == 0) fp_sorted[j] = rr;
-            const Footprint fp = make_footprint(rr, tmask_hi, id);
+            fp = make_footprint(rr, tmask_hi, id);
             coop = wants_coop(fp);
             if (!coop) {
                 Cells4 c4;
                 if (small_cells(pg, fp, c4)) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicAdd(&s_cnt[c4.cell[k]], 1u);
-                } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+                } else medium = true;
             }
         }
+        wave_flat_cells<0>(pg, fp, id, medium, lane, [&](int cell, uint64_t, int, uint32_t) { atomicAdd(&s_cnt[cell], 1u); });          // the batch's medium rectangles, an item per lane
         uint64_t todo = __ballot(coop);
-        while (todo != 0ull) {          // wave-uniform: the large rectangles of this batch, one after the other, a cell per lane
-            const int g = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, g);
-            const Footprint fp = make_footprint(fpr[gid], tmask_hi, gid);
-            wave_for_cells(pg, fp, rec, gid, lane, s_runs[wave], [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+        if (todo != 0ull) {
+            const RowsRec rq = load_rows_rec(rec, id, coop && fp.rows);          // (every owner at once: one memory round trip for the batch)
+            while (todo != 0ull) {          // wave-uniform: the large rectangles of this batch, one after the other, a cell per lane
+                const int g = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint32_t gid = bcast_u32(id, g);
+                const Footprint fg = bcast_footprint(fp, g);
+                wave_for_cells(pg, fg, bcast_rows_rec(rq, g), gid, lane, s_runs[wave], [&](int cell, uint64_t) { atomicAdd(&s_cnt[cell], 1u); });
+            }
         }
     }
     __syncthreads();
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) cnt[(size_t)(pg.c0 + c) * pg.nblk + blk] = s_cnt[c];
 }
 
-__global__ void __launch_bounds__(256) cell_colscan_kernel(int nblk, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cell_total)
-{
-    __shared__ uint32_t s_part[256];
-    uint32_t* row = cnt + (size_t)blockIdx.x * nblk;
-    const int per = (nblk + 255) / 256;
-    const int b0 = min(nblk, (int)threadIdx.x * per), b1 = min(nblk, b0 + per);
-    uint32_t sum = 0;
-    for (int b = b0; b < b1; b++) sum += row[b];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    // inclusive scan of the 256 strip sums (Hillis-Steele in LDS)
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (int b = b0; b < b1; b++) { const uint32_t v = row[b]; row[b] = run; run += v; }
-    if (threadIdx.x == 255) cell_total[blockIdx.x] = s_part[255];
-}
-
-// First entry of every cell + chunk bookkeeping + C, ONE workgroup (ncells <= a few thousand)
+// First entry of every cell + chunk bookkeeping + C, ONE workgroup (ncells <= a few thousand).
+// (Round 6 tried to run this as the LAST workgroup of cell_colscan_kernel -- and tile_ranges as the last workgroup of cell_scan_kernel -- behind the classic
+// fence / ticket hand-over: two launches fewer, and SLOWER: cell_colscan 7.9 -> 27.4 us, cell_scan 5.0 -> 34.6 us against the 6.5 + 9.5 us of the two
+// one-workgroup kernels saved.  The agent-scope release fence every workgroup must issue before its ticket writes the XCD's L2 back; 135 of them in a row
+// cost more than a launch.  profiles/r06_frontend.txt)
 __global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const uint32_t* __restrict__ cell_total, int ncells,
                                                          uint32_t* __restrict__ cell_start /* ncells + 1 */,
                                                          uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */, uint32_t* __restrict__ C_out)
@@ -318,6 +410,29 @@ __global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const ui
     __syncthreads();
     run = s_chunks[threadIdx.x];
     for (int c = c0; c < c1; c++) { cell_chunk0[c] = run; run += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK; }
+}
+
+// One workgroup per cell: exclusive scan of the cell's counts over the blocks, in place, and the cell's total
+__global__ void __launch_bounds__(256) cell_colscan_kernel(int nblk, uint32_t* __restrict__ cnt, uint32_t* __restrict__ cell_total)
+{
+    __shared__ uint32_t s_part[256];
+    uint32_t* row = cnt + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + 255) / 256;
+    const int b0 = min(nblk, (int)threadIdx.x * per), b1 = min(nblk, b0 + per);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; b++) sum += row[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    // inclusive scan of the 256 strip sums (Hillis-Steele in LDS)
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; b++) { const uint32_t v = row[b]; row[b] = run; run += v; }
+    if (threadIdx.x == 255) cell_total[blockIdx.x] = s_part[255];
 }
 
 // The caller's launch order hint for the blend kernel (ibgs_forward_args::tile_order_hint) is used only when it holds every tile exactly once
@@ -369,6 +484,7 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
     extern __shared__ unsigned long long s_place[];        // 4 x nc lane words (one table per wave), then nc next-free slots
     if (meta) { if (blockIdx.x == 0) { check_order_hint(ntiles, order_hint, meta, reinterpret_cast<uint32_t*>(s_place)); return; } }
     __shared__ uint32_t s_runs[PLACE_THREADS / 64][64];
+    __shared__ unsigned long long s_coop[PLACE_THREADS / 64][COOP_SLOTS * 64];          // the first walk's masks of this wave's large rectangles, for the second one (CoopCache)
     const int nc = pg.nc;
     unsigned long long* s_touch = s_place;
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + 4 * nc);
@@ -383,7 +499,7 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
         const bool have = j < j1;
         const uint32_t id = have ? order[j] : 0u;
         unsigned long long* mine = s_touch + wave * nc;
-        Footprint fp; Cells4 c4; bool small = true, coop = false;
+        Footprint fp{}; Cells4 c4; bool small = true, coop = false, medium = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) c4.cell[k] = -1;
         if (have) {
@@ -394,17 +510,20 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
                 if (small) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) atomicOr(&mine[c4.cell[k]], 1ull << lane);
-                } else for_cells(pg, fp, [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << lane); });
+                } else medium = true;
             }
         }
+        FlatCache fcache;
+        wave_flat_cells<1>(pg, fp, id, medium, lane, [&](int cell, uint64_t, int o, uint32_t) { atomicOr(&mine[cell], 1ull << o); }, &fcache);          // the batch's medium rectangles: who touches which cell ...
         // the large rectangles of this wave's batch, one after the other, a cell per lane (wave_for_cells): first who touches which cell ...
         const uint64_t coopm = __ballot(coop);
-        const int jw = j0 + wave * 64;          // this wave's first rank
+        const RowsRec rq = load_rows_rec(rec, id, coop && fp.rows);          // (all owners of the batch at once; out of their registers from here on: bcast_footprint)
+        CoopCache cc{s_coop[wave], 0, 1};
         for (uint64_t todo = coopm; todo != 0ull; todo &= todo - 1ull) {
             const int g = __builtin_ctzll(todo);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, g);
-            const Footprint fg = make_footprint(fp_sorted[jw + g], tmask_hi, gid);
-            wave_for_cells(pg, fg, rec, gid, lane, s_runs[wave], [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << g); });
+            const uint32_t gid = bcast_u32(id, g);
+            const Footprint fg = bcast_footprint(fp, g);
+            wave_for_cells(pg, fg, bcast_rows_rec(rq, g), gid, lane, s_runs[wave], [&](int cell, uint64_t) { atomicOr(&mine[cell], 1ull << g); }, &cc);
         }
         __syncthreads();
         auto place_as = [&](int cell, uint64_t m, uint32_t gid, int g) {          // entry of the batch's rank g
@@ -413,18 +532,18 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
             if (pos < ccap) cent[pos] = make_uint4(gid, 0u, (uint32_t)m, (uint32_t)(m >> 32));          // one 16-byte store per entry
         };
         auto place = [&](int cell, uint64_t m) { place_as(cell, m, id, lane); };
-        if (have && !coop) {
-            if (small) {
+        if (have && small && !coop) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) place(c4.cell[k], c4.m[k]);
-            } else for_cells(pg, fp, place);
+            for (int k = 0; k < 4; k++) if (c4.cell[k] >= 0) place(c4.cell[k], c4.m[k]);
         }
+        wave_flat_cells<2>(pg, fp, id, medium, lane, [&](int cell, uint64_t m, int o, uint32_t oid) { place_as(cell, m, oid, o); }, &fcache);          // ... and their entries
         // ... then the entries themselves
+        cc.slot = 0; cc.mode = 2;          // the same walks in the same order: slot k holds what iteration k computed
         for (uint64_t todo = coopm; todo != 0ull; todo &= todo - 1ull) {
             const int g = __builtin_ctzll(todo);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, g);
-            const Footprint fg = make_footprint(fp_sorted[jw + g], tmask_hi, gid);
-            wave_for_cells(pg, fg, rec, gid, lane, s_runs[wave], [&](int cell, uint64_t m) { place_as(cell, m, gid, g); });
+            const uint32_t gid = bcast_u32(id, g);
+            const Footprint fg = bcast_footprint(fp, g);
+            wave_for_cells(pg, fg, bcast_rows_rec(rq, g), gid, lane, s_runs[wave], [&](int cell, uint64_t m) { place_as(cell, m, gid, g); }, &cc);
         }
         __syncthreads();
         for (int c = tid; c < nc; c += PLACE_THREADS)
@@ -471,6 +590,64 @@ __global__ void __launch_bounds__(64) expand_count_kernel(const uint32_t* __rest
     chunk_cnt[(size_t)ch * 64 + lane] = cnt;
 }
 
+// Per-tile totals -> tile starts (exclusive scan, in place; [ntiles] = R) -> ranges, ONE workgroup of 16 waves.
+// Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after its memset).
+constexpr int TR_WAVES = 16;
+__global__ void __launch_bounds__(64 * TR_WAVES) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
+                                                                   uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
+                                                                   const uint32_t* __restrict__ sort_flag /* the depth sort's error word, or nullptr */,
+                                                                   uint32_t* __restrict__ host_note /* pinned HOST words or nullptr: [0] R, [2] C, [3] |= sort error, [4] = note_ticket */, uint32_t note_ticket)
+{
+    constexpr int NW = TR_WAVES;
+    __shared__ uint32_t s_wave[NW];
+    // Every wave owns a contiguous range of tiles and walks it 64 tiles at a time: coalesced loads and stores, a wave-level scan per step.
+    // (A strip of consecutive tiles per THREAD made every lane touch its own cache line, per step: 11 us at 1080p, 54 us for the 32 640 tiles
+    // of a four-view batched depth pass.)  The totals stay in registers between the summing pass and the writing pass.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_wave = ((ntiles + NW - 1) / NW + 63) / 64 * 64;          // tiles per wave, a multiple of 64
+    const int w0 = min(ntiles, wave * per_wave), w1 = min(ntiles, w0 + per_wave);
+    constexpr int KEEP = 32;                               // steps kept in registers: 16 waves x 32 steps x 64 tiles = 32 K tiles (beyond: read twice; 64 steps would spill at 1 024 threads)
+    const int nsteps = (w1 - w0 + 63) / 64;
+    uint32_t v[KEEP];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) { const int t = w0 + k * 64 + lane; v[k] = (k < nsteps && t < w1) ? tile_start[t] : 0u; sum += v[k]; }
+    for (int k = KEEP; k < nsteps; k++) { const int t = w0 + k * 64 + lane; sum += t < w1 ? tile_start[t] : 0u; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);          // the wave's total, in every lane
+    if (lane == 0) s_wave[wave] = sum;
+    __syncthreads();
+    uint32_t run = 0;                                      // tiles in front of this wave's range
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+    // clamped to the capacity of point_list: after a too small hint the render kernels must not walk past it (the call is redone)
+    auto step = [&](int k, uint32_t n) {
+        uint32_t inc = n;                                  // inclusive scan over the 64 tiles of the step
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+        const uint32_t start = run + inc - n;
+        const int t = w0 + k * 64 + lane;
+        if (t < w1) {
+            tile_start[t] = start;
+            const uint32_t a = min(start, cap), b = min(start + n, cap);
+            *reinterpret_cast<uint2*>(ranges + 2 * (size_t)t) = (b > a) ? make_uint2(a, b) : make_uint2(0u, 0u);
+        }
+        run += (uint32_t)__shfl((int)inc, 63, 64);
+    };
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) if (k < nsteps) step(k, v[k]);          // (wave-uniform condition)
+    for (int k = KEEP; k < nsteps; k++) { const int t = w0 + k * 64 + lane; step(k, t < w1 ? tile_start[t] : 0u); }
+    if (tid == NW * 64 - 1) {
+        tile_start[ntiles] = run; counters[0] = run;      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
+        // what the host looks at LATER without having queued anything for it (api.hip, round 5: the copies, events and the stream wait that carried these words
+        // cost the forward ~10 us of host time): diagnostics and the depth sort's sticky error word, stored straight into pinned host memory
+        if (host_note) {
+            host_note[0] = run; host_note[2] = counters[2]; if (sort_flag && *sort_flag) host_note[3] = 1u;
+            __threadfence_system();          // the words above are visible to the host before the ticket that says "this forward's binning has run" (api.hip: check_sort_flag)
+            __hip_atomic_store(host_note + 4, note_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // One workgroup per cell (lane = tile of the cell, CSCAN_WAVES waves): counts -> exclusive prefixes over the cell's chunks, per-tile totals.
 // Every wave takes a contiguous share of the cell's chunks: sums it (eight loads in flight), learns the sums of the waves before it
 // through LDS, then walks its share again writing the prefixes (the second read comes out of the L2).  One wave per cell walked a
@@ -506,63 +683,6 @@ __global__ void __launch_bounds__(64 * CSCAN_WAVES) cell_scan_kernel(const uint3
     }
     const int tx = (cell % cgx) * CB + (lane & 7), ty = (cell / cgx) * CB + (lane >> 3);
     if (wave == 0 && tx < gx && ty < gy) tile_total[ty * gx + tx] = total;
-}
-
-// Per-tile totals -> tile starts (exclusive scan, in place; [ntiles] = R) -> ranges, ONE workgroup: a strip of consecutive tiles per
-// thread, the 1024 strip sums scanned through LDS.  Empty tiles keep (0, 0) like identifyTileRanges (rasterizer_impl.cu:233-255 after
-// its memset).
-__global__ void __launch_bounds__(1024) tile_ranges_kernel(int ntiles, uint32_t* __restrict__ tile_start /* ntiles + 1: totals in, starts out */,
-                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ counters /* R, -, C */, uint32_t cap,
-                                                           const uint32_t* __restrict__ sort_flag /* the depth sort's error word, or nullptr */,
-                                                           uint32_t* __restrict__ host_note /* pinned HOST words or nullptr: [0] R, [2] C, [3] |= sort error, [4] = note_ticket */, uint32_t note_ticket)
-{
-    // Every wave owns a contiguous range of tiles and walks it 64 tiles at a time: coalesced loads and stores, a wave-level scan per step.
-    // (A strip of consecutive tiles per THREAD made every lane touch its own cache line, per step: 11 us at 1080p, 54 us for the 32 640 tiles
-    // of a four-view batched depth pass.)  The totals stay in registers between the summing pass and the writing pass.
-    __shared__ uint32_t s_wave[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per_wave = ((ntiles + 15) / 16 + 63) / 64 * 64;          // tiles per wave, a multiple of 64
-    const int w0 = min(ntiles, wave * per_wave), w1 = min(ntiles, w0 + per_wave);
-    constexpr int KEEP = 32;                               // steps kept in registers: 16 waves x 32 steps x 64 tiles = 32 K tiles (beyond: read twice; 64 steps would spill at 1 024 threads)
-    const int nsteps = (w1 - w0 + 63) / 64;
-    uint32_t v[KEEP];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < KEEP; k++) { const int t = w0 + k * 64 + lane; v[k] = (k < nsteps && t < w1) ? tile_start[t] : 0u; sum += v[k]; }
-    for (int k = KEEP; k < nsteps; k++) { const int t = w0 + k * 64 + lane; sum += t < w1 ? tile_start[t] : 0u; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);          // the wave's total, in every lane
-    if (lane == 0) s_wave[wave] = sum;
-    __syncthreads();
-    uint32_t run = 0;                                      // tiles in front of this wave's range
-    for (int w = 0; w < wave; w++) run += s_wave[w];
-    // clamped to the capacity of point_list: after a too small hint the render kernels must not walk past it (the call is redone)
-    auto step = [&](int k, uint32_t n) {
-        uint32_t inc = n;                                  // inclusive scan over the 64 tiles of the step
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
-        const uint32_t start = run + inc - n;
-        const int t = w0 + k * 64 + lane;
-        if (t < w1) {
-            tile_start[t] = start;
-            const uint32_t a = min(start, cap), b = min(start + n, cap);
-            *reinterpret_cast<uint2*>(ranges + 2 * (size_t)t) = (b > a) ? make_uint2(a, b) : make_uint2(0u, 0u);
-        }
-        run += (uint32_t)__shfl((int)inc, 63, 64);
-    };
-#pragma unroll
-    for (int k = 0; k < KEEP; k++) if (k < nsteps) step(k, v[k]);          // (wave-uniform condition)
-    for (int k = KEEP; k < nsteps; k++) { const int t = w0 + k * 64 + lane; step(k, t < w1 ? tile_start[t] : 0u); }
-    if (tid == 1023) {
-        tile_start[ntiles] = run; counters[0] = run;      // R as the binning counted it (the last wave ends at ntiles, whatever its own range)
-        // what the host looks at LATER without having queued anything for it (api.hip, round 5: the copies, events and the stream wait that carried these words
-        // cost the forward ~10 us of host time): diagnostics and the depth sort's sticky error word, stored straight into pinned host memory
-        if (host_note) {
-            host_note[0] = run; host_note[2] = counters[2]; if (sort_flag && *sort_flag) host_note[3] = 1u;
-            __threadfence_system();          // the words above are visible to the host before the ticket that says "this forward's binning has run" (api.hip: check_sort_flag)
-            __hip_atomic_store(host_note + 4, note_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
 }
 
 // One wave per chunk: ids to their final slots, in order.  Per round of 64 entries the wave transposes the bit matrix (row = entry,
@@ -699,7 +819,7 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     IBGS_HIP(hipGetLastError());
     hipLaunchKernelGGL(cell_scan_kernel, dim3(ncells), dim3(64 * CSCAN_WAVES), 0, s, b.cell_chunk0, ncells, cgx, gx, gy, b.chunk_cnt, b.tile_total);
     IBGS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(1024), 0, s, ntiles, b.tile_total, ranges, counters,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(1), dim3(64 * TR_WAVES), 0, s, ntiles, b.tile_total, ranges, counters,
                        (uint32_t)(cap < (int64_t)0xFFFFFFFFll ? cap : (int64_t)0xFFFFFFFFll), sort_flag, host_note, note_ticket);
     IBGS_HIP(hipGetLastError());
     return 0;
