@@ -528,12 +528,14 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
             if (nvalid <= IBGS_MAX_SRC - 1) p.valid_idx[(size_t)nvalid * HW + pix] = -1;
             // unused source slots and the mask are written too, so the caller needs no 36-plane memset per frame
             // (the reference zero-fills every output plane on each call, rasterize_points.cu:80-90)
+#ifndef IBGS_DIAG_NO_ZERO_FILL          // (diagnostic build, profiles/r06_geo_fwd_split.txt: what the zero planes cost; its outputs are NOT valid)
             for (int k = nvalid; k < IBGS_MAX_SRC; k++) {
 #pragma unroll
                 for (int ch = 0; ch < 4; ch++) p.out_cam_feat[((size_t)k * 4 + ch) * HW + pix] = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) p.out_warped[((size_t)k * 3 + ch) * HW + pix] = 0.f;
             }
+#endif
             p.out_mask[pix] = first_ok;
             p.out_min_depth_diff[pix] = min_err;
             p.out_depth[pix] = med;
