@@ -84,9 +84,11 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                      3 floats instead of 3 M, ibgs_sh_grad_from_views rebuilds the summed dL/dsh */
 
 #define IBGS_FLAG_NO_REF_POWER_SKIP 512u /* both passes: do NOT reproduce the reference's `if (power > 0.0f) continue;` (forward.cu:420,
-                                           backward.cu:645).  By default the blend kernels evaluate the reference's expression for the
-                                           Gaussians whose conic is within 1e-5 of singular (the only ones for which that test can fire,
-                                           csrc/common.h: conic_is_risky) and drop the pairs it drops; with this flag every Gaussian
+                                           backward.cu:645).  By default the blend kernels evaluate the reference's expression per pixel,
+                                           uncontracted, for every Gaussian whose conic is within 1e-3 of singular (b^2 > 0.999 a c; csrc/common.h:
+                                           conic_takes_ref_power / BLEND_REF_POWER_RISK) and drop the pairs it drops -- the test itself can only fire
+                                           within 1e-5 (conic_is_risky / POWER_RISK: those are also exempt from the tile cull); the two decades around
+                                           them take the branch so that their decisions round as the reference's do.  With this flag every Gaussian
                                            takes the fast path and such pairs are blended with alpha ~= opacity */
 
 #define IBGS_FLAG_REF_ARITH 4096u /* ibgs_backward only (SURVEY Q1 as a switch).  The pairs of a Gaussian whose conic is within 1e-3 of singular (csrc/common.h:
