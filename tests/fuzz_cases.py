@@ -130,3 +130,55 @@ def fused_case(seed, index):
     for _ in range(index):
         draw_fused(rng)
     return draw_fused(rng)
+
+
+def fused_eval(c, mask=None, builds=("plain", "fma", "f64", "acc32")):
+    """(forward outputs and parameter gradients of the HIP path through renderer.render with the fused plane glue, {build: (oracle outputs, gradients)} of the oracle
+    chain evaluated at the plane map the KERNELS built -- tests/test_gpu_fused_planes._oracle_chain(planes=...): the float64 arbiter must look at the same inputs)"""
+    from tests.test_gpu_fused_planes import _oracle_chain, _run, _scene
+    dev, g, cams, scene, pipe, args, bg = _scene(P=c["P"], W=c["W"], H=c["H"], seed=c["seed"])
+    planes = {}
+    o_fus, g_fus = _run(True, c["learnt"], g, dev, cams, scene, pipe, args, bg, planes_out=planes, mask=mask)
+    ob = {}
+    for b in builds:
+        with oracle.variant(b):
+            ob[b] = _oracle_chain(c["learnt"], g, dev, cams, scene, bg, planes=planes, mask=mask)
+    hip = {"median_depth": o_fus["median_intersected_depth"].cpu().numpy(), "warped_image": o_fus["warped_image"].cpu().numpy(), "color": o_fus["render"].cpu().numpy(),
+           "normal_map": o_fus["rendered_normal"].cpu().numpy()}
+    return hip, g_fus, ob
+
+
+def flipped_pixels(out, out64, H, W):
+    """pixels at which a forward output differs from the float64 build's by more than rounding: a decision on a rounded float fell the other way"""
+    m = np.zeros(H * W, bool)
+    for k in ("median_depth", "warped_image", "color", "normal_map"):
+        a, b = np.asarray(out[k]).reshape(-1, H * W), np.asarray(out64[k]).reshape(-1, H * W)
+        m |= np.abs(a - b).max(0) > 1e-3 * max(1e-6, float(np.abs(b).max()))
+    return m
+
+
+def fused_names(c):
+    return ["_xyz", "_rotation", "_scaling", "_opacity", "_features_dc"] + (["_normal", "_offset"] if c["learnt"] else [])
+
+
+def fused_ratio(c, g_fus, ob, floor=1e-3):
+    """(max over the parameter gradients of |HIP - f64| / max(floor, farthest fp32 oracle build), the per-gradient distances)"""
+    g64 = ob["f64"][1]
+    e = {n: (rel_l2(g_fus[n], g64[n]),) + tuple(rel_l2(ob[b][1][n], g64[n]) for b in ob if b != "f64") for n in fused_names(c) if g64[n] is not None and np.abs(g64[n]).sum() > 0}
+    return max(p[0] / max(floor, max(p[1:])) for p in e.values()), e
+
+
+def fused_verdict(c):
+    """The arbiter's verdict on one fused-glue case: dict(ratio, flips_hip, flips_oracle, masked_ratio or None).  Flipped pixels (decisions that fall differently from
+    float64's) are counted; when the kernels and the fp32 oracle flipped DIFFERENT pixels the gradients are compared again with those pixels' upstream gradients masked."""
+    H, W = c["H"], c["W"]
+    hip, g_fus, ob = fused_eval(c)
+    fh, fo = flipped_pixels(hip, ob["f64"][0], H, W), flipped_pixels(ob["plain"][0], ob["f64"][0], H, W)
+    r0, e0 = fused_ratio(c, g_fus, ob)
+    out = {"ratio": r0, "detail": e0, "flips_hip": [(int(p % W), int(p // W)) for p in np.flatnonzero(fh)], "flips_oracle": [(int(p % W), int(p // W)) for p in np.flatnonzero(fo)],
+           "masked_ratio": None, "color_l1": float(np.abs(hip["color"] - np.asarray(ob["plain"][0]["color"]).reshape(hip["color"].shape)).mean()),
+           "normal_l1": float(np.abs(hip["normal_map"] - np.asarray(ob["plain"][0]["normal_map"]).reshape(hip["normal_map"].shape)).mean())}
+    if (fh ^ fo).any():
+        hip2, g2, ob2 = fused_eval(c, mask=(fh | fo).reshape(H, W))
+        out["masked_ratio"], out["masked_detail"] = fused_ratio(c, g2, ob2)
+    return out

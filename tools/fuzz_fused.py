@@ -1,10 +1,14 @@
 """Random sweep of `renderer.render(render_geo=True)` with the plane glue fused into the kernels (not part of the suite): image, normals and every
 parameter gradient against the oracle pushed through the reference-style torch glue (tests/test_gpu_fused_planes.py's check) at random sizes and seeds.
-python tools/fuzz_fused.py [n_cases] [seed]"""
+python tools/fuzz_fused.py [n_cases] [seed]
+Round 6: a case whose gradients are more than 5e-3 from the fp32 oracle goes to the float64 arbiter AS tests/test_gpu_fuzz_pins.py RUNS IT (tests/fuzz_cases.fused_verdict): the
+oracle's builds are evaluated at the plane map the kernels built (an ulp of a normal is per cents of the depth of a pixel that sees its plane edge-on), pixels whose decisions
+fall differently from float64's are counted, and when the two fp32 evaluations flipped different pixels the comparison is repeated with those pixels masked."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
+from tests import fuzz_cases as fc
 from tests.metrics import l1, rel_l2
 from tests.test_gpu_fused_planes import _oracle_chain, _run, _scene
 
@@ -12,24 +16,22 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n_cases):
-    P = int(rng.choice([500, 2500, 6000])); W, H = int(rng.integers(96, 520)), int(rng.integers(80, 340)); seed = int(rng.integers(0, 10**6)); learnt = bool(rng.integers(0, 2))
+    c = fc.draw_fused(rng)
+    P, W, H, seed, learnt = c["P"], c["W"], c["H"], c["seed"], c["learnt"]
     dev, g, cams, scene, pipe, args, bg = _scene(P=P, W=W, H=H, seed=seed)
     o_fus, g_fus = _run(True, learnt, g, dev, cams, scene, pipe, args, bg)
     ref, g_orc = _oracle_chain(learnt, g, dev, cams, scene, bg)
     dc, dn = l1(o_fus["render"].cpu().numpy(), ref["color"]), l1(o_fus["rendered_normal"].cpu().numpy(), ref["normal_map"])
-    names = ["_xyz", "_rotation", "_scaling", "_opacity", "_features_dc"] + (["_normal", "_offset"] if learnt else [])
+    names = fc.fused_names(c)
     errs = {n: (rel_l2(g_fus[n], g_orc[n]) if g_orc[n] is not None and np.abs(g_orc[n]).sum() > 0 else float("nan")) for n in names}
     worst = max(v for v in errs.values() if v == v) if any(v == v for v in errs.values()) else 0.0
     note = ""
-    if worst >= 5e-3:
-        # the arbiter (tests/test_gpu_anisotropic.py): one decision on a rounded float -- in the fp32 oracle as easily as in the kernels -- moves a gradient of
-        # a 6 000-Gaussian scene by per cents; the float64 build of the oracle says who is off
-        with oracle.variant("f64"):
-            _, g_64 = _oracle_chain(learnt, g, dev, cams, scene, bg)
-        e64 = {n: (rel_l2(g_fus[n], g_64[n]), rel_l2(g_orc[n], g_64[n])) for n in names if errs[n] == errs[n]}
-        worst = max((a if a > max(5e-3, 2.0 * b) else 0.0) for a, b in e64.values())
-        note = " | vs float64 (HIP, oracle fp32): %s" % {k: "%.1e, %.1e" % v for k, v in e64.items()}
     ok = dc < 1e-6 and dn < 1e-5 and worst < 5e-3
+    if dc < 1e-6 and dn < 1e-5 and worst >= 5e-3:
+        v = fc.fused_verdict(c)
+        r = v["masked_ratio"] if v["masked_ratio"] is not None else v["ratio"]
+        ok = r <= 2.0 and len(v["flips_hip"]) <= len(v["flips_oracle"]) + 1
+        note = " | arbiter (same plane map): ratio %.2f, flipped pixels HIP %s oracle %s%s" % (v["ratio"], v["flips_hip"], v["flips_oracle"], (", masked ratio %.2f" % v["masked_ratio"]) if v["masked_ratio"] is not None else "")
     bad += not ok
     print("%s case %2d: P %d %dx%d seed %d learnt %d | colour %.1e normal %.1e grads %s%s" % ("ok  " if ok else "FAIL", case, P, W, H, seed, learnt, dc, dn, {k: "%.1e" % v for k, v in errs.items()}, note), flush=True)
 print("failures:", bad)
