@@ -149,21 +149,10 @@ static int stage_check(hipStream_t s, bool debug, const char* what)
 // the total, then a ticket, straight into pinned host memory; the host polls the ticket (ibgs_forward).  The four runtime calls it replaces -- event
 // record, stream wait, copy, event record -- cost the forward ~12 us of host time, and the copy engine's own latency on top.  The ticket is a kernel argument
 // (round 6: until round 5 a device word counted it, for a replay from a hipGraph that no longer exists; an argument cannot get out of step after a failed call).
-__global__ void __launch_bounds__(1024) rendered_note_kernel(const uint32_t* __restrict__ partial, uint32_t nwords, uint32_t ticket, volatile uint32_t* host_words)
+__global__ void __launch_bounds__(1024) rendered_note_kernel(RenderedNote n)
 {
     __shared__ unsigned long long s_w[16];
-    unsigned long long sum = 0;
-    for (uint32_t i = threadIdx.x; i < nwords; i += 1024) sum += partial[i];
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < 16; w++) t += s_w[w];
-        host_words[0] = (uint32_t)t; host_words[1] = (uint32_t)(t >> 32);
-        __threadfence_system();                                   // the total is visible to the host before the ticket is
-        __hip_atomic_store(const_cast<uint32_t*>(host_words) + 2, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    rendered_note_block<1024>(n, s_w);
 }
 
 }  // namespace ibgs
@@ -407,9 +396,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
           // behind the sort, by a copy on a second stream, together with the sort's error flag: on small frames the host then sat out five sort launches'
           // worth of GPU latency -- ~45 us of a 0.34 ms call pair, profiles/r05_host_split.txt -- before it could queue the loss and the backward.)
           ticket = ++rs->seq;          // (wraps after 4 G forwards on one stream: the comparison below is for equality)
-          hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, g.tile_partial, (uint32_t)nwaves, ticket, rs->host);
-          IBGS_HIP(hipGetLastError());
-          if ((rc = launch_preprocess(s, a, g, 2))) return rc;
+          const RenderedNote note{g.tile_partial, (uint32_t)nwaves, ticket, rs->host};
+          if ((rc = launch_preprocess(s, a, g, 2, &note)) < 0) return rc;          // (1: the SH colour kernel's first workgroup carries the note -- one launch fewer)
+          if (rc == 0) { hipLaunchKernelGGL(rendered_note_kernel, dim3(1), dim3(1024), 0, s, note); IBGS_HIP(hipGetLastError()); }
       }
     }
     if ((rc = stage_check(s, debug, "preprocess"))) return rc;

@@ -115,7 +115,8 @@ __device__ __forceinline__ uint64_t cell_mask(const Footprint& f, uint32_t ccx, 
 // a Gaussian reaches) are recomputed from the Gaussian's rectangle and tile mask instead of being read from an array.
 //   cell_count_kernel   one workgroup per block of G consecutive depth ranks: entries per cell (LDS histogram) -> cnt[cell][block]
 //   cell_colscan_kernel one workgroup per cell: exclusive scan over the blocks, in place; the cell's total
-//   cell_setup_kernel   one workgroup: first entry of every cell, chunk bookkeeping, C (the number of coarse entries)
+//   (cell_setup_block)  first entry of every cell, chunk bookkeeping, C (the number of coarse entries): until round 5 a one-workgroup kernel, now every place
+//                       workgroup scans the cells' totals itself and the first one stores the tables
 //   cell_place_kernel   same traversal as the count; an entry's slot = first entry of its cell + entries of earlier blocks + entries
 //                       of earlier ranks in its own block.  The last term: per batch of 64 ranks (a wave, lane = rank) every cell
 //                       collects the lanes that reach it as a 64-bit word in LDS (ds_or); rank inside the batch = set bits below
@@ -374,42 +375,75 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_count_kernel(PlaceGeom pg,
     for (int c = tid; c < pg.nc; c += PLACE_THREADS) cnt[(size_t)(pg.c0 + c) * pg.nblk + blk] = s_cnt[c];
 }
 
-// First entry of every cell + chunk bookkeeping + C, ONE workgroup (ncells <= a few thousand).
+// First entry of every cell + chunk bookkeeping + C (ncells <= a few thousand).
 // (Round 6 tried to run this as the LAST workgroup of cell_colscan_kernel -- and tile_ranges as the last workgroup of cell_scan_kernel -- behind the classic
 // fence / ticket hand-over: two launches fewer, and SLOWER: cell_colscan 7.9 -> 27.4 us, cell_scan 5.0 -> 34.6 us against the 6.5 + 9.5 us of the two
 // one-workgroup kernels saved.  The agent-scope release fence every workgroup must issue before its ticket writes the XCD's L2 back; 135 of them in a row
-// cost more than a launch.  profiles/r06_frontend.txt)
-__global__ void __launch_bounds__(256) cell_setup_kernel(uint32_t ccap, const uint32_t* __restrict__ cell_total, int ncells,
-                                                         uint32_t* __restrict__ cell_start /* ncells + 1 */,
-                                                         uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */, uint32_t* __restrict__ C_out)
+// cost more than a launch.  profiles/r06_frontend.txt.  What did work: no hand-over at all.  Every workgroup of the place kernel scans the cells' totals ITSELF
+// (a few hundred words out of L2, cell_starts below) and workgroup 0 also stores the tables the kernels behind it read -- the one-workgroup launch, 6.4 us
+// of an idle machine, is gone.)
+// The strips: thread t owns cells [t per, (t + 1) per), per = ceil(ncells / 256).  s_part <- exclusive scan of the strips' entry totals; returns the grand total.
+__device__ __forceinline__ uint32_t cell_strip_scan(const uint32_t* __restrict__ cell_total, int ncells, uint32_t* s_part /* 256 */, uint32_t* s_w /* 4 */)
 {
-    __shared__ uint32_t s_part[256], s_chunks[256];
-    // exclusive scans over the cells (sequential per thread over a strip, then over the 256 strip sums), entries first
-    const int per = (ncells + 255) / 256;
-    const int c0 = min(ncells, (int)threadIdx.x * per), c1 = min(ncells, c0 + per);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (ncells + PLACE_THREADS - 1) / PLACE_THREADS;
+    const int c0 = min(ncells, tid * per), c1 = min(ncells, c0 + per);
     uint32_t sum = 0;
     for (int c = c0; c < c1; c++) sum += cell_total[c];
-    s_part[threadIdx.x] = sum;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 256; t++) { const uint32_t v = s_part[t]; s_part[t] = run; run += v; }
-        *C_out = run;                                       // entries the frame needs; > ccap: the arena was carved for a too small hint
-        cell_start[ncells] = min(run, ccap);
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < PLACE_THREADS / 64; w++) { const uint32_t v = s_w[w]; if (w < wave) before += v; all += v; }
+    s_part[tid] = before + incl - sum;
+    __syncthreads();
+    return all;
+}
+// first entry of cell c, clamped to the capacity: the place kernel drops what does not fit, nobody reads past it, the call is redone (api.hip)
+__device__ __forceinline__ uint32_t cell_start_of(const uint32_t* __restrict__ cell_total, int ncells, const uint32_t* s_part, int c, uint32_t ccap)
+{
+    const int per = (ncells + PLACE_THREADS - 1) / PLACE_THREADS;
+    const int t = c / per;
+    uint32_t run = s_part[t];
+    for (int k = t * per; k < c; k++) run += cell_total[k];
+    return min(run, ccap);
+}
+// ... and the tables for the kernels behind the place kernel (one workgroup): cell_start, the cells' first chunks, C
+__device__ __forceinline__ void cell_setup_block(uint32_t ccap, const uint32_t* __restrict__ cell_total, int ncells, const uint32_t* s_part, uint32_t all, uint32_t* s_w,
+                                                 uint32_t* __restrict__ cell_start /* ncells + 1 */, uint32_t* __restrict__ cell_chunk0 /* ncells + 1 */, uint32_t* __restrict__ C_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (ncells + PLACE_THREADS - 1) / PLACE_THREADS;
+    const int c0 = min(ncells, tid * per), c1 = min(ncells, c0 + per);
+    if (tid == 0) {
+        *C_out = all;                                       // entries the frame needs; > ccap: the arena was carved for a too small hint
+        cell_start[ncells] = min(all, ccap);
     }
+    uint32_t run = s_part[tid], chunks = 0;
+    for (int c = c0; c < c1; c++) {
+        const uint32_t st = min(run, ccap), en = min(run + cell_total[c], ccap);
+        cell_start[c] = st; run += cell_total[c];
+        chunks += (en - st + XCHUNK - 1) / XCHUNK;
+    }
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+    __syncthreads();          // (s_w was read by everybody in cell_strip_scan)
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    // clamped to the capacity: the place kernel drops what does not fit, nobody reads past it, the call is redone (api.hip)
-    uint32_t run = s_part[threadIdx.x];
-    for (int c = c0; c < c1; c++) { cell_start[c] = min(run, ccap); run += cell_total[c]; }
-    __syncthreads();
-    sum = 0;
-    for (int c = c0; c < c1; c++) sum += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK;
-    s_chunks[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t r2 = 0; for (int t = 0; t < 256; t++) { const uint32_t v = s_chunks[t]; s_chunks[t] = r2; r2 += v; } cell_chunk0[ncells] = r2; }
-    __syncthreads();
-    run = s_chunks[threadIdx.x];
-    for (int c = c0; c < c1; c++) { cell_chunk0[c] = run; run += (cell_start[c + 1] - cell_start[c] + XCHUNK - 1) / XCHUNK; }
+    uint32_t before = 0, allc = 0;
+#pragma unroll
+    for (int w = 0; w < PLACE_THREADS / 64; w++) { const uint32_t v = s_w[w]; if (w < wave) before += v; allc += v; }
+    if (tid == 0) cell_chunk0[ncells] = allc;
+    uint32_t r2 = before + incl - chunks;
+    run = s_part[tid];
+    for (int c = c0; c < c1; c++) {
+        const uint32_t st = min(run, ccap), en = min(run + cell_total[c], ccap);
+        cell_chunk0[c] = r2; r2 += (en - st + XCHUNK - 1) / XCHUNK; run += cell_total[c];
+    }
 }
 
 // One workgroup per cell: exclusive scan of the cell's counts over the blocks, in place, and the cell's total
@@ -477,7 +511,8 @@ __device__ __forceinline__ void check_order_hint(int ntiles, const uint32_t* __r
 
 __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg, uint32_t ccap, const uint32_t* __restrict__ order0, const uint32_t* __restrict__ order1, const uint32_t* __restrict__ n_kept,
                                                                    const uint4* __restrict__ fp_sorted, const uint64_t* __restrict__ tmask_hi, const float4* __restrict__ rec,
-                                                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_start,
+                                                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cell_total, int ncells,
+                                                                   uint32_t* __restrict__ cell_start /* written by the first slice's first workgroup */, uint32_t* __restrict__ cell_chunk0, uint32_t* __restrict__ C_out,
                                                                    uint4* __restrict__ cent, int ntiles, const uint32_t* __restrict__ order_hint, uint32_t* __restrict__ meta)
 {
     // the extra workgroup (first slice only) is workgroup 0: dispatched first, it runs beside the placement instead of after it
@@ -490,7 +525,10 @@ __global__ void __launch_bounds__(PLACE_THREADS) cell_place_kernel(PlaceGeom pg,
     uint32_t* s_base = reinterpret_cast<uint32_t*>(s_place + 4 * nc);
     const uint32_t* __restrict__ order = n_kept[1] ? order1 : order0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x - (meta ? 1 : 0);
-    for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start[pg.c0 + c] + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
+    __shared__ uint32_t s_part[PLACE_THREADS], s_w4[PLACE_THREADS / 64];
+    const uint32_t all = cell_strip_scan(cell_total, ncells, s_part, s_w4);
+    for (int c = tid; c < nc; c += PLACE_THREADS) s_base[c] = cell_start_of(cell_total, ncells, s_part, pg.c0 + c, ccap) + cnt[(size_t)(pg.c0 + c) * pg.nblk + blk];
+    if (blk == 0 && pg.c0 == 0) cell_setup_block(ccap, cell_total, ncells, s_part, all, s_w4, cell_start, cell_chunk0, C_out);          // (workgroup-uniform)
     const int j1 = min((int)min((uint32_t)pg.P, *n_kept), (blk + 1) * pg.G);
     for (int j0 = blk * pg.G; j0 < j1; j0 += PLACE_THREADS) {          // uniform over the workgroup
         for (int c = tid; c < 4 * nc; c += PLACE_THREADS) s_touch[c] = 0ull;
@@ -803,15 +841,13 @@ int launch_binning(hipStream_t s, int P, int64_t cap, int gx, int gy, const Geom
     }
     hipLaunchKernelGGL(cell_colscan_kernel, dim3((unsigned)ncells), dim3(256), 0, s, pg.nblk, b.cnt, b.cell_total);
     IBGS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cell_setup_kernel, dim3(1), dim3(256), 0, s, ccap, b.cell_total, ncells, b.cell_start, b.cell_chunk0, counters + 2);
-    IBGS_HIP(hipGetLastError());
     for (pg.c0 = 0; pg.c0 < ncells; pg.c0 += PLACE_MAX_CELLS) {
         pg.nc = min(PLACE_MAX_CELLS, ncells - pg.c0);
         const bool check = meta != nullptr && pg.c0 == 0;
         size_t lds = 36u * (size_t)pg.nc;
         if (check && order_hint && ntiles <= HINT_MAX_TILES) lds = max(lds, sizeof(uint32_t) * (size_t)((ntiles + 31) / 32));
         hipLaunchKernelGGL(cell_place_kernel, dim3((unsigned)pg.nblk + (check ? 1u : 0u)), dim3(PLACE_THREADS), lds, s, pg, ccap, order, g.sort_val[1], g.offsets + P + 3, g.fp_sorted, g.tmask_hi, rec,
-                           b.cnt, b.cell_start, b.cent, ntiles, order_hint, check ? meta : nullptr);
+                           b.cnt, b.cell_total, ncells, b.cell_start, b.cell_chunk0, counters + 2, b.cent, ntiles, order_hint, check ? meta : nullptr);
         IBGS_HIP(hipGetLastError());
     }
     const unsigned nchunks_max = (unsigned)(ccap / XCHUNK + (size_t)ncells + 1);

@@ -403,7 +403,30 @@ constexpr int HYBRID_MIN_TILES = 768;
 constexpr int hybrid_max_tiles() { return 4096; }
 constexpr int hybrid_theta() { return HYBRID_THETA; }
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0);
+// The note the host waits for when it sizes the tile lists (api.hip, ibgs_forward): the per-wave tile sums of the preprocess kernel added up by ONE workgroup
+// of NT threads, the total and then a ticket stored straight into pinned, host-coherent memory.  Either rendered_note_kernel (api.hip) or -- round 6, a launch
+// fewer -- workgroup 0 of the SH colour kernel on its way in (preprocess.hip: the kernel behind the geometry kernel in the stream anyway).
+struct RenderedNote { const uint32_t* partial; uint32_t nwords; uint32_t ticket; uint32_t* host; };
+template <int NT>
+__device__ __forceinline__ void rendered_note_block(const RenderedNote& n, unsigned long long* s_w /* NT / 64 words of LDS */)
+{
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < n.nwords; i += NT) sum += n.partial[i];
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < NT / 64; w++) t += s_w[w];
+        volatile uint32_t* host_words = n.host;
+        host_words[0] = (uint32_t)t; host_words[1] = (uint32_t)(t >> 32);
+        __threadfence_system();                                   // the total is visible to the host before the ticket is
+        __hip_atomic_store(n.host + 2, n.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// phase 0: everything; 1: the geometry kernel(s) alone; 2: what phase 1 left out (the SH colours).  note (phase 2): carried by the SH kernel's first workgroup when
+// such a kernel is launched -- the return value is then 1 (0: the caller launches rendered_note_kernel itself; < 0: error)
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase = 0, const RenderedNote* note = nullptr);
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present);
 
 // device-wide primitives (scan_sort.hip)

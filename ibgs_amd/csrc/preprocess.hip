@@ -40,6 +40,7 @@ struct PreParams {
     uint32_t* sort_key; uint32_t* sort_val;
     int cull;
     uint32_t* zero_a; uint32_t zero_a_n; uint32_t* zero_b; uint32_t zero_b_n;      // words the next stages want zeroed (the depth sort's scratch, its counters)
+    RenderedNote note;          // sh_color_kernel: note.host != nullptr -> workgroup 0 adds the tile sums up for the host first (common.h)
     uint32_t* tile_partial; int partial0; int partial_err;      // tiles touched per wave: this launch's first word; the word that follows ALL waves' words (the depth sort's error flag, zeroed here)
 };
 
@@ -95,20 +96,65 @@ __device__ __forceinline__ void set_run(uint64_t (&m)[IBGS_CULL_WORDS], int star
     }
 }
 
-// The owning lane walks the rows (few rows): tile count, and the mask unless the rectangle is too large for one.
-__device__ __forceinline__ uint32_t cull_rows(const CullJob& j, uint64_t (&m)[IBGS_CULL_WORDS])
-{
-    const bool masked = j.w * j.h <= IBGS_CULL_MAX_TILES;
-    uint32_t cnt = 0;
-    for (int r = 0; r < j.h; r++) {
-        int t0, t1;
-        if (!cull_row_run(j.rows, j.y0 + r, t0, t1)) continue;
-        if (masked) set_run(m, r * j.w + (t0 - j.rows.x0), t1 - t0 + 1);
-        cnt += (uint32_t)(t1 - t0 + 1);
-    }
-    return cnt;
-}
+// ---- the row walks of one wave's 64 Gaussians (round 6: flattened) -----------------------------------------------------------------------------------
+// Until round 5 the owning lane walked the rows of its rectangle (~110 instructions per row with the IEEE square roots): a wave ran as long as its
+// TALLEST rectangle, and on a trained scene (plane-like Gaussians, log-normal sizes) that is 16 rows where the mean is 3.  Now every lane with a job parks
+// it in the wave's LDS stage (the record transpose has not started yet) and the wave walks ITEMS = (Gaussian, row) pairs, an item per lane, 64 at a time:
+// the owner of an item by binary search in the scanned row counts (six ds_bpermute), the job by a broadcast LDS read, the same cull_row_run on the same
+// numbers (common.h: it does not know who calls it), the run OR-ed into the owner's mask words in LDS.  Rectangles of more than CULL_COOP_ROWS rows are
+// still taken one at a time, a row per lane, and reduced in registers (their runs span more words than an LDS atomic per item is worth).
+// The stage row of a lane (5 quads = 20 words): [0..7] px py B det invA aq ymax ystar, [8] x0 | x1 << 16, [9] y0 | h << 16, [10] tile count, [12..19] mask.
 constexpr int CULL_COOP_ROWS = 16;          // rectangles taller than this are walked by the whole wave, one row per lane
+__device__ __forceinline__ void park_job(float4* stage_row, const CullJob& j)
+{
+    stage_row[0] = make_float4(j.rows.px, j.rows.py, j.rows.B, j.rows.det);
+    stage_row[1] = make_float4(j.rows.invA, j.rows.aq, j.rows.ymax, j.rows.ystar);
+    stage_row[2] = make_float4(__uint_as_float((uint32_t)j.rows.x0 | ((uint32_t)j.rows.x1 << 16)), __uint_as_float((uint32_t)j.y0 | ((uint32_t)j.h << 16)), 0.f, 0.f);
+    stage_row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    stage_row[4] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void fetch_job(const float4* stage_row, CullJob& j)
+{
+    const float4 q0 = stage_row[0], q1 = stage_row[1], q2 = stage_row[2];
+    j.rows.px = q0.x; j.rows.py = q0.y; j.rows.B = q0.z; j.rows.det = q0.w;
+    j.rows.invA = q1.x; j.rows.aq = q1.y; j.rows.ymax = q1.z; j.rows.ystar = q1.w;
+    const uint32_t xs = __float_as_uint(q2.x), ys = __float_as_uint(q2.y);
+    j.rows.x0 = (int)(xs & 0xFFFFu); j.rows.x1 = (int)(xs >> 16);
+    j.y0 = (int)(ys & 0xFFFFu); j.h = (int)(ys >> 16); j.w = j.rows.x1 - j.rows.x0;
+}
+// rows: this lane's row count when its rectangle goes through the flat walk (CULL_ROWS, at most CULL_COOP_ROWS rows), else 0.  The whole wave calls.
+__device__ __forceinline__ void wave_flat_rows(float4* stage, int rows, int lane)
+{
+    uint32_t* words = reinterpret_cast<uint32_t*>(stage);
+    int incl = rows;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    for (int base = 0; base < total; base += 64) {          // wave-uniform
+        const int item = base + lane;
+        int lo = 0;          // number of lanes whose inclusive count is <= item = the owner (incl is non-decreasing)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) { const int v = __shfl(incl, lo + step - 1, 64); if (v <= item) lo += step; }
+        const int owner = min(lo, 63);
+        const int r = item - (__shfl(incl, owner, 64) - __shfl(rows, owner, 64));
+        if (item < total) {
+            CullJob u;
+            fetch_job(stage + owner * 5, u);
+            int t0, t1;
+            if (cull_row_run(u.rows, u.y0 + r, t0, t1)) {
+                uint32_t* ow = words + owner * 20;
+                atomicAdd(ow + 10, (uint32_t)(t1 - t0 + 1));
+                if (u.w * u.h <= IBGS_CULL_MAX_TILES) {
+                    const int s0 = r * u.w + (t0 - u.rows.x0), e0 = s0 + (t1 - t0 + 1);          // bits [s0, e0) of the 256-bit mask
+                    for (int k = s0 >> 5; k <= (e0 - 1) >> 5; k++) {
+                        const int lo_b = max(s0, 32 * k) - 32 * k, hi_b = min(e0, 32 * k + 32) - 32 * k;
+                        atomicOr(ow + 12 + k, ((hi_b - lo_b == 32) ? ~0u : ((1u << (hi_b - lo_b)) - 1u)) << lo_b);
+                    }
+                }
+            }
+        }
+    }
+}
 
 // One thread per Gaussian. The AoS inputs (12..192 B per Gaussian) are read with plain per-lane
 // loads; a wave touches a contiguous span of each array, so every fetched line is fully used.
@@ -129,9 +175,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     float rec[REC_FLOATS];
 #pragma unroll
     for (int k = 0; k < REC_FLOATS; k++) rec[k] = 0.f;
-    int radius = 0; uint32_t ntiles = 0; uint32_t rx = 0, ry = 0; float depth = 0.f; uint8_t clampbits = 0;
-    uint64_t tmask[IBGS_CULL_WORDS] = {0, 0, 0, 0};
-    bool tall = false, big_rect = false;
+    int radius = 0; uint32_t ntiles = 0; float depth = 0.f; uint8_t clampbits = 0;
     float c6loc[6] = {0, 0, 0, 0, 0, 0};
 
     const float px3 = p.means3D[3 * i], py3 = p.means3D[3 * i + 1], pz3 = p.means3D[3 * i + 2];
@@ -143,6 +187,12 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     const float zview = vm[2] * px3 + vm[6] * py3 + vm[10] * pz3 + vm[14];
 
     bool alive = zview > 0.2f;   // !(z <= 0.2) differs only for NaN, which is culled either way
+    // (values of the first half -- up to the cull decision -- that the second half needs; the wave walks its rectangles' rows in between, all lanes together)
+    float ca = 0.f, cb = 0.f, cc = 0.f, det_inv = 0.f, pxs = 0.f, pys = 0.f;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    int walk_rows = 0;          // rows of this lane's rectangle that the wave has to walk (0: no row cull)
+    bool full_mask = false;     // every tile of the rectangle (no cull, or a conic the cull leaves alone)
+    const int lane = threadIdx.x & 63;
     if (alive) {
         // ---- 3D covariance (upper triangle) ----
         if (p.cov3D_precomp) {
@@ -189,121 +239,178 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int r = 0; r < 3; r++) SA[a][r] = S[r][0] * A[a][0] + S[r][1] * A[a][1] + S[r][2] * A[a][2];
-        const float ca = A[0][0] * SA[0][0] + A[0][1] * SA[0][1] + A[0][2] * SA[0][2] + 0.3f;
-        const float cb = A[0][0] * SA[1][0] + A[0][1] * SA[1][1] + A[0][2] * SA[1][2];
-        const float cc = A[1][0] * SA[1][0] + A[1][1] * SA[1][1] + A[1][2] * SA[1][2] + 0.3f;
+        ca = A[0][0] * SA[0][0] + A[0][1] * SA[0][1] + A[0][2] * SA[0][2] + 0.3f;
+        cb = A[0][0] * SA[1][0] + A[0][1] * SA[1][1] + A[0][2] * SA[1][2];
+        cc = A[1][0] * SA[1][0] + A[1][1] * SA[1][1] + A[1][2] * SA[1][2] + 0.3f;
         const float det = ca * cc - cb * cb;
         alive = (det != 0.0f);
         if (alive) {
-            const float det_inv = 1.f / det;
+            det_inv = 1.f / det;
             const float mid = 0.5f * (ca + cc);
             const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
             const float lam1 = mid + disc, lam2 = mid - disc;
             const float my_radius = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
-            const float pxs = ndc_to_pix(hx * pw, cam.W), pys = ndc_to_pix(hy * pw, cam.H);
+            pxs = ndc_to_pix(hx * pw, cam.W); pys = ndc_to_pix(hy * pw, cam.H);
             const int rad = (int)my_radius;
-            int x0 = clampi((int)((pxs - rad) / TILE), 0, cam.gx);
-            int y0 = clampi((int)((pys - rad) / TILE), 0, cam.gy);
-            int x1 = clampi((int)((pxs + rad + TILE - 1) / TILE), 0, cam.gx);
-            int y1 = clampi((int)((pys + rad + TILE - 1) / TILE), 0, cam.gy);
+            x0 = clampi((int)((pxs - rad) / TILE), 0, cam.gx);
+            y0 = clampi((int)((pys - rad) / TILE), 0, cam.gy);
+            x1 = clampi((int)((pxs + rad + TILE - 1) / TILE), 0, cam.gx);
+            y1 = clampi((int)((pys + rad + TILE - 1) / TILE), 0, cam.gy);
             alive = ((x1 - x0) * (y1 - y0)) != 0;
             if (alive) {
                 radius = rad; ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-#pragma unroll
-                for (int k = 0; k < IBGS_CULL_WORDS; k++) tmask[k] = ~0ull;
+                full_mask = true;
                 if (p.cull) {
                     CullJob job;
                     const int cull_mode = cull_setup(pxs, pys, ca, cc, cc * det_inv, -cb * det_inv, ca * det_inv, p.opacities[i], x0, y0, x1, y1, job);
-                    if (cull_mode == CULL_NONE) { ntiles = 0; tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull; }
+                    if (cull_mode == CULL_NONE) { ntiles = 0; full_mask = false; }
                     else if (cull_mode == CULL_AABB) ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-                    else {          // CULL_ROWS (tall rectangles: the whole wave walks them, below)
-                        tmask[0] = tmask[1] = tmask[2] = tmask[3] = 0ull;
-                        tall = job.h > CULL_COOP_ROWS;
-                        if (!tall) ntiles = cull_rows(job, tmask);
+                    else {          // CULL_ROWS: the wave walks the rows, right below
+                        full_mask = false;
+                        walk_rows = job.h;
+                        park_job(s_stage + lane * 5, job);
                     }
-                }
-                big_rect = (x1 - x0) * (y1 - y0) > 64 && (x1 - x0) * (y1 - y0) <= IBGS_CULL_MAX_TILES;          // mask words 1..3 in use
-                rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
-                depth = zview;
-                rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
-                rec[R_CA] = cc * det_inv; rec[R_CB] = -cb * det_inv; rec[R_CC] = ca * det_inv;
-                if (p.colors_precomp) {
-                    rec[R_R] = p.colors_precomp[3 * i]; rec[R_G] = p.colors_precomp[3 * i + 1]; rec[R_B] = p.colors_precomp[3 * i + 2];
-                } else if (WITH_SH && !p.depth_only) {
-                    // ---- SH -> RGB ----
-                    float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2 = pz3 - cam.campos[2];
-                    const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-                    d0 /= len; d1 /= len; d2 /= len;
-                    float B[16];
-                    int nb = 1;
-                    B[0] = kC0;
-                    if (p.D > 0) {
-                        const float x = d0, y = d1, z = d2;
-                        B[1] = -kC1 * y; B[2] = kC1 * z; B[3] = -kC1 * x; nb = 4;
-                        if (p.D > 1) {
-                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                            B[4] = kC2[0] * xy; B[5] = kC2[1] * yz; B[6] = kC2[2] * (2.0f * zz - xx - yy);
-                            B[7] = kC2[3] * xz; B[8] = kC2[4] * (xx - yy); nb = 9;
-                            if (p.D > 2) {
-                                B[9] = kC3[0] * y * (3.0f * xx - yy);
-                                B[10] = kC3[1] * xy * z;
-                                B[11] = kC3[2] * y * (4.0f * zz - xx - yy);
-                                B[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-                                B[13] = kC3[4] * x * (4.0f * zz - xx - yy);
-                                B[14] = kC3[5] * z * (xx - yy);
-                                B[15] = kC3[6] * x * (xx - 3.0f * yy);
-                                nb = 16;
-                            }
-                        }
-                    }
-                    // All coefficient loads are issued back to back (compile-time unrolled, 16-B vector loads
-                    // when rows are 16-B aligned) so that they overlap instead of one dependent wait per term.
-                    float shv[48];
-                    const float* sh = p.shs + (size_t)i * p.M * 3;
-                    const int need = 3 * nb;
-                    if (p.shs_rest) {          // DC and the rest in two arrays (the model's f_dc / f_rest as they are): plain per-lane loads
-                        const float* sr = p.shs_rest + (size_t)i * (p.M - 1) * 3;
-                        const float* sd = p.shs + (size_t)i * 3;
-#pragma unroll
-                        for (int k = 0; k < 48; k++) if (k < need) shv[k] = k < 3 ? sd[k] : sr[k - 3];
-                    } else if (p.M == 16) {
-                        const float4* r4 = reinterpret_cast<const float4*>(sh);
-#pragma unroll
-                        for (int v = 0; v < 12; v++) {
-                            if (4 * v < need) {
-                                const float4 q = r4[v];
-                                shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w;
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 48; k++) if (k < need) shv[k] = sh[k];
-                    }
-                    float col[3];
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) col[ch] = B[0] * shv[ch];
-#pragma unroll
-                    for (int k = 1; k < 16; k++) {
-                        if (k < nb) {
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++) col[ch] = col[ch] + B[k] * shv[3 * k + ch];
-                        }
-                    }
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        const float v = col[ch] + 0.5f;
-                        if (v < 0) clampbits |= (uint8_t)(1u << ch);
-                        rec[R_R + ch] = fmaxf(v, 0.0f);
-                    }
-                }
-                if (p.plane_mode) {
-                    const PlaneEval e = plane_eval(p.plane_mode, p.plane_normal, p.plane_offset, p.scales, p.rotations, i, px3, py3, pz3, cam.campos, vm);
-                    rec[R_NX] = e.ncam[0]; rec[R_NY] = e.ncam[1]; rec[R_NZ] = e.ncam[2]; rec[R_DIST] = e.dist;
-                } else if (p.all_map) {
-                    rec[R_NX] = p.all_map[5 * i]; rec[R_NY] = p.all_map[5 * i + 1]; rec[R_NZ] = p.all_map[5 * i + 2];
-                    rec[R_DIST] = p.all_map[5 * i + 4];
                 }
             }
+        }
+    }
+    // ---- the row walks, all lanes together (see wave_flat_rows above); the stage is not yet in use for the records ----
+    if (p.cull) {          // uniform
+        const bool tall = walk_rows > CULL_COOP_ROWS;
+        if (__ballot(walk_rows != 0) != 0ull) {          // wave-uniform
+            wave_flat_rows(s_stage, tall ? 0 : walk_rows, lane);
+            uint64_t todo = __ballot(tall);
+            while (todo != 0ull) {          // wave-uniform: the heavy tail of a trained scene, a per cent or two of its Gaussians -- one at a time, a row per lane
+                const int g = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                CullJob u;
+                fetch_job(s_stage + g * 5, u);
+                const bool masked = u.w * u.h <= IBGS_CULL_MAX_TILES;
+                uint64_t m[IBGS_CULL_WORDS] = {0, 0, 0, 0};
+                uint32_t cnt = 0;
+                for (int r = lane; r < u.h; r += 64) {
+                    int t0, t1;
+                    if (!cull_row_run(u.rows, u.y0 + r, t0, t1)) continue;
+                    if (masked) set_run(m, r * u.w + (t0 - u.rows.x0), t1 - t0 + 1);
+                    cnt += (uint32_t)(t1 - t0 + 1);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
+                uint32_t* ow = reinterpret_cast<uint32_t*>(s_stage) + g * 20;          // into the owner's stage row, like the flat walk's results
+                if (masked) {          // wave-uniform
+#pragma unroll
+                    for (int k = 0; k < IBGS_CULL_WORDS; k++) {
+                        uint32_t lo = (uint32_t)m[k], hi = (uint32_t)(m[k] >> 32);
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d, 64); hi |= (uint32_t)__shfl_xor((int)hi, d, 64); }
+                        if (lane == 0) { ow[12 + 2 * k] = lo; ow[13 + 2 * k] = hi; }
+                    }
+                }
+                if (lane == 0) ow[10] = cnt;
+            }
+        }
+    }
+    {   // the footprint leaves right here (rectangle + mask word 0: one 16-byte record; words 1..3 only matter -- and are only read by the binning -- for
+        // rectangles of more than 64 tiles), so that the mask is not carried through the second half
+        uint64_t tmask[IBGS_CULL_WORDS];
+        const uint32_t* ow = reinterpret_cast<const uint32_t*>(s_stage) + lane * 20;
+#pragma unroll
+        for (int k = 0; k < IBGS_CULL_WORDS; k++) tmask[k] = walk_rows != 0 ? (((uint64_t)ow[13 + 2 * k] << 32) | ow[12 + 2 * k]) : (full_mask ? ~0ull : 0ull);
+        if (walk_rows != 0) ntiles = ow[10];
+        uint32_t rx = 0, ry = 0;
+        bool big_rect = false;
+        if (alive) {
+            big_rect = (x1 - x0) * (y1 - y0) > 64 && (x1 - x0) * (y1 - y0) <= IBGS_CULL_MAX_TILES;          // mask words 1..3 in use
+            rx = pack_rect(x0, x1); ry = pack_rect(y0 + (uint32_t)p.tile_row0, y1 + (uint32_t)p.tile_row0);
+        }
+        if (valid) {
+            const int o = p.inst0 + i;            // instance slot (= i for a single view)
+            p.fp[o] = make_uint4(rx, ry, (uint32_t)tmask[0], (uint32_t)(tmask[0] >> 32));
+            if (big_rect) {
+#pragma unroll
+                for (int k = 1; k < IBGS_CULL_WORDS; k++) p.tmask_hi[(size_t)o * (IBGS_CULL_WORDS - 1) + (k - 1)] = tmask[k];
+            }
+        }
+    }
+    if (alive) {          // ---- second half: the record ----
+        depth = zview;
+        rec[R_X] = pxs; rec[R_Y] = pys; rec[R_OP] = p.opacities[i];
+        rec[R_CA] = cc * det_inv; rec[R_CB] = -cb * det_inv; rec[R_CC] = ca * det_inv;
+        if (p.colors_precomp) {
+            rec[R_R] = p.colors_precomp[3 * i]; rec[R_G] = p.colors_precomp[3 * i + 1]; rec[R_B] = p.colors_precomp[3 * i + 2];
+        } else if (WITH_SH && !p.depth_only) {
+            // ---- SH -> RGB ----
+            float d0 = px3 - cam.campos[0], d1 = py3 - cam.campos[1], d2 = pz3 - cam.campos[2];
+            const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            d0 /= len; d1 /= len; d2 /= len;
+            float B[16];
+            int nb = 1;
+            B[0] = kC0;
+            if (p.D > 0) {
+                const float x = d0, y = d1, z = d2;
+                B[1] = -kC1 * y; B[2] = kC1 * z; B[3] = -kC1 * x; nb = 4;
+                if (p.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    B[4] = kC2[0] * xy; B[5] = kC2[1] * yz; B[6] = kC2[2] * (2.0f * zz - xx - yy);
+                    B[7] = kC2[3] * xz; B[8] = kC2[4] * (xx - yy); nb = 9;
+                    if (p.D > 2) {
+                        B[9] = kC3[0] * y * (3.0f * xx - yy);
+                        B[10] = kC3[1] * xy * z;
+                        B[11] = kC3[2] * y * (4.0f * zz - xx - yy);
+                        B[12] = kC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                        B[13] = kC3[4] * x * (4.0f * zz - xx - yy);
+                        B[14] = kC3[5] * z * (xx - yy);
+                        B[15] = kC3[6] * x * (xx - 3.0f * yy);
+                        nb = 16;
+                    }
+                }
+            }
+            // All coefficient loads are issued back to back (compile-time unrolled, 16-B vector loads
+            // when rows are 16-B aligned) so that they overlap instead of one dependent wait per term.
+            float shv[48];
+            const float* sh = p.shs + (size_t)i * p.M * 3;
+            const int need = 3 * nb;
+            if (p.shs_rest) {          // DC and the rest in two arrays (the model's f_dc / f_rest as they are): plain per-lane loads
+                const float* sr = p.shs_rest + (size_t)i * (p.M - 1) * 3;
+                const float* sd = p.shs + (size_t)i * 3;
+#pragma unroll
+                for (int k = 0; k < 48; k++) if (k < need) shv[k] = k < 3 ? sd[k] : sr[k - 3];
+            } else if (p.M == 16) {
+                const float4* r4 = reinterpret_cast<const float4*>(sh);
+#pragma unroll
+                for (int v = 0; v < 12; v++) {
+                    if (4 * v < need) {
+                        const float4 q = r4[v];
+                        shv[4 * v] = q.x; shv[4 * v + 1] = q.y; shv[4 * v + 2] = q.z; shv[4 * v + 3] = q.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 48; k++) if (k < need) shv[k] = sh[k];
+            }
+            float col[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) col[ch] = B[0] * shv[ch];
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                if (k < nb) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) col[ch] = col[ch] + B[k] * shv[3 * k + ch];
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float v = col[ch] + 0.5f;
+                if (v < 0) clampbits |= (uint8_t)(1u << ch);
+                rec[R_R + ch] = fmaxf(v, 0.0f);
+            }
+        }
+        if (p.plane_mode) {
+            const PlaneEval e = plane_eval(p.plane_mode, p.plane_normal, p.plane_offset, p.scales, p.rotations, i, px3, py3, pz3, cam.campos, vm);
+            rec[R_NX] = e.ncam[0]; rec[R_NY] = e.ncam[1]; rec[R_NZ] = e.ncam[2]; rec[R_DIST] = e.dist;
+        } else if (p.all_map) {
+            rec[R_NX] = p.all_map[5 * i]; rec[R_NY] = p.all_map[5 * i + 1]; rec[R_NZ] = p.all_map[5 * i + 2];
+            rec[R_DIST] = p.all_map[5 * i + 4];
         }
     }
     if (!alive) {
@@ -312,7 +419,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     }
     {   // the 64-byte records leave through LDS: a lane storing its own record spreads every store instruction over 64 lines; transposed, the
         // wave writes its 4 KB as four fully coalesced 1 KB stores
-        const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 4; k++) s_stage[lane * 5 + k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
         const int first = blockIdx.x * blockDim.x + (threadIdx.x & ~63);          // this wave's Gaussians are [first, first + 64) cut at P
@@ -324,51 +430,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
             if (row < nrow) out[q] = s_stage[row * 5 + (q & 3)];
         }
     }
-    // Tall rectangles (more than CULL_COOP_ROWS tile rows: the heavy tail of a trained scene, a per cent or two of its Gaussians) are walked by
-    // the WHOLE WAVE, one row per lane, Gaussian after Gaussian: a lane walking 68 rows on its own keeps the other 63 waiting (~150
-    // instructions per row with IEEE square roots and divisions).  Same runs, same masks: cull_row_run does not know who calls it.
-    {
-        const int lane = threadIdx.x & 63;
-        uint64_t todo = __ballot(valid && alive && tall);
-        while (todo != 0ull) {          // wave-uniform
-            const int g = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            // the job is rebuilt from the owner's record and rectangle (values that are live anyway; the same operations on the same numbers
-            // as in cull_setup) instead of being carried in eleven registers through the rest of the kernel; the record itself is dead by now
-            const float4 gq0 = s_stage[g * 5], gq1 = s_stage[g * 5 + 1];          // the owner's record, still parked in LDS from the transpose above
-            const float gpx = gq0.x, gpy = gq0.y, go = gq0.z, gA = gq1.x, gB = gq1.y, gC = gq1.z;
-            const uint32_t grx = (uint32_t)__builtin_amdgcn_readlane((int)rx, g), gry = (uint32_t)__builtin_amdgcn_readlane((int)ry, g);
-            CullJob u;
-            cull_rows_setup_conic(u.rows, gpx, gpy, gA, gB, gC, cull_qmax(go), (int)(grx & 0xFFFFu), (int)(grx >> 16));
-            u.y0 = (int)(gry & 0xFFFFu) - p.tile_row0; u.w = (int)(grx >> 16) - (int)(grx & 0xFFFFu); u.h = (int)(gry >> 16) - (int)(gry & 0xFFFFu);
-            const bool masked = u.w * u.h <= IBGS_CULL_MAX_TILES;
-            uint64_t m[IBGS_CULL_WORDS] = {0, 0, 0, 0};
-            uint32_t cnt = 0;
-            for (int r = lane; r < u.h; r += 64) {
-                int t0, t1;
-                if (!cull_row_run(u.rows, u.y0 + r, t0, t1)) continue;
-                if (masked) set_run(m, r * u.w + (t0 - u.rows.x0), t1 - t0 + 1);
-                cnt += (uint32_t)(t1 - t0 + 1);
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
-            if (masked) {          // wave-uniform
-#pragma unroll
-                for (int k = 0; k < IBGS_CULL_WORDS; k++) {
-                    uint32_t lo = (uint32_t)m[k], hi = (uint32_t)(m[k] >> 32);
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d, 64); hi |= (uint32_t)__shfl_xor((int)hi, d, 64); }
-                    m[k] = ((uint64_t)hi << 32) | lo;
-                }
-            }
-            if (lane == g) {
-                ntiles = cnt;
-#pragma unroll
-                for (int k = 0; k < IBGS_CULL_WORDS; k++) tmask[k] = m[k];
-            }
-        }
-    }
-
     if (p.alive64) {          // (a full-wave ballot: lanes past the end are still here)
         const uint64_t am = __ballot(valid && alive && ntiles > 0);
         if ((threadIdx.x & 63) == 0) p.alive64[gi >> 6] = am;
@@ -385,12 +446,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_kernel(PreParams p, Cam cam
     const int o = p.inst0 + i;            // instance slot (= i for a single view)
     p.radii[o] = radius;
     p.tiles[o] = ntiles;
-    // rectangle + mask word 0: one 16-byte record; words 1..3 only matter (and are only read by the binning) for rectangles of more than 64 tiles
-    p.fp[o] = make_uint4(rx, ry, (uint32_t)tmask[0], (uint32_t)(tmask[0] >> 32));
-    if (big_rect) {
-#pragma unroll
-        for (int k = 1; k < IBGS_CULL_WORDS; k++) p.tmask_hi[(size_t)o * (IBGS_CULL_WORDS - 1) + (k - 1)] = tmask[k];
-    }
     p.depths[o] = depth;
     p.clamped[o] = clampbits;
     if (!p.cov3D_precomp) {
@@ -419,6 +474,10 @@ template <bool SPLIT>          // SPLIT: DC and rest coefficients in two arrays 
 __global__ void __launch_bounds__(256) sh_color_kernel(PreParams p, Cam cam)
 {
     __shared__ float s_sh_all[4][32 * SHC_ROW];
+    if (p.note.host != nullptr && blockIdx.x == 0) {          // (workgroup-uniform) R for the host, before anything else: it sizes the tile lists with it
+        __shared__ unsigned long long s_note[4];
+        rendered_note_block<256>(p.note, s_note);
+    }
     float* s_sh = s_sh_all[threadIdx.x >> 6];          // private to the wave (LDS operations of one wave execute in order)
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -565,9 +624,11 @@ static bool preprocess_is_split(const ibgs_forward_args& a)          // geometry
     return a.shs && !a.colors_precomp && !a.render_depth_only;
 }
 
-int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase)
+int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState& g, int phase, const RenderedNote* note)
 {   // phase 0: everything; 1: the geometry kernel(s) alone -- after them the tiles-touched sums are final; 2: what phase 1 left out (the SH colours)
     PreParams p;
+    p.note = RenderedNote{nullptr, 0u, 0u, nullptr};
+    int carried = 0;
     p.P = a.P; p.D = a.D; p.M = a.M;
     p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.opacities = a.opacities;
     p.shs = a.shs; p.shs_rest = a.shs_rest; p.cov3D_precomp = a.cov3D_precomp; p.colors_precomp = a.colors_precomp; p.all_map = a.all_map;
@@ -597,13 +658,14 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         if (split) {
             if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
             if (phase != 1) {
+                if (note && !carried) { p.note = *note; carried = 1; } else p.note.host = nullptr;          // (the first view's launch carries it)
                 if (p.shs_rest) hipLaunchKernelGGL(sh_color_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
                 else hipLaunchKernelGGL(sh_color_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, p, cam);
             }
         } else if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);          // (no_sh: nothing else can get here)
     }
     IBGS_HIP(hipGetLastError());
-    return 0;
+    return carried;
 }
 
 int launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* vm, uint8_t* present)
