@@ -653,7 +653,7 @@ int launch_preprocess(hipStream_t s, const ibgs_forward_args& a, const GeomState
         const bool split = preprocess_is_split(a);
         p.alive64 = split ? g.alive64 : nullptr;
         // no SH evaluation at all (depth-only passes, precomputed colours): the geometry kernel alone -- the one-kernel form carries the SH path's
-        // registers (120 VGPRs, 4 waves per SIMD against 65 / 7) whether it runs or not: 73 -> ~50 us per source view of a test-time frame
+        // registers (120 VGPRs, 4 waves per SIMD against 78 / 6 -- 65 / 7 until the row walk was flattened --) whether it runs or not: 73 -> ~50 us per source view of a test-time frame
         const bool no_sh = a.render_depth_only || a.colors_precomp || !a.shs;
         if (split) {
             if (phase != 2) hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, s, p, cam);
