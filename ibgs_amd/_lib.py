@@ -114,7 +114,7 @@ EXPORTS = ["ibgs_required_geom", "ibgs_required_img", "ibgs_required_binning", "
            "ibgs_forward", "ibgs_backward", "ibgs_mark_visible", "ibgs_tile_order_slots",
            "ibgs_geom_offset", "ibgs_img_offset", "ibgs_binning_offset",
            "ibgs_sizeof_forward_args", "ibgs_sizeof_backward_args", "ibgs_timing_enable", "ibgs_timing_collect",
-           "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step",
+           "ibgs_required_knn", "ibgs_knn_mean_dist2", "ibgs_sh_grad_from_views", "ibgs_adam_step", "ibgs_adam_step_sh",
            "ibgs_required_compact", "ibgs_compact_plan", "ibgs_compact_apply", "ibgs_densify_stats", "ibgs_required_deterministic", "ibgs_required_geo_table", "ibgs_required_deterministic_for", "ibgs_required_geo_table_for", "ibgs_last_forward_stats", "ibgs_check_async",
            "ibgs_required_l1", "ibgs_l1_loss", "ibgs_l1_grad", "ibgs_l1_rescale",
            "ibgs_depth_normal_forward", "ibgs_depth_normal_backward", "ibgs_activate_forward", "ibgs_activate_backward",
@@ -175,6 +175,9 @@ def load():
     lib.ibgs_sh_grad_from_views.argtypes = [ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     lib.ibgs_adam_step.restype = ctypes.c_int32
     lib.ibgs_adam_step.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.ibgs_adam_step_sh.restype = ctypes.c_int32
+    lib.ibgs_adam_step_sh.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.ibgs_tile_order_slots.restype = ctypes.c_size_t
     lib.ibgs_tile_order_slots.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.ibgs_required_l1.restype = ctypes.c_size_t

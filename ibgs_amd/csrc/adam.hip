@@ -5,24 +5,14 @@
 // HBM-bound: 7 floats of traffic per parameter (p, g, m, v read; p, m, v written); 16-byte vector accesses.
 #include <cmath>
 #include "common.h"
+#include "adam_math.h"          // AdamDev, adam_one: shared with the SH-from-factors step (preprocess_bwd.hip)
 
 namespace ibgs {
 
-// per-tensor constants as the kernel uses them: every scalar is rounded to fp32 exactly once, like torch's kernels do
-struct AdamDev { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long numel; float b2, omb1, omb2, step_size, inv_bc2_sqrt, eps; };
 struct AdamTable { AdamDev t[IBGS_ADAM_MAX_TENSORS]; unsigned long long first_block[IBGS_ADAM_MAX_TENSORS + 1]; int n; };
 
 constexpr int ADAM_THREADS = 256, ADAM_VEC = 4, ADAM_ITEMS = 4;            // 4096 floats per workgroup
 constexpr size_t ADAM_CHUNK = (size_t)ADAM_THREADS * ADAM_VEC * ADAM_ITEMS;
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamDev& d)
-{
-    const float step_size = d.step_size, eps = d.eps;
-    m = m + d.omb1 * (g - m);                      // torch: exp_avg.lerp_(grad, 1 - beta1)
-    v = d.b2 * v + d.omb2 * g * g;                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-    const float denom = sqrtf(v) * d.inv_bc2_sqrt + eps;
-    p = p - step_size * (m / denom);               // param.addcdiv_(exp_avg, denom, value = -step_size)
-}
 
 __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamTable tab)
 {
@@ -72,10 +62,7 @@ extern "C" int32_t ibgs_adam_step(void* stream, int32_t n_tensors, const ibgs_ad
         if (d.numel <= 0) continue;
         if (!d.param || !d.grad || !d.exp_avg || !d.exp_avg_sq) { set_error("ibgs_adam_step: null pointer in tensor %d", k); return -IBGS_ERR_INVALID; }
         if (!(d.bias_correction1 > 0.f) || !(d.bias_correction2 > 0.f)) { set_error("ibgs_adam_step: bias corrections must be positive"); return -IBGS_ERR_INVALID; }
-        AdamDev& o = tab.t[tab.n];
-        o.param = d.param; o.grad = d.grad; o.exp_avg = d.exp_avg; o.exp_avg_sq = d.exp_avg_sq; o.numel = d.numel;
-        o.b2 = (float)d.beta2; o.omb1 = (float)(1.0 - d.beta1); o.omb2 = (float)(1.0 - d.beta2);
-        o.step_size = (float)(d.lr / d.bias_correction1); o.inv_bc2_sqrt = (float)(1.0 / sqrt(d.bias_correction2)); o.eps = (float)d.eps;
+        tab.t[tab.n] = adam_dev_from(d);
         tab.first_block[tab.n] = blocks; tab.n++;
         blocks += ((unsigned long long)d.numel + ADAM_CHUNK - 1) / ADAM_CHUNK;
     }

@@ -7,6 +7,7 @@
 // the 64-byte accumulation row written by render_bwd.hip (one coalesced line per Gaussian) and writes
 // every output of the operator in the reference's layout (rasterize_points.cu:209-219).
 #include "common.h"
+#include "adam_math.h"          // AdamDev, adam_one (adam_sh_kernel below)
 
 namespace ibgs {
 
@@ -565,4 +566,101 @@ int launch_sh_grad_from_views(hipStream_t s, int P, int D, int M, int n_views, c
     return 0;
 }
 
+// ---- the optimiser step of the SH coefficients straight from the factors (round 6) --------------------------------------------------------------------
+// A single-GPU trainer with FusedAdam (optim.py) pays for dL/dsh twice: preprocess_bwd writes the dense (P, 16, 3) gradient -- 192 B per Gaussian, two thirds of
+// everything that kernel writes -- and the Adam kernel reads it back, although for one view it is the outer product basis(dir) x dL/dRGB of 3 + 3 floats.  Here the
+// gradient of a workgroup's 64 Gaussians is rebuilt in LDS (the loop of sh_grad_from_views_kernel above: the same products, summed over the views in index order)
+// and consumed on the spot by the update of the coefficient tensors -- `f_dc` (P, 1, 3) and `f_rest` (P, M - 1, 3) with their own learning rates, or one combined
+// (P, M, 3) tensor: tensor t holds coefficients k0[t] .. k0[t] + K[t] - 1 of every Gaussian.  The update is adam_math.h's, so parameters and moments are bit-identical
+// to ibgs_sh_grad_from_views + ibgs_adam_step (tests/test_gpu_adam.py).  HBM-bound like adam_kernel: 6 floats of traffic per coefficient instead of 7 + the write.
+struct AdamShParams {
+    int P, D, n_views, n; size_t view_stride;
+    const float* means3D; const float* camposes; const float* dcolor;
+    AdamDev t[2]; int k0[2], K3[2]; uint32_t inv24[2];          // K3 = 3 K; inv24 = ceil(2^24 / K3): e / K3 == (e * inv24) >> 24 for e < 64 K3 (K <= 16)
+};
+constexpr int ASH_ROW = 49;          // LDS words per Gaussian: 48 gradient values + 1 of padding
+__global__ void __launch_bounds__(256) adam_sh_kernel(AdamShParams q)
+{
+    __shared__ float s_g[64 * ASH_ROW];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * 64;
+    if (tid < 64) {
+        const int i = i0 + tid;
+        float acc[48];
+#pragma unroll
+        for (int k = 0; k < 48; k++) acc[k] = 0.f;
+        if (i < q.P) {
+            const float mx = q.means3D[3 * i], my = q.means3D[3 * i + 1], mz = q.means3D[3 * i + 2];
+            for (int v = 0; v < q.n_views; v++) {
+                const float* g = q.dcolor + (size_t)v * q.view_stride + (size_t)i * 3;
+                const float g0 = g[0], g1 = g[1], g2 = g[2];
+                const float dx = mx - q.camposes[3 * v], dy = my - q.camposes[3 * v + 1], dz = mz - q.camposes[3 * v + 2];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                float B[16];
+                const int nb = sh_basis(q.D, dx / len, dy / len, dz / len, B);
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < nb) { acc[3 * k] += B[k] * g0; acc[3 * k + 1] += B[k] * g1; acc[3 * k + 2] += B[k] * g2; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 48; k++) s_g[tid * ASH_ROW + k] = acc[k];
+    }
+    __syncthreads();
+    const int nrows = min(64, q.P - i0);
+    for (int t = 0; t < q.n; t++) {          // uniform
+        const AdamDev d = q.t[t];
+        const int K3 = q.K3[t], off = 3 * q.k0[t];
+        const uint32_t inv = q.inv24[t];
+        const size_t base = (size_t)i0 * K3;          // (a multiple of 64 floats: the slab starts 16-byte aligned whenever the tensor does)
+        const int count = nrows * K3;
+        auto grad_of = [&](int e) { const int r = (int)(((uint32_t)e * inv) >> 24); return s_g[r * ASH_ROW + off + (e - r * K3)]; };
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(d.param) | reinterpret_cast<uintptr_t>(d.exp_avg) | reinterpret_cast<uintptr_t>(d.exp_avg_sq)) & 15u) == 0;
+        const int nvec = vec_ok ? (count & ~3) : 0;
+        for (int e = tid * 4; e < nvec; e += 256 * 4) {
+            float4 p = *reinterpret_cast<float4*>(d.param + base + e);
+            float4 m = *reinterpret_cast<float4*>(d.exp_avg + base + e), v = *reinterpret_cast<float4*>(d.exp_avg_sq + base + e);
+            adam_one(p.x, grad_of(e), m.x, v.x, d);
+            adam_one(p.y, grad_of(e + 1), m.y, v.y, d);
+            adam_one(p.z, grad_of(e + 2), m.z, v.z, d);
+            adam_one(p.w, grad_of(e + 3), m.w, v.w, d);
+            *reinterpret_cast<float4*>(d.param + base + e) = p;
+            *reinterpret_cast<float4*>(d.exp_avg + base + e) = m; *reinterpret_cast<float4*>(d.exp_avg_sq + base + e) = v;
+        }
+        for (int e = nvec + tid; e < count; e += 256) {
+            float p = d.param[base + e], m = d.exp_avg[base + e], v = d.exp_avg_sq[base + e];
+            adam_one(p, grad_of(e), m, v, d);
+            d.param[base + e] = p; d.exp_avg[base + e] = m; d.exp_avg_sq[base + e] = v;
+        }
+    }
+}
+
 }  // namespace ibgs
+
+extern "C" int32_t ibgs_adam_step_sh(void* stream, int32_t P, int32_t D, int32_t n_views, const float* means3D, const float* camposes, const float* dcolor,
+                                     int64_t view_stride, int32_t n_tensors, const ibgs_adam_tensor* tensors, const int32_t* first_coeff, const int32_t* n_coeff)
+{
+    using namespace ibgs;
+    if (P <= 0 || n_tensors <= 0) return 0;
+    if (n_tensors > 2 || !tensors || !first_coeff || !n_coeff) { set_error("ibgs_adam_step_sh: 1 or 2 coefficient tensors"); return -IBGS_ERR_INVALID; }
+    if (D < 0 || D > 3 || n_views < 1 || !means3D || !camposes || !dcolor) { set_error("ibgs_adam_step_sh: D in 0..3, n_views >= 1, non-null factors"); return -IBGS_ERR_INVALID; }
+    AdamShParams q;
+    q.P = P; q.D = D; q.n_views = n_views; q.n = 0; q.view_stride = view_stride > 0 ? (size_t)view_stride : (size_t)P * 3;
+    q.means3D = means3D; q.camposes = camposes; q.dcolor = dcolor;
+    for (int t = 0; t < n_tensors; t++) {
+        const ibgs_adam_tensor& d = tensors[t];
+        const int k0 = first_coeff[t], K = n_coeff[t];
+        if (K <= 0) continue;
+        if (k0 < 0 || k0 + K > 16) { set_error("ibgs_adam_step_sh: tensor %d holds coefficients %d .. %d (of 16)", t, k0, k0 + K - 1); return -IBGS_ERR_INVALID; }
+        if (!d.param || !d.exp_avg || !d.exp_avg_sq || d.numel != (int64_t)P * K * 3) { set_error("ibgs_adam_step_sh: tensor %d must hold P x %d x 3 floats", t, K); return -IBGS_ERR_INVALID; }
+        if (!(d.bias_correction1 > 0.f) || !(d.bias_correction2 > 0.f)) { set_error("ibgs_adam_step_sh: bias corrections must be positive"); return -IBGS_ERR_INVALID; }
+        q.t[q.n] = adam_dev_from(d); q.t[q.n].grad = nullptr;
+        q.k0[q.n] = k0; q.K3[q.n] = 3 * K; q.inv24[q.n] = (uint32_t)(((1u << 24) + 3u * (uint32_t)K - 1u) / (3u * (uint32_t)K));
+        q.n++;
+    }
+    if (q.n == 0) return 0;
+    hipLaunchKernelGGL(adam_sh_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q);
+    IBGS_HIP(hipGetLastError());
+    return 0;
+}

@@ -333,6 +333,15 @@ typedef struct ibgs_adam_tensor {
     double bias_correction1, bias_correction2;      /* 1 - beta1^step, 1 - beta2^step */
 } ibgs_adam_tensor;
 int32_t ibgs_adam_step(void* stream, int32_t n_tensors, const ibgs_adam_tensor* tensors);
+/* ... and the SH coefficients straight from the per-view factors of IBGS_FLAG_SH_FACTORED backwards (round 6): what ibgs_sh_grad_from_views followed by
+ * ibgs_adam_step computes for them -- bit for bit --, without the dense P x M x 3 gradient ever being written or read (192 of the ~285 bytes per Gaussian that
+ * ibgs_backward's per-Gaussian kernel writes, and 1/7 of the optimiser step's traffic on these tensors).  means3D, camposes, dcolor, view_stride, D, n_views as for
+ * ibgs_sh_grad_from_views.  1 or 2 tensors: tensor t holds coefficients first_coeff[t] .. first_coeff[t] + n_coeff[t] - 1 of every Gaussian (P x n_coeff[t] x 3
+ * floats; the reference's `_features_dc` = {0, 1} and `_features_rest` = {1, 15}, each with its own learning rate; a combined P x 16 x 3 tensor = {0, 16});
+ * `grad` of the tensors is ignored.  Coefficients above the active degree D receive a zero gradient (their moments still decay, as under torch.optim.Adam).
+ * No reference counterpart: train.py runs torch.optim.Adam on the dense gradient. */
+int32_t ibgs_adam_step_sh(void* stream, int32_t P, int32_t D, int32_t n_views, const float* means3D, const float* camposes, const float* dcolor,
+                          int64_t view_stride, int32_t n_tensors, const ibgs_adam_tensor* tensors, const int32_t* first_coeff, const int32_t* n_coeff);
 
 /* The photometric L1 term of the trainer's loss, l1_loss(image, gt) = |image - gt|.mean() (utils/loss_utils.py:23-24, train.py:302),
  * value and gradient in ONE pass over the image: *loss = mean |x - y|, grad[i] = sign(x[i] - y[i]) / n (grad may be NULL: value only).
