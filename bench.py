@@ -570,10 +570,13 @@ class TrainIteration:
             "normal": "_normal", "offset": "_offset"}
     LRS = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20.0, "opacity": 2.5e-2, "scaling": 5e-3, "rotation": 1e-3, "normal": 1e-3, "offset": 1.6e-5}   # arguments/__init__.py:90-98
 
-    def __init__(self, dev, c, opt_cls, full=False):
+    def __init__(self, dev, c, opt_cls, full=False, sh_factored=False):
         from ibgs_amd import densify, renderer, simple_scene
         self.renderer = renderer
         self.full = bool(full)
+        # sh_factored (FusedAdam only, round 6): the backward leaves dL/dsh unwritten and optimizer.step() updates the SH coefficients straight from its factors
+        # (ibgs_amd/optim.py: 192 B per Gaussian neither written nor read back) -- a two-line change of the trainer, INTEGRATION.md
+        self.sh_factored = bool(sh_factored)
         P, W, H = c["P"], c["W"], c["H"]
         self.P, self.dev = P, dev
         g = syn.make_gaussians(P, c["seed"], sh_degree=3, max_coeffs=16, opacity="trained", anisotropy="plane", scale_sigma=1.0, cluster=0.3)
@@ -609,13 +612,21 @@ class TrainIteration:
             masked = valid * warped + (1 - valid) * ref
             l1p = torch.abs(ref - masked).mean(1)
             loss = loss + 0.3 * (torch.sum(l1p * valid[:, 0]) / torch.sum(valid[:, 0]).clamp(min=1.0))
-        loss.backward()
+        if self.sh_factored:
+            from ibgs_amd import rasterizer as _rz
+            with _rz.capture_sh_factors() as sh_items:
+                loss.backward()
+        else:
+            loss.backward()
         with torch.no_grad():
             scene.rendered_depth_list[k] = out["median_intersected_depth"].detach()
             # max_radii2D + add_densification_stats (train.py:400-405) in one launch (`densify.add_densification_stats`; the reference's five boolean-indexed
             # updates each stop the host for an index count)
             self.densify.add_densification_stats(st, out["viewspace_points"], out["viewspace_points_abs"], out["radii"])
-        self.opt.step()
+        if self.sh_factored:
+            self.opt.step(sh_factors=sh_items, sh_params=(self.pc._features_dc, self.pc._features_rest), means3D=self.pc._xyz)
+        else:
+            self.opt.step()
         self.opt.zero_grad(set_to_none=True)
 
     def densify_pass(self, keep):
@@ -635,8 +646,9 @@ def train_iter(dev, c, steps):
     torch.optim.Adam; and one `compact_append` pass (1 % of the points pruned, as many appended) as the trainer runs it every 100th iteration.  Never `value`."""
     from ibgs_amd.optim import FusedAdam
     res = {}
-    for name, opt_cls, full in (("fused_adam", FusedAdam, False), ("torch_adam", torch.optim.Adam, False), ("full_fused_adam", FusedAdam, True)):
-        ti = TrainIteration(dev, c, opt_cls, full=full)
+    for name, opt_cls, full, shf in (("fused_adam", FusedAdam, False, False), ("torch_adam", torch.optim.Adam, False, False), ("full_fused_adam", FusedAdam, True, False),
+                                     ("fused_adam_sh_factored", FusedAdam, False, True), ("full_fused_adam_sh_factored", FusedAdam, True, True)):
+        ti = TrainIteration(dev, c, opt_cls, full=full, sh_factored=shf)
         wall = timed_wall_ms(ti, steps, warmup=10)
         ksum = gpu_kernel_sum_ms(ti, 4)
         res[name] = {"ms_per_iter": wall, "kernel_sum_ms": ksum, "host_exposed_ms": None if ksum is None else max(0.0, wall - ksum)}
@@ -661,7 +673,9 @@ def train_iter(dev, c, steps):
     res["which_is_train_py"] = ("fused_adam / torch_adam: the loss is L1 on `render` alone = train.py's 2 x len(cameras) warm-in iterations of the geo pass (no upstream gradient for normal map, "
                                 "median depth, warped images; the window pass of the backward is skipped).  full_fused_adam: train.py's steady state (iteration > 7000): + normal consistency "
                                 "(train.py:309-316) + multi-view photometric L1 on 3 sources (train.py:319-338), all four upstream gradients reach the rasterizer backward and the depth -> normal "
-                                "backward runs; NOT included: the two SSIM terms (out of scope) and the colour-aggregation network")
+                                "backward runs; NOT included: the two SSIM terms (out of scope) and the colour-aggregation network.  *_sh_factored: the same two iterations with the trainer's "
+                                "backward inside `rasterizer.capture_sh_factors()` and `optimizer.step(sh_factors=...)`: the dense dL/dsh (192 B per Gaussian) is neither written by the "
+                                "backward nor read by the optimiser; parameters bit-identical to the expanded gradient's (tests/test_gpu_adam.py)")
     res["steps"] = steps
     return res
 

@@ -9,6 +9,8 @@ bash tools/profile_round.sh r06geo --geo > gpurun_out/r06_final/profile_r06geo.l
 bash tools/profile_round.sh r06tg --opacity trained --cluster 0.3 --anisotropy plane --scale-sigma 1.0 --geo > gpurun_out/r06_final/profile_r06tg.log 2>&1
 python tools/train_iter_profile.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_final/train_iter_kernels.txt
 python tools/train_iter_profile.py full 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_final/train_iter_full_kernels.txt
+python tools/train_iter_profile.py sh_factored 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_final/train_iter_sh_factored_kernels.txt
+python tools/train_iter_profile.py full sh_factored 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_final/train_iter_full_sh_factored_kernels.txt
 # the counter CSVs are large: keep what profiles/summarize.py reads
 find gpurun_out -name "*kernel_trace.csv" -path "*r06*" -delete 2>/dev/null
 du -sh gpurun_out | tail -1
