@@ -12,11 +12,11 @@
 // In torch that is ~25 kernels per call (two aranges, a meshgrid, a stack, a (HW x 3) @ (3 x 3) product through rocBLAS -- 128 us for a 1080p
 // image on MI355X, profiles/r05_train_iter_kernels.txt --, an LU inversion, slices, cross, norm, pad, permute, norm, div) and as many again in the
 // backward: ~0.3 ms of a 3.1 ms trainer iteration.  Here: one pixel-parallel kernel each way, bound by its HBM traffic (forward 4 + 12 B per pixel,
-// backward 4 + 12 + 4 B; the 3 x 3 / 13-point stencils come out of L1 / L2).
+// backward 4 + 12 + 4 B; the 3 x 3 / 13-point stencils come out of L1 / L2; the backward shares its per-pixel edge gradients through LDS: see its kernel).
 //
 // The backward is the exact derivative of the expression above (both normalisations, the clamp branch of F.normalize included), written as a GATHER:
-// the depth of pixel q enters the normals of its four neighbours p (as their right / left / top / bottom point), so q recomputes dL/d(P_r - P_l) and
-// dL/d(P_t - P_b) of each of them from the 13 depths around it -- no atomics, no intermediate buffer, bit-reproducible.
+// the depth of pixel q enters the normals of its four neighbours p (as their right / left / top / bottom point), so q takes dL/d(P_r - P_l) and
+// dL/d(P_t - P_b) of each of them (computed once per pixel of a tile and its halo, parked in LDS) -- no atomics, no buffer in memory, bit-reproducible.
 #include "common.h"
 
 namespace ibgs {
@@ -93,20 +93,41 @@ __device__ __forceinline__ void dn_grad_edges(const DnCam& c, const float* __res
     gb = cross3(gc, a);
 }
 
+// One workgroup per tile of 64 x 8 pixels.  Round 6: until then every pixel recomputed dL/da, dL/db of its four neighbours (dn_grad_edges: ~300 instructions with its
+// three square roots and a dozen IEEE divisions) -- four evaluations per pixel, 75 us for a 1080p image, VALU-bound at 5 x its forward.  Now a pixel's pair is
+// evaluated ONCE, parked in LDS, and read by the four neighbours that need it: 512 own pixels + 16 (left / right halo, dL/da only matters) + 128 (top / bottom halo,
+// dL/db) = 1.28 evaluations per pixel.  Same expression per evaluation, same order of the four terms: the gradient is what it was.
+constexpr int DN_TW = 64, DN_TH = 8;
 __global__ void __launch_bounds__(256) depth_normal_bwd_kernel(DnCam c, const float* __restrict__ depth, const float* __restrict__ g, float* __restrict__ gdepth)
 {
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u >= c.W || v >= c.H) return;
-    float rx, ry;
-    dn_ray(c, u, v, rx, ry);
-    Vec3 ga, gb;
-    float acc = 0.f;
-    // this pixel is the RIGHT point of (u - 1, v), the LEFT point of (u + 1, v), the TOP point of (u, v + 1), the BOTTOM point of (u, v - 1)
-    if (u >= 1)       { dn_grad_edges(c, depth, g, u - 1, v, ga, gb); acc += ga.x * rx + ga.y * ry + ga.z; }
-    if (u + 1 < c.W)  { dn_grad_edges(c, depth, g, u + 1, v, ga, gb); acc -= ga.x * rx + ga.y * ry + ga.z; }
-    if (v + 1 < c.H)  { dn_grad_edges(c, depth, g, u, v + 1, ga, gb); acc += gb.x * rx + gb.y * ry + gb.z; }
-    if (v >= 1)       { dn_grad_edges(c, depth, g, u, v - 1, ga, gb); acc -= gb.x * rx + gb.y * ry + gb.z; }
-    gdepth[(size_t)v * c.W + u] = acc;
+    __shared__ float s_ga[3][DN_TH][DN_TW + 2];          // dL/da of pixels (u0 - 1 .. u0 + 64, v0 .. v0 + 7)
+    __shared__ float s_gb[3][DN_TH + 2][DN_TW];          // dL/db of pixels (u0 .. u0 + 63, v0 - 1 .. v0 + 8)
+    const int u0 = blockIdx.x * DN_TW, v0 = blockIdx.y * DN_TH, tid = threadIdx.x;
+    constexpr int OWN = DN_TW * DN_TH, HALO_A = 2 * DN_TH, HALO_B = 2 * DN_TW;
+    for (int j = tid; j < OWN + HALO_A + HALO_B; j += 256) {
+        int lx, ly;          // tile coordinates; -1 / DN_TW and -1 / DN_TH are the halo
+        if (j < OWN) { lx = j % DN_TW; ly = j / DN_TW; }
+        else if (j < OWN + HALO_A) { const int k = j - OWN; ly = k >> 1; lx = (k & 1) ? DN_TW : -1; }
+        else { const int k = j - OWN - HALO_A; lx = k % DN_TW; ly = (k / DN_TW) ? DN_TH : -1; }
+        Vec3 ga, gb;
+        dn_grad_edges(c, depth, g, u0 + lx, v0 + ly, ga, gb);          // (zero outside the image's interior)
+        if (ly >= 0 && ly < DN_TH) { s_ga[0][ly][lx + 1] = ga.x; s_ga[1][ly][lx + 1] = ga.y; s_ga[2][ly][lx + 1] = ga.z; }
+        if (lx >= 0 && lx < DN_TW) { s_gb[0][ly + 1][lx] = gb.x; s_gb[1][ly + 1][lx] = gb.y; s_gb[2][ly + 1][lx] = gb.z; }
+    }
+    __syncthreads();
+    for (int j = tid; j < OWN; j += 256) {
+        const int lx = j % DN_TW, ly = j / DN_TW, u = u0 + lx, v = v0 + ly;
+        if (u >= c.W || v >= c.H) continue;
+        float rx, ry;
+        dn_ray(c, u, v, rx, ry);
+        float acc = 0.f;
+        // this pixel is the RIGHT point of (u - 1, v), the LEFT point of (u + 1, v), the TOP point of (u, v + 1), the BOTTOM point of (u, v - 1)
+        if (u >= 1)       acc += s_ga[0][ly][lx] * rx + s_ga[1][ly][lx] * ry + s_ga[2][ly][lx];
+        if (u + 1 < c.W)  acc -= s_ga[0][ly][lx + 2] * rx + s_ga[1][ly][lx + 2] * ry + s_ga[2][ly][lx + 2];
+        if (v + 1 < c.H)  acc += s_gb[0][ly + 2][lx] * rx + s_gb[1][ly + 2][lx] * ry + s_gb[2][ly + 2][lx];
+        if (v >= 1)       acc -= s_gb[0][ly][lx] * rx + s_gb[1][ly][lx] * ry + s_gb[2][ly][lx];
+        gdepth[(size_t)v * c.W + u] = acc;
+    }
 }
 
 static bool dn_cam(DnCam& c, int W, int H, float fx, float fy, float cx, float cy)
@@ -137,7 +158,7 @@ int32_t ibgs_depth_normal_backward(void* stream, int32_t W, int32_t H, float fx,
 {
     DnCam c;
     if (!dn_cam(c, W, H, fx, fy, cx, cy) || !depth || !dL_dnormal || !dL_ddepth) { set_error("depth_normal backward: bad size / intrinsics / null pointer"); return -IBGS_ERR_INVALID; }
-    hipLaunchKernelGGL(depth_normal_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c, depth, dL_dnormal, dL_ddepth);
+    hipLaunchKernelGGL(depth_normal_bwd_kernel, dim3((W + DN_TW - 1) / DN_TW, (H + DN_TH - 1) / DN_TH), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), c, depth, dL_dnormal, dL_ddepth);
     IBGS_HIP(hipGetLastError());
     return 0;
 }
