@@ -144,11 +144,17 @@ def profile_counters(kernel_substr, workload_tag):
 
 
 def step_traffic_measured(workload_tag):
-    """HBM bytes of one step as the PMC passes measured them (profiles/summarize.py: sum over the library's kernels), quoted only while EVERY
-    translation unit of the library is what it was when the passes ran."""
+    """HBM bytes of one step as the PMC passes measured them (profiles/summarize.py: sum over the library's kernels), quoted only while every translation
+    unit THAT HOLDS ONE OF THE SUMMED KERNELS is what it was when the passes ran (round 6: until then every unit of the library had to be -- an edit of
+    depth_normal.hip, whose kernels no bench step launches, dropped the figure)."""
     now = tu_shas()
     for d in _profiles_for(workload_tag):
-        if "step_traffic_measured" in d and ((d.get("tu_shas") or {}) == now or d.get("csrc_sha") == csrc_sha()):
+        if "step_traffic_measured" not in d:
+            continue
+        stamp = d.get("tu_shas") or {}
+        units = {tu_of(k) for k in (d["step_traffic_measured"].get("by_kernel") or {})}
+        fresh = bool(units) and None not in units and all(stamp.get(u) is not None and stamp.get(u) == now.get(u) for u in units)
+        if fresh or stamp == now or d.get("csrc_sha") == csrc_sha():
             return {"bytes_per_step": d["step_traffic_measured"]["bytes_per_step"], "source": "profiles/%s_counters.json (%s)" % (d.get("tag"), d.get("date", "?")),
                     "how": d["step_traffic_measured"].get("how")}
     return None

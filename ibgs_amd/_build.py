@@ -64,7 +64,7 @@ def csrc_sha():
 KERNEL_TU = (("render_fwd", "render_fwd"), ("pack_rgba", "render_fwd"), ("render_bwd", "render_bwd"), ("geo_window", "render_bwd"), ("tile_order", "render_bwd"),
              ("preprocess_bwd", "preprocess_bwd"), ("sh_grad", "preprocess_bwd"), ("preprocess_kernel", "preprocess"), ("sh_color", "preprocess"), ("mark_visible", "preprocess"),
              ("onesweep", "scan_sort"), ("radix", "scan_sort"), ("scan_", "scan_sort"), ("cell_", "binning"), ("expand_", "binning"), ("tile_ranges", "binning"),
-             ("l1_", "loss"), ("depth_normal", "depth_normal"), ("activate_", "activate"), ("adam", "adam"), ("compact", "compact"), ("det_", "deterministic"), ("knn", "knn"))
+             ("rendered_note", "api"), ("l1_", "loss"), ("depth_normal", "depth_normal"), ("activate_", "activate"), ("adam", "adam"), ("compact", "compact"), ("det_", "deterministic"), ("knn", "knn"))
 
 
 def tu_of(kernel_name):
