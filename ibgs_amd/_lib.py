@@ -24,6 +24,7 @@ FLAG_TEX_PACKED = 256
 FLAG_NO_REF_POWER_SKIP = 512
 FLAG_NO_ABS_GRAD = 1024
 FLAG_REF_ARITH = 4096
+FLAG_SRC_DEPTH_SLOTS = 8192
 PLANE_NONE, PLANE_LEARNT, PLANE_SMALLEST_AXIS = 0, 1, 2
 MAX_VIEWS = 8
 
@@ -60,6 +61,7 @@ class ForwardArgs(ctypes.Structure):
         ("tile_order_hint", ctypes.c_void_p),
         ("binning", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
         ("shs_rest", c_float_p),
+        ("src_depth_slot", ctypes.c_int32 * 5),
     ]
 
 

@@ -360,6 +360,9 @@ int64_t ibgs_forward(const ibgs_forward_args* ap)
     if (a.render_geo) {
         if (a.n_src < 1 || a.n_src > IBGS_MAX_SRC) { set_error("n_src %d outside 1..%d", a.n_src, IBGS_MAX_SRC); return -IBGS_ERR_INVALID; }
         if (!a.ref_to_src || !a.src_cam_pos || !a.src_images || !a.src_depths) { set_error("source view pointers required for render_geo"); return -IBGS_ERR_INVALID; }
+        if (a.flags & IBGS_FLAG_SRC_DEPTH_SLOTS) {
+            for (int m = 0; m < a.n_src; m++) if (a.src_depth_slot[m] < 0) { set_error("src_depth_slot[%d] = %d is negative", m, a.src_depth_slot[m]); return -IBGS_ERR_INVALID; }
+        }
         if (!a.out_normal || !a.out_cam_feat || !a.out_warped || !a.out_min_depth_diff || !a.out_camera_ray || !a.out_mask) { set_error("geo outputs required"); return -IBGS_ERR_INVALID; }
         if (!a.tex || a.tex_bytes < ibgs_required_tex(a.n_src, a.W, a.H)) { set_error("tex scratch too small"); return -IBGS_ERR_ALLOC; }
     }

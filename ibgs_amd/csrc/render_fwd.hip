@@ -37,6 +37,7 @@ struct FwdParams {
     int n_src; int L; float thr; int tex_quant;
     int power_skip;      // reproduce the reference's `power > 0` skip for near-singular conics (common.h)
     const float* ref_to_src; const float* src_cam_pos; const float4* src_rgba; const float* src_depths;
+    int ds0, ds1, ds2, ds3, ds4;          // plane of src_depths that source 0..4 reads (IBGS_FLAG_SRC_DEPTH_SLOTS; else 0..4) -- scalars, not an array: a run-time index must stay a select chain
     // per-pixel state
     float* final_T; uint32_t* n_contrib; float* sum_w; uint32_t* low_high; int32_t* valid_idx; float* valid_w; uint32_t* slot_c; uint32_t* meta; uint32_t* walked;
     uint32_t* risky;          // ImgState::tile_risky (4 words per tile): this wave staged a record whose conic is near-singular
@@ -482,7 +483,7 @@ __device__ __forceinline__ void render_fwd_body(const FwdParams& p, const int ti
                     izm = 1.0f / (tzm + eps);
                     const float u = tx * fx * izm + cx, v = ty * fy * izm + cy;
                     if (u >= 0.0f && u <= (float)(W - 1) && v >= 0.0f && v <= (float)(H - 1))
-                        wdep = tex_depth(p.src_depths + (size_t)si * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
+                        wdep = tex_depth(p.src_depths + (size_t)(si == 0 ? p.ds0 : si == 1 ? p.ds1 : si == 2 ? p.ds2 : si == 3 ? p.ds3 : p.ds4) * HW, W, H, u + 0.5f, v + 0.5f, p.tex_quant);
                     err = fabsf(wdep - tzm) * izm;
                 }
                 if (!(wdep > 0.0f && err < p.thr)) continue;
@@ -612,6 +613,11 @@ int launch_render_forward(hipStream_t s, const ibgs_forward_args& a, const GeomS
     p.tex_quant = (a.flags & IBGS_FLAG_TEX_QUANT) ? 1 : 0;
     p.power_skip = (a.flags & IBGS_FLAG_NO_REF_POWER_SKIP) ? 0 : 1;
     p.ref_to_src = a.ref_to_src; p.src_cam_pos = a.src_cam_pos; p.src_rgba = src_rgba; p.src_depths = a.src_depths;
+    {   // the depth plane of every source: its own number, or the caller's table slot
+        const bool slots = (a.flags & IBGS_FLAG_SRC_DEPTH_SLOTS) != 0;
+        p.ds0 = slots ? a.src_depth_slot[0] : 0; p.ds1 = slots ? a.src_depth_slot[1] : 1; p.ds2 = slots ? a.src_depth_slot[2] : 2;
+        p.ds3 = slots ? a.src_depth_slot[3] : 3; p.ds4 = slots ? a.src_depth_slot[4] : 4;
+    }
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.sum_w = im.sum_w; p.low_high = im.low_high;
     p.valid_idx = im.valid_idx; p.valid_w = im.valid_w; p.slot_c = im.slot_c; p.meta = im.meta; p.walked = im.tile_walked; p.risky = im.tile_risky; p.order = nullptr;
     p.out_color = a.out_color; p.out_normal = a.out_normal; p.out_depth = a.out_depth; p.out_cam_feat = a.out_cam_feat;

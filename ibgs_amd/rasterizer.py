@@ -19,7 +19,7 @@ import weakref
 import ctypes
 import os
 import threading
-from typing import NamedTuple
+from typing import NamedTuple, Optional
 
 import torch
 import torch.nn as nn
@@ -392,10 +392,12 @@ class _CModule:
                             cov3D_precomp, all_map, viewmatrix, projmatrix, ref_to_src_list, src_cam_pos,
                             src_images, src_rendered_depths, nb_src_images, buffer_length,
                             depth_error_threshold, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, render_geo, render_depth_only, debug, plane=None, sh_rest=None):
+                            campos, prefiltered, render_geo, render_depth_only, debug, plane=None, sh_rest=None, depth_slots=None):
         """The reference's 29 positional arguments; `plane` = (raw_normal or None, raw_offset or None, mode) is this
         library's extension (fused plane-map glue, include/ibgs_rast.h) and replaces `all_map`; `sh_rest`: `sh` holds the DC coefficient only
-        (P, 1, 3) and `sh_rest` the others (P, M - 1, 3) -- the model's two arrays instead of their torch.cat (ibgs_forward_args.shs_rest)."""
+        (P, 1, 3) and `sh_rest` the others (P, M - 1, 3) -- the model's two arrays instead of their torch.cat (ibgs_forward_args.shs_rest);
+        `depth_slots`: `src_rendered_depths` is a table of depth planes (the trainer's depth cache) and source m reads plane depth_slots[m] of it
+        (IBGS_FLAG_SRC_DEPTH_SLOTS: no stack of the n_src planes is built per call)."""
         lib = _lib.load()
         if means3D.ndimension() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:69-71
@@ -478,7 +480,15 @@ class _CModule:
                 if render_geo:
                     if simg_c is None or simg_c.numel() < int(nb_src_images) * 3 * H * W:
                         raise RuntimeError("src_images must hold nb_src_images x 3 x H x W values")
-                    if sdep_c is None or sdep_c.numel() < int(nb_src_images) * H * W:
+                    if depth_slots is not None:
+                        slots = [int(x) for x in depth_slots]
+                        if len(slots) < int(nb_src_images) or min(slots[:int(nb_src_images)]) < 0:
+                            raise RuntimeError("depth_slots must name one non-negative plane per source")
+                        if sdep_c is None or sdep_c.numel() < (max(slots[:int(nb_src_images)]) + 1) * H * W:
+                            raise RuntimeError("src_rendered_depths (a table of planes) does not hold plane %d" % max(slots[:int(nb_src_images)]))
+                        for m_ in range(M_SRC):
+                            a.src_depth_slot[m_] = slots[m_] if m_ < int(nb_src_images) else 0
+                    elif sdep_c is None or sdep_c.numel() < int(nb_src_images) * H * W:
                         raise RuntimeError("src_rendered_depths must hold nb_src_images x 1 x H x W values")
                     # the packed RGBA of the sources goes to the per-stream scratch; the ticket lets the backward of this call
                     # skip its own pack when no other geo call used the scratch in between (the training loop's normal case)
@@ -492,7 +502,8 @@ class _CModule:
                         tex, _CModule.last_tex = _tex_packed(device, nbytes, source)
                     a.tex = tex.data_ptr(); a.tex_bytes = tex.numel()
                 a.flags = ((_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_TEX_QUANT if TEX_QUANT else 0)
-                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL) | _shape_flag() | tex_flag)
+                           | (0 if TILE_CULL else _lib.FLAG_NO_TILE_CULL) | _shape_flag() | tex_flag
+                           | (_lib.FLAG_SRC_DEPTH_SLOTS if (render_geo and depth_slots is not None) else 0))
                 a.out_color = out_color.data_ptr() if write_color else None
                 a.radii = radii.data_ptr()
                 if render_geo:
@@ -803,6 +814,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         kw = {"plane": plane} if plane is not None else {}
         if sh_rest is not None:
             kw["sh_rest"] = sh_rest
+        if raster_settings.render_geo and getattr(raster_settings, "src_depth_slots", None) is not None:
+            kw["depth_slots"] = raster_settings.src_depth_slots
         # argument order of the reference's _C.rasterize_gaussians (reference __init__.py:66-98)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -915,6 +928,10 @@ class GaussianRasterizationSettings(NamedTuple):
     render_geo: bool
     render_depth_only: bool
     debug: bool
+    # this library's extension (the reference's settings end with `debug`): `src_rendered_depths` is a TABLE of depth planes -- e.g. the trainer's depth cache
+    # scene.rendered_depth_list, one plane per training camera -- and source m reads plane src_depth_slots[m] of it; what the reference obtains by indexing the
+    # cache (a copy of n_src planes per call, gaussian_renderer/__init__.py:255).  None: src_rendered_depths holds exactly the n_src planes, in order.
+    src_depth_slots: Optional[tuple] = None
 
 
 class GaussianRasterizer(nn.Module):

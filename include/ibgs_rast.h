@@ -97,6 +97,7 @@ typedef char* (*ibgs_alloc_fn)(size_t bytes, void* user);
                                      chain (backward.cu:405-420), without its cancellation: 3-10 x closer to a float64 evaluation than ANY fp32 evaluation of the reference's own
                                      expressions (profiles/r06_ref_arith_ab.txt).  With this flag they are formed exactly as the reference forms them: the eight per-pair quantities of
                                      backward.cu:779-804 in its association, uncontracted, and the chain of :405-420 on their sums.  Every other Gaussian: unchanged */
+#define IBGS_FLAG_SRC_DEPTH_SLOTS 8192u /* ibgs_forward only: src_depths is a table of planes, source m reads plane src_depth_slot[m] (ibgs_forward_args) */
 #define IBGS_FLAG_NO_ABS_GRAD 1024u /* ibgs_backward only: dL_dmean2D_abs is not wanted (it may be NULL and is not written).  It is the densification statistic of
                                        train.py:400-410 (sum over pixels of |dL/dmean2D| per Gaussian, backward.cu:793-804): nobody reads it after
                                        densify_until_iter or at test time.  The colour blend then skips the two |.| moments (conic x d per quadrant, two fma per
@@ -206,6 +207,10 @@ typedef struct ibgs_forward_args {
      * torch.cat of scene/gaussian_model.py:140-143 (192 B read + written per Gaussian and call at M = 16, and its mirror image in the backward).  Both 16-byte aligned.
      * Results are bit-identical to the concatenated form. */
     const float* shs_rest;
+    /* IBGS_FLAG_SRC_DEPTH_SLOTS (round 6): `src_depths` is a TABLE of depth planes (any number of H x W planes, e.g. the trainer's depth cache
+     * scene.rendered_depth_list: one plane per training camera) and source m's plane is number src_depth_slot[m] of it -- what the reference gets by indexing,
+     * rendered_depth_list[src_idx] (gaussian_renderer/__init__.py:255), i.e. by a copy of n_src planes per call.  Without the flag the field is ignored. */
+    int32_t src_depth_slot[IBGS_MAX_SRC];
 } ibgs_forward_args;
 
 typedef struct ibgs_backward_args {

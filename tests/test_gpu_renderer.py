@@ -259,3 +259,58 @@ def test_render_keeps_source_stacks_and_poses_per_camera():
             assert seen[-1].src_images is not seen[-2].src_images and d["render"].shape == a["render"].shape
     finally:
         renderer.GaussianRasterizer = real
+
+
+def test_depth_cache_as_a_table_equals_the_stacked_source_depths():
+    """`render()` hands the rasterizer the depth cache itself + the sources' plane numbers (IBGS_FLAG_SRC_DEPTH_SLOTS, renderer.DEPTH_TABLE) instead of stacking
+    the n_src planes per call as the reference's indexing does: every output and every gradient bit-identical (deterministic backward), sources taken from
+    NON-consecutive planes in a non-ascending order, and the cache may be overwritten between forward and backward (train.py:298-299 writes it right after the render)."""
+    from ibgs_amd import rasterizer
+    dev, g, pc, cams, scene = _setup(P=4000, W=208, H=144, n_views=7, seed=9)
+    pipe, args = simple_scene.default_pipe(), simple_scene.default_args()
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        scene.rendered_depth_list = renderer.render_depth_batch(cams, pc, scene, pipe, args, bg, True, 3, 4)
+    assert torch.is_tensor(scene.rendered_depth_list) and scene.rendered_depth_list.is_contiguous()
+    cam = cams[2]
+    cam.nearest_id = list(reversed([int(i) for i in cam.nearest_id]))          # the neighbours' planes of the table, in descending order (a stack would hold them as 0, 1, 2)
+    assert len(cam.nearest_id) == 3 and cam.nearest_id != sorted(cam.nearest_id)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    up = {k: torch.randn(s, device=dev, generator=gen) for k, s in (("render", (3, 144, 208)), ("rendered_normal", (3, 144, 208)), ("median_intersected_depth", (1, 144, 208)),
+                                                                      ("warped_image", (15, 144, 208)))}
+    params = [pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation, pc._normal, pc._offset]
+    old = (renderer.DEPTH_TABLE, rasterizer.DETERMINISTIC)
+    rasterizer.DETERMINISTIC = True
+    try:
+        res = []
+        for table in (False, True):
+            renderer.DEPTH_TABLE = table
+            out = renderer.render(cam, pc, scene, pipe, args, bg, learnt_normal=True, nb_src_frames=3, buffer_length=4, render_geo=True, return_depth_normal=False)
+            loss = sum((out[k] * up[k]).sum() for k in up)
+            if table:          # the trainer's order: the cache entry of this camera is rewritten BEFORE the backward runs (the backward reads no source depth)
+                with torch.no_grad():
+                    scene.rendered_depth_list[2] = out["median_intersected_depth"].detach()
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append(({k: out[k].detach().clone() for k in ("render", "rendered_normal", "median_intersected_depth", "cam_feat", "warped_image", "min_depth_diff",
+                                                              "use_first_src_frame_mask")}, [p.grad.clone() for p in params]))
+            for p in params:
+                p.grad = None
+        (oa, ga), (ob, gb) = res
+        assert int((oa["cam_feat"].view(5, 4, 144, 208).abs().sum(1) > 0).sum()) > 200          # sources really are valid somewhere (random plane parameters: few pixels pass the depth test)
+        for k in oa:
+            assert torch.equal(oa[k], ob[k]), k
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+        # ... and the comparison can see a wrong plane: the same sources reading each other's depth planes give another answer
+        renderer.DEPTH_TABLE = True
+        real = renderer.GaussianRasterizationSettings
+        try:
+            renderer.GaussianRasterizationSettings = lambda **kw: real(**dict(kw, src_depth_slots=tuple(kw["src_depth_slots"][1:] + kw["src_depth_slots"][:1])))
+            with torch.no_grad():
+                oc = renderer.render(cam, pc, scene, pipe, args, bg, learnt_normal=True, nb_src_frames=3, buffer_length=4, render_geo=True, return_depth_normal=False)
+        finally:
+            renderer.GaussianRasterizationSettings = real
+        assert not torch.equal(oc["cam_feat"], ob["cam_feat"])
+    finally:
+        renderer.DEPTH_TABLE, rasterizer.DETERMINISTIC = old

@@ -14,7 +14,10 @@ def test_settings_fields_match_reference_order():
     want = ["image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
             "ref_to_src_list", "src_cam_pos", "src_images", "src_rendered_depths", "nb_src_images", "buffer_length",
             "depth_error_threshold", "sh_degree", "campos", "prefiltered", "render_geo", "render_depth_only", "debug"]
-    assert list(dpr.GaussianRasterizationSettings._fields) == want
+    fields = list(dpr.GaussianRasterizationSettings._fields)
+    assert fields[:len(want)] == want
+    # ... followed only by this library's extensions, every one with a default: the reference's own 21-argument construction keeps working (`_settings()` below)
+    assert fields[len(want):] == ["src_depth_slots"] and set(fields[len(want):]) <= set(dpr.GaussianRasterizationSettings._field_defaults)
     assert dpr.GaussianRasterizer is rasterizer.GaussianRasterizer
     assert hasattr(dpr, "_C") and hasattr(dpr._C, "rasterize_gaussians") and hasattr(dpr._C, "mark_visible")
 
