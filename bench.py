@@ -604,7 +604,9 @@ class TrainIteration:
         k = self.it % 8
         self.it += 1
         st, scene = self.st, self.scene
+        self.renderer.LEAF_SINKS = self.sh_factored          # (the tuned twins also take the opt-in leaf sinks: no retain_grad() clones of the two (P, 3) sink gradients)
         out = self.renderer.render(self.cams[k], self.pc, scene, self.pipe, self.args, self.bg, True, 4, 4, render_geo=True, return_depth_normal=True)
+        self.renderer.LEAF_SINKS = False
         gt = scene.original_image_list[k]
         loss = torch.abs(out["render"] - gt).mean()
         if self.full:
@@ -681,7 +683,8 @@ def train_iter(dev, c, steps):
                                 "(train.py:309-316) + multi-view photometric L1 on 3 sources (train.py:319-338), all four upstream gradients reach the rasterizer backward and the depth -> normal "
                                 "backward runs; NOT included: the two SSIM terms (out of scope) and the colour-aggregation network.  *_sh_factored: the same two iterations with the trainer's "
                                 "backward inside `rasterizer.capture_sh_factors()` and `optimizer.step(sh_factors=...)`: the dense dL/dsh (192 B per Gaussian) is neither written by the "
-                                "backward nor read by the optimiser; parameters bit-identical to the expanded gradient's (tests/test_gpu_adam.py)")
+                                "backward nor read by the optimiser; parameters bit-identical to the expanded gradient's (tests/test_gpu_adam.py); and `renderer.LEAF_SINKS = True` (the two gradient sinks "
+                                "as leaf aliases: no retain_grad() clones)")
     res["steps"] = steps
     return res
 

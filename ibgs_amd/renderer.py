@@ -185,7 +185,10 @@ TRACK_ABS_GRAD = True
 # fills and two adds of a (P, 3) tensor whose VALUES nobody reads (the rasterizer uses neither; train.py:404-405 reads `.grad` only).  SHARED_SINKS: the
 # zeros are ONE cached read-only buffer per (device, P), and each call gets two fresh non-leaf views of it through a no-op autograd node -- same
 # properties (zeros, requires_grad, not a leaf, retain_grad() works, `.grad` receives dL/dmean2D), no kernel.  False = the reference's expression.
+# LEAF_SINKS (opt-in, round 6): the two aliases are leaves instead -- everything a reader of `.grad` sees is the same, `is_leaf` is not (tests/test_glue_golden.py pins
+# the reference's value of it, hence not the default); saves the two (P, 3) clones per iteration that a non-leaf's retain_grad() hook makes.
 SHARED_SINKS = True
+LEAF_SINKS = False         # (round 6, opt-in) True: the two sinks are LEAF aliases of the shared zeros; False: non-leaf views with retain_grad(), like the reference's `zeros + 0`
 _sink_zeros = {}
 
 
@@ -214,6 +217,12 @@ def _sinks(pc):
             ent = _sink_zeros[key] = (torch.zeros_like(xyz, requires_grad=False), torch.zeros(1, device=xyz.device, requires_grad=True),
                                       torch.zeros((1,) + tuple(xyz.shape[1:]), dtype=xyz.dtype, device=xyz.device).expand(tuple(xyz.shape)))
         z, anchor, z_ro = ent
+        if LEAF_SINKS:
+            # a fresh LEAF alias of the shared zeros per call: `.grad` is then filled by autograd's AccumulateGrad, which takes the backward's tensor as it is; the
+            # retain_grad() hook of a non-leaf (the reference's `zeros + 0`, and _SinkView below) CLONES it -- two (P, 3) copies per iteration that nobody needs
+            a = z.detach().requires_grad_(True)
+            b = z.detach().requires_grad_(True) if TRACK_ABS_GRAD else z_ro
+            return a, b
         a = _SinkView.apply(z, anchor)
         b = _SinkView.apply(z, anchor) if TRACK_ABS_GRAD else z_ro
         if a.requires_grad:          # (not under torch.no_grad(): render.py:297)

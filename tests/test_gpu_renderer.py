@@ -314,3 +314,28 @@ def test_depth_cache_as_a_table_equals_the_stacked_source_depths():
         assert not torch.equal(oc["cam_feat"], ob["cam_feat"])
     finally:
         renderer.DEPTH_TABLE, rasterizer.DETERMINISTIC = old
+
+
+def test_leaf_sinks_receive_the_same_gradients():
+    """renderer.LEAF_SINKS (opt-in): `viewspace_points(_abs).grad` -- all the trainer reads of the two sinks (train.py:400-405) -- is the same tensor of numbers
+    whether the sinks are the reference's non-leaf `zeros + 0` with retain_grad() or leaf aliases of the shared zeros."""
+    from ibgs_amd import rasterizer
+    dev, g, pc, cams, scene = _setup(P=3000, W=160, H=112, n_views=4, seed=7)
+    pipe, args = simple_scene.default_pipe(), simple_scene.default_args()
+    bg = torch.zeros(3, device=dev)
+    tgt = torch.rand(3, 112, 160, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    old = (renderer.LEAF_SINKS, rasterizer.DETERMINISTIC)
+    rasterizer.DETERMINISTIC = True
+    try:
+        got = []
+        for leaf in (False, True):
+            renderer.LEAF_SINKS = leaf
+            out = renderer.render(cams[1], pc, scene, pipe, args, bg, learnt_normal=True, nb_src_frames=3, buffer_length=4, render_geo=False, return_depth_normal=False)
+            assert out["viewspace_points"].is_leaf == leaf and out["viewspace_points"].requires_grad and not out["viewspace_points"].any()
+            (out["render"] - tgt).abs().mean().backward()
+            got.append((out["viewspace_points"].grad.clone(), out["viewspace_points_abs"].grad.clone(), pc._xyz.grad.clone()))
+            pc._xyz.grad = None
+        for a, b in zip(*got):
+            assert torch.equal(a, b) and a.abs().sum() > 0
+    finally:
+        renderer.LEAF_SINKS, rasterizer.DETERMINISTIC = old
