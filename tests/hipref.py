@@ -64,7 +64,9 @@ def run_forward(inp, dev="cuda", debug=False, requires_grad=True):
 def internal_state(outs, inp):
     """Pull the arena arrays out of the autograd node of `outs['color']` (saved tensors)."""
     lib = _lib.load()
-    node = outs["color"].grad_fn
+    node = next((outs[k].grad_fn for k in ("color", "median_depth", "normal_map") if outs.get(k) is not None and outs[k].grad_fn is not None), None)          # (a depth-only pass has no colour)
+    if node is None:
+        raise RuntimeError("internal_state needs outputs of a forward that recorded a graph (run_forward(..., requires_grad=True) outside torch.no_grad())")
     saved = node.saved_tensors
     geom, binning, img = saved[-3], saved[-2], saved[-1]
     P = inp["means3D"].shape[0]; W, H = int(inp["W"]), int(inp["H"]); HW = W * H
